@@ -1,0 +1,161 @@
+/*
+ * rsbwt.h -- C-ABI of the MI355X population-BWT engine (librsbwt.so).
+ *
+ * Drop-in boundary for ReadServer's src/bwt backward-search path.  Every entry point
+ * names the reference interface it replaces (paths relative to the ReadServer tree).
+ * Plain pointers and sizes only; no C++ or torch types.  All functions returning int
+ * give RSBWT_OK (0) or a negative RSBWT_E* code and never call exit() (the reference
+ * exits on a bad file: src/bwt/rlebwt_reader.cpp:31-34).
+ *
+ * Conventions kept from the reference:
+ *   - symbols are ASCII '$','A','C','G','T' (include/bwt/alphabet.h:8-9);
+ *   - intervals are inclusive SA-row ranges [lower, upper], empty <=> lower > upper
+ *     (include/bwt/query.h:8-11, src/bwt/query.cpp:35);
+ *   - a k-mer holding a symbol outside ACGT, or k == 0, yields lower = 1, upper = 0 and
+ *     count 0 (callers filter these in the reference: src/service/service.cpp:299-301);
+ *   - count = upper >= lower ? upper - lower + 1 : 0 (src/service/service.cpp:304).
+ *
+ * The engine is the HIP path only: there is no CPU fallback.  Every call that needs the
+ * GPU fails with RSBWT_ENODEV when none is usable.
+ *
+ * Thread safety: a handle may be queried concurrently from several host threads (the
+ * reference shares one BWT* across its pool threads, src/service/service.cpp:1513).
+ * Host-buffer calls serialise on the handle's internal stream and staging buffers;
+ * *_dev calls only enqueue work on the caller's stream.
+ */
+#ifndef RSBWT_H
+#define RSBWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSBWT_OK 0
+#define RSBWT_EINVAL (-1)  /* bad argument                                   */
+#define RSBWT_EIO (-2)     /* file missing / short / unreadable              */
+#define RSBWT_EFORMAT (-3) /* not an SGA RLE .bwt (magic 0xCACA) or corrupt  */
+#define RSBWT_ENOMEM (-4)  /* host or HBM allocation failed                  */
+#define RSBWT_ENODEV (-5)  /* no usable HIP device                           */
+#define RSBWT_EHIP (-6)    /* a HIP runtime call failed (see rsbwt_last_error) */
+#define RSBWT_ERANGE (-7)  /* shard exceeds format limits (2^40 symbols)     */
+
+/* open flags */
+#define RSBWT_DIR_SHIFT_AUTO 0u /* low 5 bits: log2 symbols per directory window, 0 = auto */
+#define RSBWT_DIR_SHIFT_MASK 0x1Fu
+
+typedef struct rsbwt rsbwt_t;         /* one BWT shard resident in one GPU's HBM */
+typedef struct rsbwt_set rsbwt_set_t; /* several shards on this process's GPU(s) */
+
+/* Library / environment ------------------------------------------------------------ */
+const char *rsbwt_version(void);
+int rsbwt_device_count(void);           /* number of visible HIP devices, 0 if none */
+const char *rsbwt_last_error(void);     /* thread-local message of the last failure */
+const char *rsbwt_strerror(int code);
+
+/* Index lifetime ---------------------------------------------------------------------
+ * rsbwt_open replaces  RLEBWT::RLEBWT(const std::string& filename, int smallSampleRate)
+ * (include/bwt/rlebwt.h:17, src/bwt/rlebwt.cpp:11-32): reads the SGA .bwt file
+ * (src/bwt/rlebwt_reader.cpp:27-48), uploads the run bytes and builds the device index in
+ * HBM.  A "<file>.bpi2" next to it is ignored: the device index is derived from the runs. */
+int rsbwt_open(const char *bwt_path, int device, uint32_t flags, rsbwt_t **out);
+/* Same from run bytes in host memory (RLUnit bytes, include/bwt/rlunit.h:8-11). */
+int rsbwt_open_runs(const uint8_t *runs, uint64_t num_runs, uint64_t num_strings,
+                    int device, uint32_t flags, rsbwt_t **out);
+/* Same from run bytes already in HBM on `device` (not retained after the call). */
+int rsbwt_open_device_runs(const void *d_runs, uint64_t num_runs, uint64_t num_strings,
+                           int device, uint32_t flags, rsbwt_t **out);
+/* Replaces the owner's unique_ptr<BWT> release (src/service/service.cpp:1513). */
+void rsbwt_close(rsbwt_t *h);
+
+/* class BWT mirrors (include/bwt/bwt.h:6-15), one value per call ---------------------- */
+uint64_t rsbwt_bwlen(const rsbwt_t *h);               /* BWT::getBWLen, rlebwt.cpp:303-305 */
+uint64_t rsbwt_pc(const rsbwt_t *h, char b);          /* BWT::getPC,    rlebwt.cpp:229-231 */
+char rsbwt_f(const rsbwt_t *h, uint64_t index);       /* BWT::getF,     rlebwt.cpp:307-314 */
+int rsbwt_occ(rsbwt_t *h, char b, uint64_t index, uint64_t *occ);   /* BWT::getOcc,  rlebwt.cpp:268-301 */
+int rsbwt_char(rsbwt_t *h, uint64_t index, char *c);                /* BWT::getChar, rlebwt.cpp:202-227 */
+int rsbwt_occ_at(rsbwt_t *h, char b, uint64_t bc, uint64_t *index); /* BWT::getOccAt, rlebwt.cpp:233-266 */
+
+/* batched forms of the same (host buffers) */
+int rsbwt_occ_batch(rsbwt_t *h, const char *b, const uint64_t *index, size_t n, uint64_t *occ);
+int rsbwt_char_batch(rsbwt_t *h, const uint64_t *index, size_t n, char *c);
+int rsbwt_occ_at_batch(rsbwt_t *h, const char *b, const uint64_t *bc, size_t n, uint64_t *index);
+
+/* Shape of the resident index */
+uint64_t rsbwt_num_runs(const rsbwt_t *h);
+uint64_t rsbwt_num_strings(const rsbwt_t *h);
+uint64_t rsbwt_num_blocks(const rsbwt_t *h);
+uint32_t rsbwt_dir_shift(const rsbwt_t *h);
+uint64_t rsbwt_hbm_bytes(const rsbwt_t *h); /* blocks + directory + tables */
+int rsbwt_device(const rsbwt_t *h);
+
+/* query.h mirrors, batched (include/bwt/query.h:18-32) ---------------------------------
+ * rsbwt_find_intervals replaces  BWTInterval findInterval(const BWT*, const std::string& w)
+ * (src/bwt/query.cpp:24-41) for Q k-mers at once: k-mer q is the k ASCII bytes at
+ * kmers + q*stride (stride >= k).  lower/upper receive Q values each. */
+int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                         uint64_t *lower, uint64_t *upper);
+/* Replaces the count in count_reads (src/service/service.cpp:303-304). */
+int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                uint64_t *counts);
+
+/* Device-resident forms: all pointers are HBM addresses on the handle's device, `stream` is a
+ * hipStream_t (NULL = the null stream).  Nothing is synchronised. ------------------------ */
+/* ASCII k-mers -> 2-bit packed words (A,C,G,T = 0..3, symbol i at bits 2*(i%32) of word i/32,
+ * ceil(k/32) words per k-mer) + one validity byte per k-mer (0 = holds a non-ACGT symbol). */
+int rsbwt_pack_kmers_dev(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
+                         void *d_packed, void *d_valid, int device, void *stream);
+int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q,
+                             uint32_t k, void *d_lower, void *d_upper, void *stream);
+int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                    void *d_counts, void *stream);
+
+/* Measurement hooks (bench.py): wall time of the last search kernel launched through this
+ * handle, from HIP events recorded on the launch stream; synchronises on the stop event. */
+int rsbwt_last_search_ms(rsbwt_t *h, float *ms);
+/* The same for up to `cap` of the most recent launches (the handle keeps 64 event pairs), oldest
+ * first; *count receives how many were written. */
+int rsbwt_search_history_ms(rsbwt_t *h, float *ms, size_t cap, size_t *count);
+/* Exact work counters of the last rsbwt_find_intervals_dev launch when the handle was put
+ * in counting mode with rsbwt_set_counting(h, 1): LF steps taken, Occ lookups made, distinct
+ * blocks those lookups read.  Counting mode costs atomics; leave it off when timing. */
+int rsbwt_set_counting(rsbwt_t *h, int on);
+int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups,
+                           uint64_t *block_reads);
+
+/* Synthetic data (bench / tests) ----------------------------------------------- */
+/* Fill d_runs (HBM) with num_runs pseudo-random RLUnit bytes: the direct run-stream
+ * synthesiser for throughput runs.  Same bytes as rsbwt_synth_runs_host for the same seed. */
+int rsbwt_synth_runs_dev(void *d_runs, uint64_t num_runs, uint64_t seed, int device, void *stream);
+int rsbwt_synth_runs_host(uint8_t *runs, uint64_t num_runs, uint64_t seed);
+/* Draw Q k-mers that are present in the index (LF walks from random rows, so every one of the
+ * k-1 updateInterval steps keeps a non-empty interval) into d_kmers (ASCII, stride bytes). */
+int rsbwt_sample_present_kmers_dev(rsbwt_t *h, size_t Q, uint32_t k, size_t stride, uint64_t seed,
+                                   void *d_kmers, void *stream);
+/* Build a valid multi-string BWT of a synthetic read population (a base genome, haplotypes with
+ * SNPs, fixed-length reads, reverse-lexicographic sort + dedup) and write it as an SGA .bwt;
+ * optionally also the sorted reads, one per line.  Host only. */
+int rsbwt_synth_popbwt(const char *bwt_path, const char *reads_path, uint64_t seed,
+                       uint64_t genome_len, uint32_t haplotypes, double snp_rate,
+                       uint32_t read_len, double coverage, int shard, int num_shards);
+
+/* Shard sets: the shards of one process, searched with one call ------------------ */
+int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
+                   uint32_t flags, rsbwt_set_t **out);
+int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out);
+void rsbwt_set_close(rsbwt_set_t *s); /* closes the shards it opened itself */
+size_t rsbwt_set_size(const rsbwt_set_t *s);
+rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
+/* lower/upper: [num_shards][Q]; counts: [Q] summed over shards, the way the front-end sums
+ * per-partition replies (src/service/server.cpp:184-197). */
+int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k,
+                             size_t stride, uint64_t *lower, uint64_t *upper);
+int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                    uint64_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

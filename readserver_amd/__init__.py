@@ -1,0 +1,21 @@
+"""readserver_amd -- MI355X-native population-BWT query engine.
+
+Replaces ReadServer's ``src/bwt`` backward-search path (``findInterval -> updateInterval ->
+RLEBWT::getOcc``) with hand-written HIP kernels for gfx950 behind a C-ABI (``include/rsbwt.h``,
+``lib/librsbwt.so``).  This package is the thin host-side mirror of the reference's ``BWT`` /
+``query.h`` interface on top of that library; there is no CPU fallback.
+"""
+from ._native import build, lib, lib_path, RsbwtError  # noqa: F401
+from .bwt import (  # noqa: F401
+    BWTInterval,
+    GpuBWT,
+    ShardSet,
+    count_kmers,
+    extractPostfix,
+    extractPrefix,
+    find_intervals,
+    findInterval,
+    query,
+    query_exactmatch,
+    synth_popbwt,
+)

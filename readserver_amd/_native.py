@@ -1,0 +1,112 @@
+"""ctypes binding of librsbwt.so (declared in include/rsbwt.h)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "librsbwt.so")
+_lock = threading.Lock()
+_lib = None
+
+RSBWT_OK = 0
+RSBWT_ENODEV = -5
+
+
+class RsbwtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rsbwt error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False):
+    """Compile csrc/ into lib/librsbwt.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "rsbwt.h"))
+    if not force and os.path.exists(_LIB):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(_LIB) >= newest:
+            return _LIB
+    subprocess.check_call(["bash", os.path.join(_HERE, "build.sh")])
+    return _LIB
+
+
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every function of include/rsbwt.h
+SIGNATURES = {
+    "rsbwt_version": (C.c_char_p, []),
+    "rsbwt_device_count": (C.c_int, []),
+    "rsbwt_last_error": (C.c_char_p, []),
+    "rsbwt_strerror": (C.c_char_p, [C.c_int]),
+    "rsbwt_open": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "rsbwt_open_runs": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "rsbwt_open_device_runs": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "rsbwt_close": (None, [_vp]),
+    "rsbwt_bwlen": (C.c_uint64, [_vp]),
+    "rsbwt_pc": (C.c_uint64, [_vp, C.c_char]),
+    "rsbwt_f": (C.c_char, [_vp, C.c_uint64]),
+    "rsbwt_occ": (C.c_int, [_vp, C.c_char, C.c_uint64, _u64p]),
+    "rsbwt_char": (C.c_int, [_vp, C.c_uint64, C.c_char_p]),
+    "rsbwt_occ_at": (C.c_int, [_vp, C.c_char, C.c_uint64, _u64p]),
+    "rsbwt_occ_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "rsbwt_char_batch": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "rsbwt_occ_at_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "rsbwt_num_runs": (C.c_uint64, [_vp]),
+    "rsbwt_num_strings": (C.c_uint64, [_vp]),
+    "rsbwt_num_blocks": (C.c_uint64, [_vp]),
+    "rsbwt_dir_shift": (C.c_uint32, [_vp]),
+    "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
+    "rsbwt_device": (C.c_int, [_vp]),
+    "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
+    "rsbwt_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
+    "rsbwt_pack_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_int, _vp]),
+    "rsbwt_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
+    "rsbwt_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_last_search_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "rsbwt_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rsbwt_set_counting": (C.c_int, [_vp, C.c_int]),
+    "rsbwt_last_search_work": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
+    "rsbwt_synth_runs_dev": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "rsbwt_synth_runs_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
+    "rsbwt_sample_present_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint64, _vp, _vp]),
+    "rsbwt_synth_popbwt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double,
+                                     C.c_uint32, C.c_double, C.c_int, C.c_int]),
+    "rsbwt_set_open": (C.c_int, [C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
+    "rsbwt_set_from_handles": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.POINTER(_vp)]),
+    "rsbwt_set_close": (None, [_vp]),
+    "rsbwt_set_size": (C.c_size_t, [_vp]),
+    "rsbwt_set_shard": (_vp, [_vp, C.c_size_t]),
+    "rsbwt_set_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
+    "rsbwt_set_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
+}
+
+
+def lib():
+    """The loaded library.  Fails loudly when it has not been built: no fallback exists."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB):
+                raise RuntimeError(
+                    f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or readserver_amd/build.sh). The popBWT engine is the HIP library only; "
+                    "there is no CPU fallback.")
+            L = C.CDLL(_LIB)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+        return _lib
+
+
+def check(rc):
+    if rc != RSBWT_OK:
+        msg = lib().rsbwt_last_error().decode(errors="replace")
+        raise RsbwtError(rc, msg or lib().rsbwt_strerror(rc).decode())

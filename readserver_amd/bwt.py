@@ -1,0 +1,278 @@
+"""Host-side mirror of ReadServer's ``BWT`` / ``query.h`` interface over librsbwt.so.
+
+Names and argument meaning follow the reference so parity tests read like its call sites:
+``class BWT`` (include/bwt/bwt.h:6-15), ``RLEBWT(filename)`` (include/bwt/rlebwt.h:17),
+``findInterval / extractPrefix / extractPostfix / query / query_exactmatch``
+(include/bwt/query.h:18-32).  Every query runs in the HIP library; numpy is used only to hand
+buffers across the C-ABI.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _native
+from ._native import RsbwtError, check, lib
+
+BWTInterval = namedtuple("BWTInterval", ["lower", "upper"])  # include/bwt/query.h:8-11
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _kmer_matrix(kmers):
+    """list of equal-length str/bytes, or a (Q, k) uint8 array -> (contiguous uint8 (Q, k), k)."""
+    if isinstance(kmers, np.ndarray):
+        a = np.ascontiguousarray(kmers, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("k-mer array must be (Q, k) uint8")
+        return a, a.shape[1]
+    ks = [s.encode() if isinstance(s, str) else bytes(s) for s in kmers]
+    if not ks:
+        return np.zeros((0, 0), np.uint8), 0
+    k = len(ks[0])
+    if any(len(s) != k for s in ks):
+        raise ValueError("all k-mers of one batch must have the same length")
+    return np.frombuffer(b"".join(ks), dtype=np.uint8).reshape(len(ks), k).copy(), k
+
+
+class GpuBWT:
+    """One BWT shard resident in HBM: ``RLEBWT`` (include/bwt/rlebwt.h:15-61) on the GPU.
+
+    GpuBWT(filename)                      # SGA .bwt, as RLEBWT(filename)
+    GpuBWT(runs=uint8 array, num_strings=) # RLUnit bytes in host memory
+    GpuBWT(device_runs=(ptr, n), ...)      # RLUnit bytes already in HBM (e.g. a torch tensor)
+    """
+
+    def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
+                 dir_shift=0):
+        self._h = C.c_void_p()
+        L = lib()
+        flags = int(dir_shift) & 0x1F
+        if filename is not None:
+            check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
+        elif runs is not None:
+            r = np.ascontiguousarray(runs, dtype=np.uint8)
+            check(L.rsbwt_open_runs(_ptr(r), r.size, num_strings, device, flags, C.byref(self._h)))
+        elif device_runs is not None:
+            ptr, n = device_runs
+            check(L.rsbwt_open_device_runs(C.c_void_p(ptr), n, num_strings, device, flags,
+                                           C.byref(self._h)))
+        else:
+            raise ValueError("one of filename, runs, device_runs is required")
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            lib().rsbwt_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- class BWT (include/bwt/bwt.h:6-15)
+    def getBWLen(self):
+        return lib().rsbwt_bwlen(self._h)
+
+    def getPC(self, b):
+        return lib().rsbwt_pc(self._h, b.encode() if isinstance(b, str) else b)
+
+    def getF(self, index):
+        return lib().rsbwt_f(self._h, index).decode()
+
+    def getOcc(self, b, index):
+        out = C.c_uint64()
+        check(lib().rsbwt_occ(self._h, b.encode() if isinstance(b, str) else b,
+                              index & 0xFFFFFFFFFFFFFFFF, C.byref(out)))
+        return out.value
+
+    def getChar(self, index):
+        out = C.create_string_buffer(1)
+        check(lib().rsbwt_char(self._h, index, out))
+        return out.raw.decode()
+
+    def getOccAt(self, b, bc):
+        out = C.c_uint64()
+        check(lib().rsbwt_occ_at(self._h, b.encode() if isinstance(b, str) else b, bc, C.byref(out)))
+        return out.value
+
+    # -- batched forms
+    def occ_batch(self, syms, index):
+        s = np.ascontiguousarray(np.frombuffer(syms.encode() if isinstance(syms, str) else bytes(syms),
+                                               dtype=np.uint8))
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        if s.size == 1 and idx.size > 1:
+            s = np.repeat(s, idx.size)
+        out = np.empty(idx.size, np.uint64)
+        check(lib().rsbwt_occ_batch(self._h, _ptr(s), _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def char_batch(self, index):
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        out = np.empty(idx.size, np.uint8)
+        check(lib().rsbwt_char_batch(self._h, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def occ_at_batch(self, syms, bc):
+        s = np.ascontiguousarray(np.frombuffer(syms.encode() if isinstance(syms, str) else bytes(syms),
+                                               dtype=np.uint8))
+        c = np.ascontiguousarray(bc, dtype=np.uint64)
+        if s.size == 1 and c.size > 1:
+            s = np.repeat(s, c.size)
+        out = np.empty(c.size, np.uint64)
+        check(lib().rsbwt_occ_at_batch(self._h, _ptr(s), _ptr(c), c.size, _ptr(out)))
+        return out
+
+    # -- shape
+    def num_runs(self):
+        return lib().rsbwt_num_runs(self._h)
+
+    def num_strings(self):
+        return lib().rsbwt_num_strings(self._h)
+
+    def num_blocks(self):
+        return lib().rsbwt_num_blocks(self._h)
+
+    def dir_shift(self):
+        return lib().rsbwt_dir_shift(self._h)
+
+    def hbm_bytes(self):
+        return lib().rsbwt_hbm_bytes(self._h)
+
+
+# ---- query.h (src/bwt/query.cpp) ------------------------------------------------------------
+
+def find_intervals(pBWT, kmers):
+    """Batched findInterval (query.cpp:24-41): returns (lower, upper) uint64 arrays."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    lower = np.empty(Q, np.uint64)
+    upper = np.empty(Q, np.uint64)
+    check(lib().rsbwt_find_intervals(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(lower), _ptr(upper)))
+    return lower, upper
+
+
+def count_kmers(pBWT, kmers):
+    """Batched count of count_reads (src/service/service.cpp:303-304)."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    out = np.empty(Q, np.uint64)
+    check(lib().rsbwt_count(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(out)))
+    return out
+
+
+def findInterval(pBWT, w):
+    """BWTInterval findInterval(const BWT*, const std::string& w) (query.cpp:24-41)."""
+    lo, up = find_intervals(pBWT, [w])
+    return BWTInterval(int(lo[0]), int(up[0]))
+
+
+def extractPrefix(pBWT, index, limit=1 << 16):
+    """query.cpp:43-63: LF-walk left from row `index` until '$'."""
+    out = []
+    idx = index
+    while True:
+        b = pBWT.getChar(idx)
+        if b == "$":
+            break
+        if len(out) >= limit:
+            raise RsbwtError(-1, "extractPrefix did not meet '$'")
+        idx = pBWT.getPC(b) + pBWT.getOcc(b, idx - 1)
+        out.append(b)
+    return "".join(reversed(out))
+
+
+def extractPostfix(pBWT, index, limit=1 << 16):
+    """query.cpp:65-85: F/select walk right from row `index` until '$'."""
+    out = []
+    idx = index
+    while True:
+        f = pBWT.getF(idx)
+        if f == "$":
+            break
+        if len(out) >= limit:
+            raise RsbwtError(-1, "extractPostfix did not meet '$'")
+        fc = idx - pBWT.getPC(f) + 1
+        idx = pBWT.getOccAt(f, fc)
+        out.append(f)
+    return "".join(out)
+
+
+def query(pBWT, w):
+    """query.cpp:87-100: every read containing w."""
+    if any(c not in "ACGT" for c in w):
+        return []
+    itv = findInterval(pBWT, w)
+    return [extractPrefix(pBWT, i) + extractPostfix(pBWT, i) for i in range(itv.lower, itv.upper + 1)]
+
+
+def query_exactmatch(pBWT, w):
+    """query.cpp:102-120: is w itself one of the reads."""
+    if any(c not in "ACGT" for c in w):
+        return False
+    itv = findInterval(pBWT, w)
+    if itv.lower > itv.upper:
+        return False
+    return any(w == extractPrefix(pBWT, i) + extractPostfix(pBWT, i)
+               for i in range(itv.lower, itv.upper + 1))
+
+
+# ---- shard sets -----------------------------------------------------------------
+
+class ShardSet:
+    """The shards held by one process; every query is searched in all of them (the reference
+    broadcasts each request to all partitions: src/service/server.cpp:124,578)."""
+
+    def __init__(self, shards):
+        self.shards = list(shards)
+        arr = (C.c_void_p * len(self.shards))(*[s.handle for s in self.shards])
+        self._s = C.c_void_p()
+        check(lib().rsbwt_set_from_handles(arr, len(self.shards), C.byref(self._s)))
+
+    def close(self):
+        if self._s:
+            lib().rsbwt_set_close(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def find_intervals(self, kmers):
+        a, k = _kmer_matrix(kmers)
+        Q, S = a.shape[0], len(self.shards)
+        lower = np.empty((S, Q), np.uint64)
+        upper = np.empty((S, Q), np.uint64)
+        check(lib().rsbwt_set_find_intervals(self._s, _ptr(a), Q, k, max(k, 1), _ptr(lower), _ptr(upper)))
+        return lower, upper
+
+    def count(self, kmers):
+        a, k = _kmer_matrix(kmers)
+        out = np.empty(a.shape[0], np.uint64)
+        check(lib().rsbwt_set_count(self._s, _ptr(a), a.shape[0], k, max(k, 1), _ptr(out)))
+        return out
+
+
+def synth_popbwt(bwt_path, reads_path=None, *, seed, genome_len, haplotypes, snp_rate, read_len,
+                 coverage, shard=-1, num_shards=1):
+    """Deterministic synthetic population BWT written as an SGA .bwt (host only; csrc/synth.cpp)."""
+    check(lib().rsbwt_synth_popbwt(str(bwt_path).encode(),
+                                   str(reads_path).encode() if reads_path else None,
+                                   seed, genome_len, haplotypes, snp_rate, read_len, coverage,
+                                   shard, num_shards))

@@ -1,0 +1,547 @@
+// capi.hip -- the C-ABI of librsbwt.so (include/rsbwt.h) over the HIP engine.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/rsbwt.h"
+#include "block_format.h"
+#include "bwt_file.h"
+#include "kernels.h"
+
+using namespace rsb;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what) {
+    return fail(RSBWT_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_OK(x)                                              \
+    do {                                                       \
+        hipError_t _e = (x);                                   \
+        if (_e != hipSuccess) return fail_hip(_e, #x);         \
+    } while (0)
+
+int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RSBWT_ENODEV, "no HIP device is visible: the popBWT engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RSBWT_ENODEV, "device %d out of range (0..%d)", device, n - 1);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    return RSBWT_OK;
+}
+
+inline uint32_t words_per_kmer(uint32_t k) { return k ? (k + 31u) / 32u : 1u; }
+
+}  // namespace
+
+struct rsbwt {
+    int device = 0;
+    int num_cus = 256;
+    rsbwt_view view;
+    uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
+    hipStream_t stream = nullptr;  // host-buffer calls run here
+    static constexpr int RING = 64;  // HIP-event pairs of the most recent search launches
+    hipEvent_t ev_start[RING] = {}, ev_stop[RING] = {};
+    uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
+    bool counting = false;
+    unsigned long long *d_work = nullptr;  // 3 counters
+    std::recursive_mutex mu;
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+
+    int stage(size_t bytes) {
+        if (bytes <= stage_bytes) return RSBWT_OK;
+        if (d_stage) (void)hipFree(d_stage);
+        d_stage = nullptr;
+        stage_bytes = 0;
+        hipError_t e = hipMalloc(&d_stage, bytes);
+        if (e != hipSuccess) return fail(RSBWT_ENOMEM, "hipMalloc(%zu) for staging: %s", bytes, hipGetErrorString(e));
+        stage_bytes = bytes;
+        return RSBWT_OK;
+    }
+};
+
+struct rsbwt_set {
+    std::vector<rsbwt_t *> shards;
+    bool owns = false;
+};
+
+extern "C" {
+
+const char *rsbwt_version(void) { return "rsbwt 0.1 (gfx950)"; }
+
+int rsbwt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rsbwt_last_error(void) { return g_err; }
+
+const char *rsbwt_strerror(int code) {
+    switch (code) {
+    case RSBWT_OK: return "ok";
+    case RSBWT_EINVAL: return "invalid argument";
+    case RSBWT_EIO: return "i/o error";
+    case RSBWT_EFORMAT: return "not an SGA run-length BWT file";
+    case RSBWT_ENOMEM: return "out of memory";
+    case RSBWT_ENODEV: return "no usable HIP device";
+    case RSBWT_EHIP: return "HIP runtime error";
+    case RSBWT_ERANGE: return "shard exceeds format limits";
+    default: return "unknown error";
+    }
+}
+
+// ---- lifetime -------------------------------------------------------------------------------
+
+static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
+                       uint32_t flags, rsbwt_t **out) {
+    rsbwt_t *h = new (std::nothrow) rsbwt();
+    if (!h) return fail(RSBWT_ENOMEM, "host allocation failed");
+    h->device = device;
+    h->num_strings = num_strings;
+    memset(&h->view, 0, sizeof h->view);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->num_cus = prop.multiProcessorCount;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&h->d_work, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        rsbwt_close(h);
+        return fail_hip(e, "creating stream/events");
+    }
+    for (int i = 0; i < rsbwt::RING; ++i) {
+        if ((e = hipEventCreate(&h->ev_start[i])) != hipSuccess ||
+            (e = hipEventCreate(&h->ev_stop[i])) != hipSuccess) {
+            rsbwt_close(h);
+            return fail_hip(e, "hipEventCreate");
+        }
+    }
+    build_result br;
+    int range_error = 0;
+    e = build_device_index(d_runs, num_runs, flags & RSBWT_DIR_SHIFT_MASK, h->stream, &br, &range_error);
+    if (e != hipSuccess) {
+        rsbwt_close(h);
+        if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the index");
+        return fail_hip(e, "build_device_index");
+    }
+    if (range_error) {
+        rsbwt_close(h);
+        return fail(RSBWT_ERANGE, "shard too large: at most 2^40 symbols and 2^32 blocks");
+    }
+    h->view = br.view;
+    h->num_runs = br.num_runs;
+    h->hbm_bytes = br.hbm_bytes;
+    *out = h;
+    return RSBWT_OK;
+}
+
+int rsbwt_open_device_runs(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
+                           uint32_t flags, rsbwt_t **out) {
+    if (!out || (!d_runs && num_runs)) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = use_device(device);
+    if (rc) return rc;
+    return finish_open(d_runs, num_runs, num_strings, device, flags, out);
+}
+
+int rsbwt_open_runs(const uint8_t *runs, uint64_t num_runs, uint64_t num_strings, int device,
+                    uint32_t flags, rsbwt_t **out) {
+    if (!out || (!runs && num_runs)) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = use_device(device);
+    if (rc) return rc;
+    void *d_runs = nullptr;
+    hipError_t e = hipMalloc(&d_runs, num_runs ? num_runs : 16);
+    if (e != hipSuccess) return fail(RSBWT_ENOMEM, "hipMalloc(%llu) for run bytes: %s", (unsigned long long)num_runs, hipGetErrorString(e));
+    e = hipMemcpy(d_runs, runs, num_runs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_runs); return fail_hip(e, "hipMemcpy(runs)"); }
+    rc = finish_open(d_runs, num_runs, num_strings, device, flags, out);
+    (void)hipFree(d_runs);
+    return rc;
+}
+
+int rsbwt_open(const char *bwt_path, int device, uint32_t flags, rsbwt_t **out) {
+    if (!out || !bwt_path) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    FILE *f = nullptr;
+    bwt_header hdr;
+    int rc = bwt_open_read(bwt_path, &f, &hdr);
+    if (rc == RSBWT_EIO) return fail(rc, "cannot open %s", bwt_path);
+    if (rc) return fail(rc, "%s is not an SGA run-length BWT (magic 0xCACA) or is truncated", bwt_path);
+    rc = use_device(device);
+    if (rc) { fclose(f); return rc; }
+    // stream the file through two pinned buffers into HBM
+    const size_t CH = 64u << 20;
+    void *d_runs = nullptr, *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipError_t e = hipMalloc(&d_runs, hdr.num_runs ? hdr.num_runs : 16);
+    if (e != hipSuccess) { fclose(f); return fail(RSBWT_ENOMEM, "hipMalloc(%llu) for run bytes: %s", (unsigned long long)hdr.num_runs, hipGetErrorString(e)); }
+    rc = RSBWT_OK;
+    if ((e = hipStreamCreate(&st)) != hipSuccess) rc = fail_hip(e, "hipStreamCreate");
+    for (int i = 0; i < 2 && rc == RSBWT_OK; ++i) {
+        if ((e = hipHostMalloc(&pin[i], CH, hipHostMallocDefault)) != hipSuccess) rc = fail(RSBWT_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+        else if ((e = hipEventCreate(&done[i])) != hipSuccess) rc = fail_hip(e, "hipEventCreate");
+    }
+    uint64_t off = 0;
+    for (int i = 0; rc == RSBWT_OK && off < hdr.num_runs; i ^= 1) {
+        const size_t m = (size_t)std::min<uint64_t>(CH, hdr.num_runs - off);
+        if ((e = hipEventSynchronize(done[i])) != hipSuccess) { rc = fail_hip(e, "hipEventSynchronize"); break; }
+        if (fread(pin[i], 1, m, f) != m) { rc = fail(RSBWT_EIO, "short read from %s", bwt_path); break; }
+        if ((e = hipMemcpyAsync((uint8_t *)d_runs + off, pin[i], m, hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (e = hipEventRecord(done[i], st)) != hipSuccess) { rc = fail_hip(e, "hipMemcpyAsync(runs)"); break; }
+        off += m;
+    }
+    if (st) (void)hipStreamSynchronize(st);
+    fclose(f);
+    if (rc == RSBWT_OK) {
+        rc = finish_open(d_runs, hdr.num_runs, hdr.num_strings, device, flags, out);
+        if (rc == RSBWT_OK && (*out)->view.n != hdr.num_symbols) {
+            rsbwt_close(*out);
+            *out = nullptr;
+            rc = fail(RSBWT_EFORMAT, "%s: header says %llu symbols, runs hold a different number", bwt_path, (unsigned long long)hdr.num_symbols);
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d_runs);
+    return rc;
+}
+
+void rsbwt_close(rsbwt_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->view.blocks) (void)hipFree((void *)h->view.blocks);
+    if (h->view.dir) (void)hipFree((void *)h->view.dir);
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->d_work) (void)hipFree(h->d_work);
+    for (int i = 0; i < rsbwt::RING; ++i) {
+        if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
+        if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ---- shape ----------------------------------------------------------------------------------
+
+static inline int rank_of(char b) { return b == 'A' ? 1 : b == 'C' ? 2 : b == 'G' ? 3 : b == 'T' ? 4 : 0; }
+
+uint64_t rsbwt_bwlen(const rsbwt_t *h) { return h->view.n; }
+uint64_t rsbwt_pc(const rsbwt_t *h, char b) { return h->view.C[rank_of(b)]; }
+char rsbwt_f(const rsbwt_t *h, uint64_t index) {
+    int ci = 0;
+    while (ci < 5 && h->view.C[ci] <= index) ci++;
+    return "$ACGT"[ci > 0 ? ci - 1 : 0];
+}
+uint64_t rsbwt_num_runs(const rsbwt_t *h) { return h->num_runs; }
+uint64_t rsbwt_num_strings(const rsbwt_t *h) { return h->num_strings; }
+uint64_t rsbwt_num_blocks(const rsbwt_t *h) { return h->view.nblocks; }
+uint32_t rsbwt_dir_shift(const rsbwt_t *h) { return h->view.dir_shift; }
+uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
+int rsbwt_device(const rsbwt_t *h) { return h->device; }
+
+// ---- class BWT mirrors ------------------------------------------------------------------------
+
+// kind 0: occ(syms, vals)  1: char(vals)  2: occ_at(syms, vals)
+static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *vals, size_t n, void *out) {
+    if (!h || (!vals && n) || (!out && n) || (kind != 1 && !syms && n)) return fail(RSBWT_EINVAL, "null argument");
+    if (n == 0) return RSBWT_OK;
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    const size_t out_bytes = (kind == 1) ? n : n * 8;
+    const size_t need = n * 8 + n + out_bytes + 64;
+    if ((rc = h->stage(need)) != RSBWT_OK) return rc;
+    uint8_t *base = (uint8_t *)h->d_stage;
+    uint64_t *d_vals = (uint64_t *)base;
+    uint8_t *d_out = base + n * 8;              // 8-aligned
+    uint8_t *d_syms = d_out + ((out_bytes + 7) & ~(size_t)7);
+    HIP_OK(hipMemcpyAsync(d_vals, vals, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (kind != 1) HIP_OK(hipMemcpyAsync(d_syms, syms, n, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = hipSuccess;
+    if (kind == 0) e = launch_occ_batch(h->view, d_syms, d_vals, n, d_out, h->stream);
+    else if (kind == 1) e = launch_char_batch(h->view, d_vals, n, d_out, h->stream);
+    else e = launch_occ_at_batch(h->view, d_syms, d_vals, n, d_out, h->stream);
+    if (e != hipSuccess) return fail_hip(e, "mirror kernel launch");
+    HIP_OK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return RSBWT_OK;
+}
+
+int rsbwt_occ_batch(rsbwt_t *h, const char *b, const uint64_t *index, size_t n, uint64_t *occ) {
+    return mirror_batch(h, 0, b, index, n, occ);
+}
+int rsbwt_char_batch(rsbwt_t *h, const uint64_t *index, size_t n, char *c) {
+    return mirror_batch(h, 1, nullptr, index, n, c);
+}
+int rsbwt_occ_at_batch(rsbwt_t *h, const char *b, const uint64_t *bc, size_t n, uint64_t *index) {
+    return mirror_batch(h, 2, b, bc, n, index);
+}
+int rsbwt_occ(rsbwt_t *h, char b, uint64_t index, uint64_t *occ) { return mirror_batch(h, 0, &b, &index, 1, occ); }
+int rsbwt_char(rsbwt_t *h, uint64_t index, char *c) { return mirror_batch(h, 1, nullptr, &index, 1, c); }
+int rsbwt_occ_at(rsbwt_t *h, char b, uint64_t bc, uint64_t *index) { return mirror_batch(h, 2, &b, &bc, 1, index); }
+
+// ---- batched search ---------------------------------------------------------------------------
+
+int rsbwt_pack_kmers_dev(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
+                         void *d_valid, int device, void *stream) {
+    if ((!d_kmers || !d_packed || !d_valid) && Q) return fail(RSBWT_EINVAL, "null argument");
+    if (stride < k) return fail(RSBWT_EINVAL, "stride %zu < k %u", stride, k);
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipError_t e = launch_pack(d_kmers, Q, k, stride, d_packed, d_valid, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+    return RSBWT_OK;
+}
+
+static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                      void *d_lower, void *d_upper, bool counts_only, hipStream_t stream) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if (h->view.n == 0 && Q) return fail(RSBWT_EINVAL, "empty index");
+    unsigned long long *work = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lock(h->mu);
+        if (h->counting) {
+            work = h->d_work;
+            HIP_OK(hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream));
+        }
+        const int slot = (int)(h->launches % rsbwt::RING);
+        HIP_OK(hipEventRecord(h->ev_start[slot], stream));
+        hipError_t e = launch_search(h->view, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream);
+        if (e != hipSuccess) return fail_hip(e, "search kernel launch");
+        HIP_OK(hipEventRecord(h->ev_stop[slot], stream));
+        h->launches++;
+    }
+    return RSBWT_OK;
+}
+
+int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                             void *d_lower, void *d_upper, void *stream) {
+    return search_dev(h, d_packed, d_valid, Q, k, d_lower, d_upper, false, (hipStream_t)stream);
+}
+
+int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                    void *d_counts, void *stream) {
+    return search_dev(h, d_packed, d_valid, Q, k, d_counts, nullptr, true, (hipStream_t)stream);
+}
+
+// host buffers: stage through HBM in slices of at most 4M k-mers
+static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                       uint64_t *lower, uint64_t *upper, bool counts_only) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers || !lower || (!counts_only && !upper)) return fail(RSBWT_EINVAL, "null argument");
+    if (stride < k) return fail(RSBWT_EINVAL, "stride %zu < k %u", stride, k);
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if (k == 0) {  // empty k-mer: empty interval
+        for (size_t q = 0; q < Q; ++q) {
+            if (counts_only) lower[q] = 0;
+            else { lower[q] = 1; upper[q] = 0; }
+        }
+        return RSBWT_OK;
+    }
+    const uint32_t wpq = words_per_kmer(k);
+    const size_t SLICE = 4u << 20;
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+        const size_t m = std::min(SLICE, Q - q0);
+        // the last k-mer needs only k bytes
+        const size_t ascii_bytes = (m - 1) * stride + k;
+        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15;
+        const size_t a_packed = m * wpq * 8;
+        const size_t a_valid = (m + 15) & ~(size_t)15;
+        std::lock_guard<std::recursive_mutex> lock(h->mu);
+        if ((rc = h->stage(a_ascii + a_packed + a_valid + 2 * m * 8)) != RSBWT_OK) return rc;
+        uint8_t *base = (uint8_t *)h->d_stage;
+        uint8_t *d_ascii = base;
+        uint8_t *d_packed = d_ascii + a_ascii;
+        uint8_t *d_valid = d_packed + a_packed;
+        uint8_t *d_lo = d_valid + a_valid;
+        uint8_t *d_up = d_lo + m * 8;
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = launch_pack(d_ascii, m, k, stride, d_packed, d_valid, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+        rc = search_dev(h, d_packed, d_valid, m, k, d_lo, d_up, counts_only, h->stream);
+        if (rc) return rc;
+        HIP_OK(hipMemcpyAsync(lower + q0, d_lo, m * 8, hipMemcpyDeviceToHost, h->stream));
+        if (!counts_only) HIP_OK(hipMemcpyAsync(upper + q0, d_up, m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    return RSBWT_OK;
+}
+
+int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                         uint64_t *lower, uint64_t *upper) {
+    return search_host(h, kmers, Q, k, stride, lower, upper, false);
+}
+
+int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
+    return search_host(h, kmers, Q, k, stride, counts, nullptr, true);
+}
+
+// ---- measurement ------------------------------------------------------------------------------
+
+int rsbwt_last_search_ms(rsbwt_t *h, float *ms) {
+    if (!h || !ms) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    const int slot = (int)((h->launches - 1) % rsbwt::RING);
+    HIP_OK(hipEventSynchronize(h->ev_stop[slot]));
+    HIP_OK(hipEventElapsedTime(ms, h->ev_start[slot], h->ev_stop[slot]));
+    return RSBWT_OK;
+}
+
+int rsbwt_search_history_ms(rsbwt_t *h, float *ms, size_t cap, size_t *count) {
+    if (!h || (!ms && cap) || !count) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    size_t n = (size_t)std::min<uint64_t>(h->launches, rsbwt::RING);
+    if (n > cap) n = cap;
+    for (size_t i = 0; i < n; ++i) {  // oldest of the n first
+        const int slot = (int)((h->launches - n + i) % rsbwt::RING);
+        HIP_OK(hipEventSynchronize(h->ev_stop[slot]));
+        HIP_OK(hipEventElapsedTime(&ms[i], h->ev_start[slot], h->ev_stop[slot]));
+    }
+    *count = n;
+    return RSBWT_OK;
+}
+
+int rsbwt_set_counting(rsbwt_t *h, int on) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    h->counting = on != 0;
+    return RSBWT_OK;
+}
+
+int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups, uint64_t *block_reads) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
+    unsigned long long w[3];
+    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    if (lf_steps) *lf_steps = w[0];
+    if (occ_lookups) *occ_lookups = w[1];
+    if (block_reads) *block_reads = w[2];
+    return RSBWT_OK;
+}
+
+// ---- synthetic data ---------------------------------------------------------------------------
+
+int rsbwt_synth_runs_dev(void *d_runs, uint64_t num_runs, uint64_t seed, int device, void *stream) {
+    if (!d_runs && num_runs) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipError_t e = launch_synth_runs(d_runs, num_runs, seed, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "synth kernel launch");
+    return RSBWT_OK;
+}
+
+int rsbwt_sample_present_kmers_dev(rsbwt_t *h, size_t Q, uint32_t k, size_t stride, uint64_t seed,
+                                   void *d_kmers, void *stream) {
+    if (!h || (!d_kmers && Q)) return fail(RSBWT_EINVAL, "null argument");
+    if (stride < k || k == 0) return fail(RSBWT_EINVAL, "bad k/stride");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    hipError_t e = launch_sample_present(h->view, Q, k, stride, seed, d_kmers, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "sample kernel launch");
+    return RSBWT_OK;
+}
+
+// ---- shard sets -------------------------------------------------------------------------------
+
+int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
+                   uint32_t flags, rsbwt_set_t **out) {
+    if (!out || (!bwt_paths && num_shards)) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
+    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
+    s->owns = true;
+    for (size_t i = 0; i < num_shards; ++i) {
+        rsbwt_t *h = nullptr;
+        int rc = rsbwt_open(bwt_paths[i], device_map ? device_map[i] : 0, flags, &h);
+        if (rc) { rsbwt_set_close(s); return rc; }
+        s->shards.push_back(h);
+    }
+    *out = s;
+    return RSBWT_OK;
+}
+
+int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
+    if (!out || (!handles && num_shards)) return fail(RSBWT_EINVAL, "null argument");
+    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
+    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
+    s->owns = false;
+    s->shards.assign(handles, handles + num_shards);
+    *out = s;
+    return RSBWT_OK;
+}
+
+void rsbwt_set_close(rsbwt_set_t *s) {
+    if (!s) return;
+    if (s->owns)
+        for (rsbwt_t *h : s->shards) rsbwt_close(h);
+    delete s;
+}
+
+size_t rsbwt_set_size(const rsbwt_set_t *s) { return s ? s->shards.size() : 0; }
+rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i) { return (s && i < s->shards.size()) ? s->shards[i] : nullptr; }
+
+int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                             uint64_t *lower, uint64_t *upper) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        int rc = rsbwt_find_intervals(s->shards[i], kmers, Q, k, stride, lower + i * Q, upper + i * Q);
+        if (rc) return rc;
+    }
+    return RSBWT_OK;
+}
+
+int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
+    if (!s || (!counts && Q)) return fail(RSBWT_EINVAL, "null argument");
+    std::vector<uint64_t> tmp(Q);
+    for (size_t q = 0; q < Q; ++q) counts[q] = 0;
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        int rc = rsbwt_count(s->shards[i], kmers, Q, k, stride, tmp.data());
+        if (rc) return rc;
+        for (size_t q = 0; q < Q; ++q) counts[q] += tmp[q];
+    }
+    return RSBWT_OK;
+}
+
+}  // extern "C"

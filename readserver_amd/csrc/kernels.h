@@ -1,0 +1,40 @@
+// kernels.h -- host-side launchers of the query kernels (kernels.hip) and index builder (index.hip).
+#ifndef RSBWT_KERNELS_H
+#define RSBWT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "block_format.h"
+
+namespace rsb {
+
+hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
+                       void *d_valid, hipStream_t stream);
+hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
+                         uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                         unsigned long long *d_work, int num_cus, hipStream_t stream);
+hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,
+                            void *d_out, hipStream_t stream);
+hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n, void *d_out,
+                             hipStream_t stream);
+hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
+                               void *d_out, hipStream_t stream);
+hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream);
+hipError_t launch_sample_present(const rsbwt_view &ix, size_t Q, uint32_t k, size_t stride,
+                                 uint64_t seed, void *d_kmers, hipStream_t stream);
+
+// index.hip: build blocks + directory in HBM from run bytes in HBM.  On success fills `view`
+// (blocks/dir are hipMalloc'ed and owned by the caller).  dir_shift 0 = choose from the mean
+// run length.  Synchronises `stream`.
+struct build_result {
+    rsbwt_view view;
+    uint64_t num_runs;
+    uint64_t hbm_bytes;
+};
+hipError_t build_device_index(const void *d_runs, uint64_t num_runs, uint32_t dir_shift,
+                              hipStream_t stream, build_result *out, int *range_error);
+
+}  // namespace rsb
+#endif

@@ -1,0 +1,396 @@
+// kernels.hip -- query kernels of the popBWT engine (gfx950).
+//
+// Hot path: search_kernel = batched findInterval (src/bwt/query.cpp:24-41).  A query is owned
+// by an octet of lanes = two DPP quads: quad L resolves Occ(b, lower-1), quad U resolves
+// Occ(b, upper) (updateInterval, query.cpp:11-15), in the same instructions.  A wavefront
+// carries 8 queries; each octet walks its own list of queries and refills as soon as one ends,
+// so short (early-terminating) queries do not idle the wave.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bwt_device.h"
+#include "kernels.h"
+#include "synth_runs.h"
+
+namespace rsb {
+
+// ------------------------------------------------------------------------------------------
+// ASCII -> 2-bit packing.  One thread per (k-mer, word).
+// ------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_t k, size_t stride,
+                            uint32_t wpq, uint64_t *__restrict__ packed,
+                            uint8_t *__restrict__ valid) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = gid; q < Q; q += nthreads) {
+        const uint8_t *s = kmers + q * stride;
+        bool ok = k > 0;
+        for (uint32_t w = 0; w < wpq; ++w) {
+            uint64_t word = 0;
+            const uint32_t base = w * 32u;
+            const uint32_t m = (k - base) < 32u ? (k - base) : 32u;
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint8_t ch = s[base + i];
+                uint32_t code;
+                switch (ch) {
+                case 'A': code = 0; break;
+                case 'C': code = 1; break;
+                case 'G': code = 2; break;
+                case 'T': code = 3; break;
+                default: code = 0; ok = false; break;
+                }
+                word |= (uint64_t)code << (2u * i);
+            }
+            packed[q * wpq + w] = word;
+        }
+        valid[q] = ok ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched backward search.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT_WORK, bool COUNTS_ONLY>
+__global__ void __launch_bounds__(256)
+search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
+              const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
+              uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
+              unsigned long long *__restrict__ work) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t = lane & 3u;          // lane in quad
+    const uint32_t role = (lane >> 2) & 1u;  // 0: lower-1 side, 1: upper side
+    const size_t octet = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const size_t noctets = ((size_t)gridDim.x * blockDim.x) >> 3;
+
+    size_t q = octet;
+    bool fresh = true;   // the next iteration starts query q
+    int j = 0;           // index of the next symbol to prepend
+    uint64_t word = 0;   // packed word holding symbol j
+    uint64_t lo = 0, hi = 0;
+    unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0;
+
+    while (q < Q) {
+        if (fresh) {
+            fresh = false;
+            const bool ok = valid[q] != 0;
+            if (!ok) {
+                if ((lane & 7u) == 0u) {
+                    if (COUNTS_ONLY) out_lower[q] = 0;
+                    else { out_lower[q] = 1; out_upper[q] = 0; }
+                }
+                q += noctets;
+                fresh = true;
+                continue;
+            }
+            j = (int)k - 1;
+            word = packed[q * wpq + ((uint32_t)j >> 5)];
+            const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+            // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
+            lo = select_C(ix, b);
+            hi = lo + select_total(ix, b) - 1ull;
+            --j;
+        }
+        bool done = j < 0;
+        if (!done) {
+            if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+            const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+            // updateInterval (query.cpp:11-15)
+            const bool skip = (role == 0u) && (lo == 0ull);  // Occ(b, -1) = 0
+            const uint64_t p = role ? hi : (skip ? 0ull : lo - 1ull);
+            lane_block lb;
+            block_meta bm;
+            const uint64_t blk = quad_fetch(ix, p, t, lb, bm);
+            uint64_t occ = quad_rank(lb, bm, t, b, p);
+            occ = skip ? 0ull : occ;
+            const uint64_t other = dpp_mov64<DPP_ROW_HALF_MIRROR>(occ);
+            const uint64_t occL = role ? other : occ;
+            const uint64_t occU = role ? occ : other;
+            const uint64_t pb = select_C(ix, b);
+            if (COUNT_WORK) {
+                const uint64_t oblk = dpp_mov64<DPP_ROW_HALF_MIRROR>(blk);
+                const uint32_t oskip = dpp_mov<DPP_ROW_HALF_MIRROR>(skip ? 1u : 0u);
+                if ((lane & 7u) == 0u) {  // role 0, so `skip` is the L side's
+                    w_steps += 1;
+                    w_occ += skip ? 1 : 2;
+                    w_blocks += (skip || oblk == blk) ? 1 : 2;
+                    (void)oskip;
+                }
+            }
+            lo = pb + occL;
+            hi = pb + occU - 1ull;
+            --j;
+            done = (lo > hi) || (j < 0);  // query.cpp:35-37
+        }
+        if (done) {
+            if ((lane & 7u) == 0u) {
+                if (COUNTS_ONLY) {
+                    out_lower[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                } else {
+                    out_lower[q] = lo;
+                    out_upper[q] = hi;
+                }
+            }
+            q += noctets;
+            fresh = true;
+        }
+    }
+    if (COUNT_WORK) {
+        if ((lane & 7u) == 0u && w_steps) {
+            atomicAdd(&work[0], w_steps);
+            atomicAdd(&work[1], w_occ);
+            atomicAdd(&work[2], w_blocks);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// class BWT mirrors, batched: one quad per item.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ascii_rank(uint8_t ch) {
+    return ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'T' ? 4u : 0u;
+}
+
+// Occ for any symbol rank 0..4; `$` comes from P0 minus the four stored counts.
+__device__ __forceinline__ uint64_t quad_occ_any(const rsbwt_view &ix, uint32_t b, uint64_t p,
+                                                 uint32_t t) {
+    lane_block lb;
+    block_meta bm;
+    quad_fetch(ix, p, t, lb, bm);
+    uint64_t r = quad_rank(lb, bm, t, b, p);  // for b == 0: just the in-block '$' symbols
+    if (b == 0u) {
+        const uint64_t cnt = ((uint64_t)(lb.hdr_hi & 0xFFu) << 32) | lb.hdr_lo;
+        r += bm.P0 - quad_sum64(cnt);
+    }
+    return r;
+}
+
+__global__ void occ_batch_kernel(const rsbwt_view ix, const uint8_t *__restrict__ syms,
+                                 const uint64_t *__restrict__ index, size_t n,
+                                 uint64_t *__restrict__ out) {
+    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
+    const uint32_t t = threadIdx.x & 3u;
+    for (size_t i = quad; i < n; i += nquads) {
+        const uint32_t b = ascii_rank(syms[i]);
+        uint64_t p = index[i];
+        uint64_t r = 0;
+        if (p != ~0ull && ix.n != 0) {  // getOcc(b, -1) = 0
+            if (p >= ix.n) p = ix.n - 1;
+            r = quad_occ_any(ix, b, p, t);
+        }
+        if (t == 0u) out[i] = r;
+    }
+}
+
+__global__ void char_batch_kernel(const rsbwt_view ix, const uint64_t *__restrict__ index, size_t n,
+                                  uint8_t *__restrict__ out) {
+    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
+    const uint32_t t = threadIdx.x & 3u;
+    for (size_t i = quad; i < n; i += nquads) {
+        uint64_t p = index[i];
+        if (p >= ix.n) p = ix.n - 1;
+        lane_block lb;
+        block_meta bm;
+        quad_fetch(ix, p, t, lb, bm);
+        const uint32_t c = quad_char(lb, bm, t, p);
+        if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
+    }
+}
+
+// Count of symbol b (1..4) before block j; `$` (0) from P0.  One thread, two or four loads.
+__device__ __forceinline__ uint64_t block_count_before(const rsbwt_view &ix, uint64_t j, uint32_t b) {
+    const uint64_t *w = (const uint64_t *)ix.blocks;  // header word t at u64 index 16*j + 4*t
+    if (b != 0u) return w[16 * j + 4 * (b - 1u)] & RSBWT_COUNT_MASK;
+    const uint64_t w0 = w[16 * j], w1 = w[16 * j + 4], w2 = w[16 * j + 8], w3 = w[16 * j + 12];
+    const uint64_t P0 = (w0 >> 40) | ((w1 >> 40) << 24);
+    return P0 - ((w0 & RSBWT_COUNT_MASK) + (w1 & RSBWT_COUNT_MASK) + (w2 & RSBWT_COUNT_MASK) +
+                 (w3 & RSBWT_COUNT_MASK));
+}
+
+// getOccAt(b, bc): position of the bc-th b (bc >= 1).  Floor search over the block headers
+// (BPTree::select's role, include/bwt/BPTree.h:50-67), then RLEBWT::getOccAt's scan
+// (src/bwt/rlebwt.cpp:245-263) over the block's 96 runs.  One thread per item.
+__device__ uint64_t thread_occ_at(const rsbwt_view &ix, uint32_t b, uint64_t bc) {
+    uint64_t lo = 0, hi = ix.nblocks - 1;  // largest j with count_before(j) < bc
+    while (hi > lo) {
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if (block_count_before(ix, mid, b) >= bc) hi = mid - 1;
+        else lo = mid;
+    }
+    const uint64_t j = lo;
+    const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
+    const uint64_t P0 = (w[0] >> 40) | ((w[4] >> 40) << 24);
+    uint64_t offset = bc - block_count_before(ix, j, b);
+    uint64_t index = P0;
+    const uint8_t *bytes = (const uint8_t *)w;
+    for (uint32_t i = 0; i < RSBWT_BLOCK_RUNS; ++i) {
+        const uint8_t u = bytes[32u * (i / RSBWT_LANE_RUNS) + 8u + (i % RSBWT_LANE_RUNS)];
+        const uint32_t len = u & 31u;
+        if ((uint32_t)(u >> 5) != b) { index += len; continue; }
+        if (offset <= len) { index += offset - 1; break; }
+        offset -= len;
+        index += len;
+    }
+    return index;
+}
+
+__global__ void occ_at_batch_kernel(const rsbwt_view ix, const uint8_t *__restrict__ syms,
+                                    const uint64_t *__restrict__ bc, size_t n,
+                                    uint64_t *__restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = gid; i < n; i += nthreads) {
+        const uint32_t b = ascii_rank(syms[i]);
+        uint64_t c = bc[i];
+        const uint64_t tot = select_total(ix, b);
+        uint64_t r = ix.n;  // out of range -> n
+        if (c >= 1 && c <= tot) r = thread_occ_at(ix, b, c);
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic inputs.
+// ------------------------------------------------------------------------------------------
+__global__ void synth_runs_kernel(uint8_t *__restrict__ runs, uint64_t num_runs, uint64_t seed) {
+    // 16 run bytes per thread, stored as one uint4
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nvec = num_runs / 16;
+    for (uint64_t v = gid; v < nvec; v += nthreads) {
+        uint32_t wds[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                x |= (uint32_t)synth_run_byte(seed, v * 16 + (uint64_t)(d * 4 + k)) << (8 * k);
+            wds[d] = x;
+        }
+        reinterpret_cast<uint4 *>(runs)[v] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+    }
+    if (gid < (num_runs & 15)) runs[nvec * 16 + gid] = synth_run_byte(seed, nvec * 16 + gid);
+}
+
+// K-mers that occur in the index: start at a random row r, emit F(r) as the last symbol, then
+// repeatedly prepend BWT[r] and move r <- LF(r).  Every suffix of the k-mer then has a non-empty
+// interval.  A walk that meets '$' restarts from another row.  One quad per k-mer.
+__global__ void sample_present_kernel(const rsbwt_view ix, size_t Q, uint32_t k, size_t stride,
+                                      uint64_t seed, uint8_t *__restrict__ kmers) {
+    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
+    const uint32_t t = threadIdx.x & 3u;
+    const uint64_t nonterm = ix.n - ix.C[1];  // rows whose first symbol is not '$'
+    for (size_t q = quad; q < Q; q += nquads) {
+        uint8_t *out = kmers + q * stride;
+        bool ok = false;
+        for (uint32_t attempt = 0; attempt < 64 && !ok && nonterm > 0; ++attempt) {
+            uint64_t r = ix.C[1] + synth_mix64(seed ^ synth_mix64(q * 64 + attempt)) % nonterm;
+            uint32_t f = 1;
+            while (f < 4 && ix.C[f + 1] <= r) ++f;
+            if (t == 0u) out[k - 1] = (uint8_t)("$ACGT"[f]);
+            ok = true;
+            for (int i = (int)k - 2; i >= 0; --i) {
+                lane_block lb;
+                block_meta bm;
+                quad_fetch(ix, r, t, lb, bm);
+                const uint32_t c = quad_char(lb, bm, t, r);
+                if (c == 0u) { ok = false; break; }
+                r = select_C(ix, c) + quad_rank(lb, bm, t, c, r) - 1ull;  // LF(r)
+                if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
+            }
+        }
+        if (!ok && t == 0u)
+            for (uint32_t i = 0; i < k; ++i) out[i] = 'A';
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host launchers
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(size_t items_per_block, size_t items, int max_blocks) {
+    size_t g = (items + items_per_block - 1) / items_per_block;
+    if (g < 1) g = 1;
+    if (g > (size_t)max_blocks) g = (size_t)max_blocks;
+    return (int)g;
+}
+
+hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
+                       void *d_valid, hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(256, Q, 8192)), dim3(256), 0, stream,
+                       (const uint8_t *)d_kmers, Q, k, stride, wpq, (uint64_t *)d_packed,
+                       (uint8_t *)d_valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
+                         uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                         unsigned long long *d_work, int num_cus, hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.
+    const int grid = grid_for(32, Q, num_cus * 8);
+    const uint64_t *pk = (const uint64_t *)d_packed;
+    const uint8_t *vd = (const uint8_t *)d_valid;
+    uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
+    if (d_work) {
+        if (counts_only)
+            hipLaunchKernelGGL((search_kernel<true, true>), dim3(grid), dim3(256), 0, stream, ix, pk,
+                               vd, Q, k, wpq, lo, up, d_work);
+        else
+            hipLaunchKernelGGL((search_kernel<true, false>), dim3(grid), dim3(256), 0, stream, ix,
+                               pk, vd, Q, k, wpq, lo, up, d_work);
+    } else {
+        if (counts_only)
+            hipLaunchKernelGGL((search_kernel<false, true>), dim3(grid), dim3(256), 0, stream, ix,
+                               pk, vd, Q, k, wpq, lo, up, d_work);
+        else
+            hipLaunchKernelGGL((search_kernel<false, false>), dim3(grid), dim3(256), 0, stream, ix,
+                               pk, vd, Q, k, wpq, lo, up, d_work);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,
+                            void *d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(occ_batch_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+                       (const uint8_t *)d_syms, (const uint64_t *)d_index, n, (uint64_t *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n, void *d_out,
+                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(char_batch_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+                       (const uint64_t *)d_index, n, (uint8_t *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
+                               void *d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(occ_at_batch_kernel, dim3(grid_for(256, n, 8192)), dim3(256), 0, stream, ix,
+                       (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream) {
+    if (num_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_runs_kernel, dim3(grid_for(256 * 16, num_runs, 16384)), dim3(256), 0,
+                       stream, (uint8_t *)d_runs, num_runs, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_present(const rsbwt_view &ix, size_t Q, uint32_t k, size_t stride,
+                                 uint64_t seed, void *d_kmers, hipStream_t stream) {
+    if (Q == 0 || k == 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_present_kernel, dim3(grid_for(64, Q, 8192)), dim3(256), 0, stream, ix,
+                       Q, k, stride, seed, (uint8_t *)d_kmers);
+    return hipGetLastError();
+}
+
+}  // namespace rsb

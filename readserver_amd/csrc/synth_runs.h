@@ -1,0 +1,39 @@
+// synth_runs.h -- the direct run-stream synthesiser: run byte i of stream `seed` is
+// a pure function of (seed, i), so the GPU fill, the host fill and any slice agree bit for bit.
+// Lengths: 20 % full units (31, i.e. pieces of long runs), 20 % 6..21, 60 % 1..4 (mean ~10.4
+// symbols per byte, a population-BWT-like mix); symbols uniform over ACGT with ~1.2 % '$'.
+#ifndef RSBWT_SYNTH_RUNS_H
+#define RSBWT_SYNTH_RUNS_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RSBWT_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define RSBWT_HD static inline
+#endif
+
+namespace rsb {
+
+RSBWT_HD uint64_t synth_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+RSBWT_HD uint8_t synth_run_byte(uint64_t seed, uint64_t i) {
+    const uint64_t h = synth_mix64(seed * 0xD1342543DE82EF95ull + i);
+    const uint32_t a = (uint32_t)(h & 0xFF);
+    const uint32_t sym = a < 3u ? 0u : 1u + (uint32_t)((h >> 8) & 3u);
+    const uint32_t u = (uint32_t)((h >> 16) % 10u);
+    const uint32_t v = (uint32_t)(h >> 32);
+    uint32_t len;
+    if (u < 2u) len = 31u;
+    else if (u < 4u) len = 6u + (v & 15u);
+    else len = 1u + (v & 3u);
+    return (uint8_t)((sym << 5) | len);
+}
+
+}  // namespace rsb
+#endif

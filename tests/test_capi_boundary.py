@@ -1,0 +1,73 @@
+"""CPU suite: the C-ABI library loads and exports exactly what include/rsbwt.h declares, and
+fails loudly (RSBWT_ENODEV, never a CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "rsbwt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsbwt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound(rsb):
+    from readserver_amd import _native
+    names = _declared()
+    assert len(names) >= 40
+    L = C.CDLL(rsb.lib_path())
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/rsbwt.h but not exported"
+    assert sorted(_native.SIGNATURES) == names, "ctypes binding and header disagree"
+
+
+def test_version_and_errors(rsb):
+    L = rsb.lib()
+    assert b"rsbwt" in L.rsbwt_version()
+    assert L.rsbwt_strerror(-5) == b"no usable HIP device"
+    assert L.rsbwt_strerror(-3) == b"not an SGA run-length BWT file"
+
+
+def test_no_gpu_means_loud_failure(rsb, tmp_path):
+    L = rsb.lib()
+    if L.rsbwt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    runs = np.array([(1 << 5) | 3, (2 << 5) | 1], np.uint8)
+    with pytest.raises(rsb.RsbwtError) as e:
+        rsb.GpuBWT(runs=runs, num_strings=0)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_files_are_reported_not_fatal(rsb, tmp_path):
+    # the reference exits the process on a bad magic (src/bwt/rlebwt_reader.cpp:31-34)
+    with pytest.raises(rsb.RsbwtError) as e:
+        rsb.GpuBWT(str(tmp_path / "missing.bwt"))
+    assert e.value.code == -2
+    bad = tmp_path / "bad.bwt"
+    bad.write_bytes(b"\xEF\xEF" + b"\0" * 40)
+    with pytest.raises(rsb.RsbwtError) as e:
+        rsb.GpuBWT(str(bad))
+    assert e.value.code == -3
+    trunc = tmp_path / "trunc.bwt"
+    trunc.write_bytes(b"\xCA\xCA" + (1).to_bytes(8, "little") + (100).to_bytes(8, "little")
+                      + (50).to_bytes(8, "little") + b"\0\0\0\0" + b"\x21" * 10)
+    with pytest.raises(rsb.RsbwtError) as e:
+        rsb.GpuBWT(str(trunc))
+    assert e.value.code == -3
+
+
+def test_synth_runs_host_matches_documented_mix(rsb):
+    L = rsb.lib()
+    a = np.empty(200000, np.uint8)
+    b = np.empty(200000, np.uint8)
+    assert L.rsbwt_synth_runs_host(a.ctypes.data, a.size, 42) == 0
+    assert L.rsbwt_synth_runs_host(b.ctypes.data, b.size, 42) == 0
+    assert np.array_equal(a, b)
+    ln = a & 31
+    assert ln.min() >= 1 and 9.5 < ln.mean() < 11.5
+    assert (a >> 5).max() <= 4 and 0.005 < np.mean((a >> 5) == 0) < 0.02

@@ -1,0 +1,317 @@
+"""GPU suite (-m gpu): the HIP engine, called through the C-ABI, against the oracle and the
+reference's golden vectors.  Bit-exact: every value is an integer or a byte."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_runs(rng, R, with_dollar=True):
+    sym = rng.integers(0 if with_dollar else 1, 5, R).astype(np.uint8)
+    ln = rng.integers(1, 32, R).astype(np.uint8)
+    return (sym << 5) | ln
+
+
+def _random_kmers(rng, Q, k):
+    return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (Q, k))]
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "popbwt_v1.npz"))
+
+
+@pytest.fixture(scope="module")
+def gix(rsb, fixture_bwt):
+    path, meta = fixture_bwt
+    g = rsb.GpuBWT(path)
+    assert g.getBWLen() == meta["num_symbols"]
+    assert g.num_runs() == meta["num_runs"]
+    assert g.num_strings() == meta["num_strings"]
+    yield g
+    g.close()
+
+
+# ---- golden vectors of the real reference ------------------------------------------------------
+
+def test_gpu_golden_pc(gix, golden):
+    assert [gix.getPC(c) for c in "$ACGT"] == golden["pc"].tolist()
+
+
+def test_gpu_golden_31mers(rsb, gix, golden):
+    lo, up = rsb.find_intervals(gix, golden["kmers31"])
+    assert np.array_equal(lo, golden["lower31"])
+    assert np.array_equal(up, golden["upper31"])
+    cnt = rsb.count_kmers(gix, golden["kmers31"])
+    exp = np.where(golden["upper31"] >= golden["lower31"], golden["upper31"] - golden["lower31"] + 1, 0)
+    assert np.array_equal(cnt, exp.astype(np.uint64))
+
+
+def test_gpu_golden_ladder(rsb, gix, golden, fixture_bwt):
+    for kk in fixture_bwt[1]["ladder"]:
+        lo, up = rsb.find_intervals(gix, golden[f"kmers{kk}"])
+        assert np.array_equal(lo, golden[f"lower{kk}"]), kk
+        assert np.array_equal(up, golden[f"upper{kk}"]), kk
+
+
+def test_gpu_golden_occ_char_occ_at(gix, golden):
+    pos = golden["occ_pos"]
+    for c, ch in enumerate("$ACGT"):
+        assert np.array_equal(gix.occ_batch(ch, pos), golden["occ_tab"][c]), ch
+    syms = bytes(b"$ACGT"[c] for c in golden["sel_sym"])
+    assert np.array_equal(gix.occ_at_batch(syms, golden["sel_bc"]), golden["sel_idx"])
+    # BWT[OccAt(b, bc)] == b
+    ch = gix.char_batch(golden["sel_idx"])
+    assert ch.tobytes() == syms
+
+
+def test_gpu_golden_extract(rsb, gix, golden):
+    for r, e, n in list(zip(golden["rows"], golden["ext"], golden["ext_len"]))[:40]:
+        s = rsb.extractPrefix(gix, int(r)) + rsb.extractPostfix(gix, int(r))
+        assert s.encode() == e[:n].tobytes()
+
+
+def test_gpu_single_query_mirrors(rsb, gix, golden):
+    w = golden["kmers31"][0].tobytes().decode()
+    itv = rsb.findInterval(gix, w)
+    assert (itv.lower, itv.upper) == (int(golden["lower31"][0]), int(golden["upper31"][0]))
+    assert gix.getOcc("A", -1) == 0
+    assert gix.getF(0) == "$" and gix.getF(gix.getBWLen() - 1) == "T"
+    reads = rsb.query(gix, w)
+    assert len(reads) == itv.upper - itv.lower + 1 and all(w in r for r in reads)
+    assert rsb.query_exactmatch(gix, reads[0])
+    assert not rsb.query_exactmatch(gix, w)
+    assert rsb.query(gix, "ACGN") == []
+
+
+# ---- oracle parity on seeded random run streams -------------------------------------------------
+
+@pytest.mark.parametrize("R,shift", [(1, 0), (2, 0), (95, 0), (96, 0), (97, 0), (1000, 0), (5000, 8),
+                                     (5000, 10), (70000, 0), (70000, 12), (300000, 9), (300000, 16)])
+def test_gpu_occ_char_vs_oracle(rsb, oracle, R, shift):
+    rng = np.random.default_rng(R + shift)
+    runs = _random_runs(rng, R)
+    oix = oracle.from_runs(runs)
+    with rsb.GpuBWT(runs=runs, dir_shift=shift) as g:
+        n = g.getBWLen()
+        assert n == oix.bwlen()
+        if shift:
+            assert g.dir_shift() == shift
+        assert [g.getPC(c) for c in "$ACGT"] == [oix.pc(c) for c in "$ACGT"]
+        pos = np.arange(n, dtype=np.uint64) if n <= 200000 else np.unique(np.concatenate([
+            rng.integers(0, n, 100000), np.arange(n - 5000, n), np.arange(5000)])).astype(np.uint64)
+        nv = ob.NaiveIndex(runs)
+        for c, ch in enumerate("$ACGT"):
+            got = g.occ_batch(ch, pos)
+            assert np.array_equal(got, nv.cum[c, 1:][pos.astype(np.int64)].astype(np.uint64)), ch
+            for p in pos[:: max(1, pos.size // 50)]:
+                assert got[np.searchsorted(pos, p)] == oix.occ(ch, int(p))
+        assert g.char_batch(pos).tobytes() == bytes(b"$ACGT"[x] for x in nv.bwt[pos.astype(np.int64)])
+        for c, ch in enumerate("$ACGT"):
+            where = np.nonzero(nv.bwt == c)[0]
+            if where.size:
+                bc = rng.integers(1, where.size + 1, min(2000, where.size)).astype(np.uint64)
+                assert np.array_equal(g.occ_at_batch(ch, bc), where[bc.astype(np.int64) - 1].astype(np.uint64))
+
+
+def test_gpu_dense_runs_force_directory_hops(rsb, oracle):
+    # all runs of length 1: 96-symbol blocks, so windows of 2^12 symbols hold ~42 block starts
+    rng = np.random.default_rng(9)
+    runs = ((rng.integers(1, 5, 200000).astype(np.uint8)) << 5) | 1
+    oix = oracle.from_runs(runs)
+    for shift in (8, 12, 16):
+        with rsb.GpuBWT(runs=runs, dir_shift=shift) as g:
+            km = _random_kmers(rng, 20000, 9)
+            lo, up = rsb.find_intervals(g, km)
+            elo, eup = oix.find_intervals(km)
+            assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+
+
+@pytest.mark.parametrize("R,with_dollar", [(50, True), (3000, False), (200000, True), (4000000, True)])
+def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar):
+    rng = np.random.default_rng(77 + R)
+    runs = _random_runs(rng, R, with_dollar)
+    oix = oracle.from_runs(runs)
+    with rsb.GpuBWT(runs=runs) as g:
+        for k in (1, 2, 7, 16, 31, 32, 33, 64, 65, 100):
+            Q = 3000 if R < 1000000 else 20000
+            km = _random_kmers(rng, Q, k)
+            lo, up = rsb.find_intervals(g, km)
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo, elo), (R, k)
+            assert np.array_equal(up, eup), (R, k)
+            cnt = rsb.count_kmers(g, km)
+            assert np.array_equal(cnt, np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64))
+
+
+def test_gpu_invalid_and_ragged_inputs(rsb, oracle):
+    rng = np.random.default_rng(3)
+    runs = _random_runs(rng, 10000)
+    oix = oracle.from_runs(runs)
+    with rsb.GpuBWT(runs=runs) as g:
+        km = _random_kmers(rng, 1000, 31)
+        km[::7, 5] = ord("N")
+        km[3, 30] = ord("$")
+        km[4, 0] = ord("a")
+        lo, up = rsb.find_intervals(g, km)
+        elo, eup = oix.find_intervals(km)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+        assert (lo[::7] == 1).all() and (up[::7] == 0).all()
+        assert (rsb.count_kmers(g, km)[::7] == 0).all()
+        # empty batch and k == 0
+        lo, up = rsb.find_intervals(g, np.zeros((0, 31), np.uint8))
+        assert lo.size == 0
+        lo, up = rsb.find_intervals(g, np.zeros((5, 0), np.uint8))
+        assert (lo == 1).all() and (up == 0).all()
+
+
+def test_gpu_present_kmers_survive_every_step(rsb, oracle):
+    """rsbwt_sample_present_kmers_dev: LF-walk k-mers keep a non-empty interval for all k-1 steps."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(21)
+    runs = _random_runs(rng, 500000)
+    oix = oracle.from_runs(runs)
+    L = rsb.lib()
+    with rsb.GpuBWT(runs=runs) as g:
+        Q, k = 5000, 31
+        d = torch.empty((Q, k), dtype=torch.uint8, device="cuda:0")
+        rc = L.rsbwt_sample_present_kmers_dev(g.handle, Q, k, k, 99, C.c_void_p(d.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        km = d.cpu().numpy()
+        assert set(np.unique(km)) <= set(b"ACGT")
+        lo, up, steps = oix.find_intervals(km, want_steps=True)
+        assert (up >= lo).all() and (steps == k - 1).all()
+        glo, gup = rsb.find_intervals(g, km)
+        assert np.array_equal(glo, lo) and np.array_equal(gup, up)
+
+
+def test_gpu_device_synth_equals_host_synth(rsb):
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    n = 1000003
+    d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_synth_runs_dev(C.c_void_p(d.data_ptr()), n, 1234, 0, None) == 0
+    torch.cuda.synchronize()
+    h = np.empty(n, np.uint8)
+    assert L.rsbwt_synth_runs_host(h.ctypes.data, n, 1234) == 0
+    assert np.array_equal(d.cpu().numpy(), h)
+
+
+def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
+    """The *_dev forms bench.py uses: pack + search on device buffers, HIP-event timing, and the
+    exact LF-step / Occ / block counters against the oracle's step counts."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    rng = np.random.default_rng(8)
+    R = 2000000
+    d_runs = torch.empty(R, dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, 5, 0, None) == 0
+    torch.cuda.synchronize()
+    runs = d_runs.cpu().numpy()
+    oix = oracle.from_runs(runs)
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
+    Q, k = 50000, 31
+    km = _random_kmers(rng, Q, k)
+    d_km = torch.from_numpy(km).cuda()
+    d_pk = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_ok = torch.empty(Q, dtype=torch.uint8, device="cuda:0")
+    d_lo = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_up = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, s) == 0
+    assert L.rsbwt_set_counting(g.handle, 1) == 0
+    assert L.rsbwt_find_intervals_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), p(d_up), s) == 0
+    ms = C.c_float()
+    assert L.rsbwt_last_search_ms(g.handle, C.byref(ms)) == 0 and ms.value > 0
+    st, oc, bl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert L.rsbwt_last_search_work(g.handle, C.byref(st), C.byref(oc), C.byref(bl)) == 0
+    elo, eup, steps = oix.find_intervals(km, nthreads=8, want_steps=True)
+    assert np.array_equal(d_lo.cpu().numpy().view(np.uint64), elo)
+    assert np.array_equal(d_up.cpu().numpy().view(np.uint64), eup)
+    assert st.value == int(steps.sum())
+    assert oc.value == 2 * st.value and st.value <= bl.value <= oc.value
+    assert L.rsbwt_set_counting(g.handle, 0) == 0
+    d_cnt = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    assert L.rsbwt_count_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_cnt), s) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy().view(np.uint64), np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64))
+    g.close()
+
+
+def test_gpu_file_open_and_shard_set(rsb, oracle, tmp_path):
+    kw = dict(seed=13, genome_len=20000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=3.0)
+    shards, oixs = [], []
+    for s in range(4):
+        p = str(tmp_path / f"s{s}.bwt")
+        rsb.synth_popbwt(p, None, shard=s, num_shards=4, **kw)
+        shards.append(rsb.GpuBWT(p))
+        oixs.append(oracle.load(p))
+    whole = str(tmp_path / "whole.bwt")
+    rd = str(tmp_path / "whole.reads")
+    rsb.synth_popbwt(whole, rd, **kw)
+    reads = open(rd).read().split()
+    rng = np.random.default_rng(2)
+    km = np.array([np.frombuffer(reads[i][j:j + 31].encode(), np.uint8)
+                   for i, j in zip(rng.integers(0, len(reads), 2000), rng.integers(0, 29, 2000))])
+    ss = rsb.ShardSet(shards)
+    lo, up = ss.find_intervals(km)
+    for s in range(4):
+        elo, eup = oixs[s].find_intervals(km)
+        assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup)
+    # per-shard counts add up to the unsharded index's (the front-end sums partitions:
+    # src/service/server.cpp:184-197)
+    with rsb.GpuBWT(whole) as gw:
+        assert np.array_equal(ss.count(km), rsb.count_kmers(gw, km))
+    ss.close()
+    for g in shards:
+        g.close()
+
+
+# ---- full-size properties (sizes the oracle cannot sweep exhaustively) --------------------------
+
+def test_gpu_large_index_properties(rsb, oracle):
+    """R = 2^28 run bytes (~2.8e9 symbols, > 2^32 positions is exercised by 40-bit counts in the
+    headers): sum_b Occ(b, p) == p + 1, Occ monotone, BWT[OccAt(b, c)] == b, and a sampled
+    comparison with the oracle built over the same bytes."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    R = 1 << 28
+    d_runs = torch.empty(R, dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, 77, 0, None) == 0
+    torch.cuda.synchronize()
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
+    n = g.getBWLen()
+    assert n > (1 << 31)
+    rng = np.random.default_rng(4)
+    pos = np.sort(rng.integers(0, n, 200000)).astype(np.uint64)
+    tot = np.zeros(pos.size, np.uint64)
+    for ch in "$ACGT":
+        o = g.occ_batch(ch, pos)
+        assert (np.diff(o.astype(np.int64)) >= 0).all()
+        tot += o
+    assert np.array_equal(tot, pos + 1)
+    for ch in "ACGT":
+        last = g.getOcc(ch, n - 1)
+        assert g.getPC(ch) + last == (g.getPC("ACGT"["ACGT".index(ch) + 1]) if ch != "T" else n)
+        bc = rng.integers(1, last + 1, 5000).astype(np.uint64)
+        idx = g.occ_at_batch(ch, bc)
+        assert (g.char_batch(idx) == ord(ch)).all()
+        assert np.array_equal(g.occ_batch(ch, idx), bc)
+    runs = d_runs.cpu().numpy()
+    del d_runs
+    oix = oracle.from_runs(runs)
+    km = _random_kmers(rng, 200000, 31)
+    lo, up = rsb.find_intervals(g, km)
+    elo, eup = oix.find_intervals(km, nthreads=16)
+    assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+    g.close()
