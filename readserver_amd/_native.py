@@ -97,6 +97,14 @@ def lib():
                     f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(or readserver_amd/build.sh). The popBWT engine is the HIP library only; "
                     "there is no CPU fallback.")
+            # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7.
+            # If torch is installed, load it first so that librsbwt's libamdhip64.so.7 dependency
+            # binds to the copy torch uses (two runtimes in one process cannot both own the GPU).
+            if os.environ.get("RSBWT_NO_TORCH_PRELOAD") != "1":
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             L = C.CDLL(_LIB)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)
