@@ -69,8 +69,11 @@ struct lane_block {
 __device__ __forceinline__ lane_block load_lane_block(const rsbwt_view &ix, uint64_t blk,
                                                       uint32_t t) {
     const uint4 *bp = ix.blocks + blk * 8u + t * 2u;
-    const uint4 a = bp[0];
-    const uint4 c = bp[1];
+    uint4 a = bp[0];
+    uint4 c = bp[1];
+    // Pin both 16-B loads here: left alone, hipcc fetches only the meta dword first (for the hop
+    // test below) and the rest after it -- two dependent HBM round trips instead of one.
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
     lane_block lb;
     lb.hdr_lo = a.x;
     lb.hdr_hi = a.y;
@@ -171,10 +174,12 @@ __device__ __forceinline__ uint64_t quad_fetch(const rsbwt_view &ix, uint64_t p,
     uint64_t blk = dir_lookup(ix, p);
     lb = load_lane_block(ix, blk, t);
     bm = quad_block_meta(lb);
-    while (p >= bm.P0 + bm.span && blk + 1 < ix.nblocks) {
-        ++blk;
-        lb = load_lane_block(ix, blk, t);
-        bm = quad_block_meta(lb);
+    if (__builtin_expect(p >= bm.P0 + bm.span, 0)) {
+        while (p >= bm.P0 + bm.span && blk + 1 < ix.nblocks) {
+            ++blk;
+            lb = load_lane_block(ix, blk, t);
+            bm = quad_block_meta(lb);
+        }
     }
     return blk;
 }

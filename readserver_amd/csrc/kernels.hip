@@ -72,7 +72,10 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     while (q < Q) {
         if (fresh) {
             fresh = false;
-            const bool ok = valid[q] != 0;
+            j = (int)k - 1;
+            const uint8_t okb = valid[q];  // both loads issue together
+            word = packed[q * wpq + ((uint32_t)j >> 5)];
+            const bool ok = okb != 0;
             if (!ok) {
                 if ((lane & 7u) == 0u) {
                     if (COUNTS_ONLY) out_lower[q] = 0;
@@ -82,8 +85,6 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                 fresh = true;
                 continue;
             }
-            j = (int)k - 1;
-            word = packed[q * wpq + ((uint32_t)j >> 5)];
             const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
             // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
             lo = select_C(ix, b);

@@ -1,0 +1,178 @@
+// gather_bench.hip -- what the MI355X memory system gives to the access pattern of an Occ lookup.
+//
+// Standalone microbenchmark (not part of the library).  A DPP quad (4 lanes) fetches random,
+// aligned records from a large HBM buffer with nothing else to do, so the rates printed here are
+// the ceiling for any kernel that makes the same accesses:
+//   line128   one random 128-B line per quad per load pair      (the block fetch of an Occ lookup)
+//   line64    one random 64-B half line per quad                (smaller blocks)
+//   dep       8-B entry from a second table, then the 128-B line it selects
+//             (directory entry -> block: the two dependent accesses of today's Occ lookup)
+// Usage: gather_bench [buffer_GiB=32] [dir_GiB=6] [iters=64] [blocks_per_cu=8]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                 \
+            exit(1);                                                               \
+        }                                                                          \
+    } while (0)
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(256)
+line128_kernel(const uint4 *__restrict__ buf, uint64_t nlines, int iters, uint32_t *__restrict__ sink) {
+    const uint64_t quad = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t t = threadIdx.x & 3;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint4 a[UNROLL], b[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t line = mix64(quad * 1315423911ull + (uint64_t)(it * UNROLL + u)) % nlines;
+            const uint4 *p = buf + line * 8 + t * 2;
+            a[u] = p[0];
+            b[u] = p[1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= a[u].x ^ a[u].w ^ b[u].y ^ b[u].z;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(256)
+line64_kernel(const uint4 *__restrict__ buf, uint64_t nhalf, int iters, uint32_t *__restrict__ sink) {
+    const uint64_t quad = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t t = threadIdx.x & 3;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint4 a[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t h = mix64(quad * 1315423911ull + (uint64_t)(it * UNROLL + u)) % nhalf;
+            a[u] = buf[h * 4 + t];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= a[u].x ^ a[u].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// dependent pair: dir[random] (8 B) -> line index -> 128-B line; the next address depends on the
+// line just read (as the next LF step depends on the rank just computed).
+template <int CHAINS>
+__global__ void __launch_bounds__(256)
+dep_kernel(const uint4 *__restrict__ buf, uint64_t nlines, const uint2 *__restrict__ dir,
+           uint64_t ndir, int iters, uint32_t *__restrict__ sink) {
+    const uint64_t quad = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t t = threadIdx.x & 3;
+    uint64_t state[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) state[c] = mix64(quad * CHAINS + c);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint2 e[CHAINS];
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) e[c] = dir[state[c] % ndir];
+        uint4 a[CHAINS], b[CHAINS];
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) {
+            const uint64_t line = (mix64(state[c]) + e[c].x) % nlines;
+            const uint4 *p = buf + line * 8 + t * 2;
+            a[c] = p[0];
+            b[c] = p[1];
+        }
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) {
+            uint32_t v = a[c].x ^ b[c].w;
+            v ^= __shfl_xor(v, 1);
+            v ^= __shfl_xor(v, 2);
+            state[c] = mix64(state[c] + v);
+            acc ^= v;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+__global__ void fill_kernel(uint4 *buf, uint64_t n16) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nt = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = gid; i < n16; i += nt) {
+        const uint32_t h = (uint32_t)mix64(i);
+        buf[i] = make_uint4(h, h ^ 1, h ^ 2, h ^ 3);
+    }
+}
+
+template <typename F>
+static double time_ms(F launch, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char **argv) {
+    const double buf_gib = argc > 1 ? atof(argv[1]) : 32.0;
+    const double dir_gib = argc > 2 ? atof(argv[2]) : 6.0;
+    const int iters = argc > 3 ? atoi(argv[3]) : 64;
+    const int bpc = argc > 4 ? atoi(argv[4]) : 8;
+    const uint64_t nlines = (uint64_t)(buf_gib * (1ull << 30)) / 128;
+    const uint64_t ndir = (uint64_t)(dir_gib * (1ull << 30)) / 8;
+    uint4 *buf;
+    uint2 *dir;
+    uint32_t *sink;
+    CK(hipMalloc(&buf, nlines * 128));
+    CK(hipMalloc(&dir, ndir * 8));
+    CK(hipMalloc(&sink, 4));
+    fill_kernel<<<4096, 256>>>(buf, nlines * 8);
+    fill_kernel<<<4096, 256>>>((uint4 *)dir, ndir / 2);
+    CK(hipDeviceSynchronize());
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int grid = prop.multiProcessorCount * bpc;
+    const uint64_t quads = (uint64_t)grid * 64;
+    printf("# buffer %.1f GiB (%llu lines), dir %.1f GiB, %d CUs x %d blocks of 256, iters %d\n", buf_gib,
+           (unsigned long long)nlines, dir_gib, prop.multiProcessorCount, bpc, iters);
+    printf("%-22s %12s %12s %12s\n", "pattern", "ms", "Gacc/s", "GB/s");
+#define RUN128(U)                                                                                   \
+    {                                                                                               \
+        double ms = time_ms([&] { line128_kernel<U><<<grid, 256>>>(buf, nlines, iters, sink); }, 3); \
+        double acc = (double)quads * iters * U;                                                     \
+        printf("line128 x%-2d inflight   %12.3f %12.2f %12.1f\n", U, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
+    }
+    RUN128(1) RUN128(2) RUN128(4) RUN128(8)
+#define RUN64(U)                                                                                    \
+    {                                                                                               \
+        double ms = time_ms([&] { line64_kernel<U><<<grid, 256>>>(buf, nlines * 2, iters, sink); }, 3); \
+        double acc = (double)quads * iters * U;                                                     \
+        printf("line64  x%-2d inflight   %12.3f %12.2f %12.1f\n", U, ms, acc / ms / 1e6, acc * 64 / ms / 1e6); \
+    }
+    RUN64(1) RUN64(2) RUN64(4) RUN64(8)
+#define RUNDEP(CH)                                                                                  \
+    {                                                                                               \
+        double ms = time_ms([&] { dep_kernel<CH><<<grid, 256>>>(buf, nlines, dir, ndir, iters, sink); }, 3); \
+        double acc = (double)quads * iters * CH;                                                    \
+        printf("dep dir->line x%-2d      %12.3f %12.2f %12.1f\n", CH, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
+    }
+    RUNDEP(1) RUNDEP(2) RUNDEP(4)
+    return 0;
+}
