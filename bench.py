@@ -124,10 +124,10 @@ def main():
     d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     d_lower = torch.empty((S, Q), dtype=torch.int64, device=dev)
     d_upper = torch.empty((S, Q), dtype=torch.int64, device=dev)
+    from readserver_amd import sharded
     gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty((2, S, Q), dtype=torch.int64, device=dev) for _ in range(world)]
-    d_pair = torch.empty((2, S, Q), dtype=torch.int64, device=dev) if world > 1 else None
 
     def step():
         ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
@@ -135,9 +135,7 @@ def main():
             ok(L.rsbwt_find_intervals_dev(g.handle, ptr(d_packed), ptr(d_valid), Q, k,
                                           ptr(d_lower[s]), ptr(d_upper[s]), sp))
         if world > 1:
-            d_pair[0].copy_(d_lower)
-            d_pair[1].copy_(d_upper)
-            dist.gather(d_pair, gathered, dst=0)
+            sharded.gather_intervals(d_lower, d_upper, dst=0, out=gathered)
 
     def barrier():
         torch.cuda.synchronize()

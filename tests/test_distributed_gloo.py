@@ -1,0 +1,90 @@
+"""CPU suite: the N > 1 path (readserver_amd/sharded.py) with world_size 2 over gloo.
+
+Each rank owns two of four suffix shards of a synthetic popBWT.  The per-shard search itself needs
+the GPU, so here the oracle stands in for it (tests may use the oracle as checker/stand-in); what is
+under test is the sharding, the broadcast of the batch, the gather of intervals and the reduction
+of counts -- against the unsharded index."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_binding
+        from readserver_amd import sharded
+        orc = oracle_binding.load()
+        S = 4
+        mine = sharded.local_shards(rank, S, world)
+        assert mine == [2 * rank, 2 * rank + 1]
+        assert all(sharded.shard_owner(s, S, world) == rank for s in mine)
+        idx = [orc.load(os.path.join(tmp, f"s{s}.bwt")) for s in mine]
+        Q, k = 500, 31
+        km = torch.zeros((Q, k), dtype=torch.uint8)
+        if rank == 0:
+            km = torch.from_numpy(np.load(os.path.join(tmp, "kmers.npy")))
+        km = sharded.broadcast_queries(km)
+        a = km.numpy()
+        lo = np.empty((len(idx), Q), np.uint64)
+        up = np.empty((len(idx), Q), np.uint64)
+        for i, ix in enumerate(idx):
+            lo[i], up[i] = ix.find_intervals(a)
+        tl = torch.from_numpy(lo.view(np.int64))
+        tu = torch.from_numpy(up.view(np.int64))
+        g = sharded.gather_intervals(tl, tu)
+        cnt = torch.from_numpy(np.where(up >= lo, up - lo + 1, 0).sum(0).astype(np.int64))
+        tot = sharded.reduce_counts(cnt)
+        if rank == 0:
+            assert g.shape == (world, 2, 2, Q)
+            whole = orc.load(os.path.join(tmp, "whole.bwt"))
+            wlo, wup = whole.find_intervals(a)
+            exp = np.where(wup >= wlo, wup - wlo + 1, 0)
+            assert np.array_equal(tot.numpy().astype(np.uint64), exp.astype(np.uint64))
+            # rank r's slice is shards 2r, 2r+1 in order
+            for r in range(world):
+                for j in range(2):
+                    ix = orc.load(os.path.join(tmp, f"s{2 * r + j}.bwt"))
+                    elo, eup = ix.find_intervals(a)
+                    assert np.array_equal(g[r, 0, j].numpy().view(np.uint64), elo)
+                    assert np.array_equal(g[r, 1, j].numpy().view(np.uint64), eup)
+            q.put("ok")
+        else:
+            assert g is None and tot is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_and_reduce(rsb, tmp_path):
+    kw = dict(seed=17, genome_len=8000, haplotypes=4, snp_rate=0.004, read_len=50, coverage=3.0)
+    for s in range(4):
+        rsb.synth_popbwt(str(tmp_path / f"s{s}.bwt"), None, shard=s, num_shards=4, **kw)
+    rd = str(tmp_path / "whole.reads")
+    rsb.synth_popbwt(str(tmp_path / "whole.bwt"), rd, **kw)
+    reads = open(rd).read().split()
+    rng = np.random.default_rng(0)
+    km = np.array([np.frombuffer(reads[i][j:j + 31].encode(), np.uint8)
+                   for i, j in zip(rng.integers(0, len(reads), 500), rng.integers(0, 19, 500))])
+    km[::5] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, km[::5].shape)]
+    np.save(str(tmp_path / "kmers.npy"), km)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get() == "ok"

@@ -69,6 +69,26 @@ line64_kernel(const uint4 *__restrict__ buf, uint64_t nhalf, int iters, uint32_t
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// LANES lanes share one random 128-B line; each lane reads 128/LANES bytes as 16-B loads.
+template <int LANES>
+__global__ void __launch_bounds__(256)
+lane_kernel(const uint4 *__restrict__ buf, uint64_t nlines, int iters, uint32_t *__restrict__ sink) {
+    constexpr int PIECES = 8 / LANES;
+    const uint64_t grp = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const uint32_t t = threadIdx.x % LANES;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint64_t line = mix64(grp * 1315423911ull + (uint64_t)it) % nlines;
+        const uint4 *p = buf + line * 8 + t * PIECES;
+        uint4 a[PIECES];
+#pragma unroll
+        for (int u = 0; u < PIECES; ++u) a[u] = p[u];
+#pragma unroll
+        for (int u = 0; u < PIECES; ++u) acc ^= a[u].x ^ a[u].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // dependent pair: dir[random] (8 B) -> line index -> 128-B line; the next address depends on the
 // line just read (as the next LF step depends on the rank just computed).
 template <int CHAINS>
@@ -174,5 +194,12 @@ int main(int argc, char **argv) {
         printf("dep dir->line x%-2d      %12.3f %12.2f %12.1f\n", CH, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
     }
     RUNDEP(1) RUNDEP(2) RUNDEP(4)
+#define RUNLANE(LN)                                                                                 \
+    {                                                                                               \
+        double ms = time_ms([&] { lane_kernel<LN><<<grid, 256>>>(buf, nlines, iters, sink); }, 3);  \
+        double acc = (double)grid * 256 / LN * iters;                                               \
+        printf("%d lane(s) per line      %12.3f %12.2f %12.1f\n", LN, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
+    }
+    RUNLANE(1) RUNLANE(2) RUNLANE(4) RUNLANE(8)
     return 0;
 }
