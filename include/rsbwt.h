@@ -45,6 +45,13 @@ extern "C" {
 /* open flags */
 #define RSBWT_DIR_SHIFT_AUTO 0u /* low 5 bits: log2 symbols per directory window, 0 = auto */
 #define RSBWT_DIR_SHIFT_MASK 0x1Fu
+/* bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
+ * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (about 6 % of the
+ * index), 31 = no table, else T = 2..15. */
+#define RSBWT_KTAB_SHIFT 5
+#define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
+#define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
+#define RSBWT_KTAB_DEPTH(t) ((uint32_t)(t) << RSBWT_KTAB_SHIFT)
 
 typedef struct rsbwt rsbwt_t;         /* one BWT shard resident in one GPU's HBM */
 typedef struct rsbwt_set rsbwt_set_t; /* several shards on this process's GPU(s) */
@@ -88,6 +95,7 @@ uint64_t rsbwt_num_runs(const rsbwt_t *h);
 uint64_t rsbwt_num_strings(const rsbwt_t *h);
 uint64_t rsbwt_num_blocks(const rsbwt_t *h);
 uint32_t rsbwt_dir_shift(const rsbwt_t *h);
+uint32_t rsbwt_ktab_depth(const rsbwt_t *h); /* 0 = no k-mer table */
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h); /* blocks + directory + tables */
 int rsbwt_device(const rsbwt_t *h);
 
@@ -124,6 +132,8 @@ int rsbwt_search_history_ms(rsbwt_t *h, float *ms, size_t cap, size_t *count);
 int rsbwt_set_counting(rsbwt_t *h, int on);
 int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups,
                            uint64_t *block_reads);
+/* ... and the number of k-mer-table lookups of that launch. */
+int rsbwt_last_search_ktab_lookups(rsbwt_t *h, uint64_t *lookups);
 
 /* Synthetic data (bench / tests) ----------------------------------------------- */
 /* Fill d_runs (HBM) with num_runs pseudo-random RLUnit bytes: the direct run-stream

@@ -61,6 +61,7 @@ SIGNATURES = {
     "rsbwt_num_strings": (C.c_uint64, [_vp]),
     "rsbwt_num_blocks": (C.c_uint64, [_vp]),
     "rsbwt_dir_shift": (C.c_uint32, [_vp]),
+    "rsbwt_ktab_depth": (C.c_uint32, [_vp]),
     "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
     "rsbwt_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "rsbwt_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_counting": (C.c_int, [_vp, C.c_int]),
     "rsbwt_last_search_work": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
+    "rsbwt_last_search_ktab_lookups": (C.c_int, [_vp, _u64p]),
     "rsbwt_synth_runs_dev": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "rsbwt_synth_runs_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "rsbwt_sample_present_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint64, _vp, _vp]),

@@ -46,10 +46,12 @@ class GpuBWT:
     """
 
     def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
-                 dir_shift=0):
+                 dir_shift=0, ktab_depth=0):
+        """dir_shift: log2 symbols per directory window (0 = auto).  ktab_depth: depth of the k-mer
+        table (0 = auto, None = no table)."""
         self._h = C.c_void_p()
         L = lib()
-        flags = int(dir_shift) & 0x1F
+        flags = (int(dir_shift) & 0x1F) | ((31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5)
         if filename is not None:
             check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
         elif runs is not None:
@@ -149,6 +151,9 @@ class GpuBWT:
 
     def dir_shift(self):
         return lib().rsbwt_dir_shift(self._h)
+
+    def ktab_depth(self):
+        return lib().rsbwt_ktab_depth(self._h)
 
     def hbm_bytes(self):
         return lib().rsbwt_hbm_bytes(self._h)

@@ -22,6 +22,10 @@
 //   block(p) = id + #{k : offs_k != 0 && (p & (2^s-1)) >= offs_k}, exact whenever window w holds
 //   at most K block starts (always for s == 8, as a full block spans >= 96 symbols); otherwise
 //   a lower bound that the reader advances while p >= P0 + span.
+//
+// K-MER TABLE (8 B per T-mer, 4^T entries): the interval findInterval returns for every string of
+// T symbols over ACGT, so a search of k >= T symbols starts from one lookup on its last T symbols
+// instead of T-1 LF steps.  Code of a T-mer = its 2-bit packing (symbol i at bits 2i).
 #ifndef RSBWT_BLOCK_FORMAT_H
 #define RSBWT_BLOCK_FORMAT_H
 
@@ -47,6 +51,13 @@ struct rsbwt_view {
     uint64_t total[5];    // occurrences of each symbol in the whole BWT
     uint32_t dir_shift;   // s
     uint32_t dir_fields;  // K = 32 / s
+    // k-mer table (optional): entry c = interval of the T-mer whose 2-bit code is c, i.e. what
+    // findInterval returns for it (early exit included): bits 0..39 lower, bits 40..63 width =
+    // upper - lower + 1 (0 = empty, upper = lower - 1; RSBWT_KTAB_WIDE = not tabulated).
+    const uint64_t *ktab;
+    uint32_t ktab_depth;  // T (0 = no table)
 };
+
+#define RSBWT_KTAB_WIDE 0xFFFFFFu
 
 #endif

@@ -63,7 +63,7 @@ struct rsbwt {
     hipEvent_t ev_start[RING] = {}, ev_stop[RING] = {};
     uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
     bool counting = false;
-    unsigned long long *d_work = nullptr;  // 3 counters
+    unsigned long long *d_work = nullptr;  // 4 counters: LF steps, Occ lookups, block reads, k-table lookups
     std::recursive_mutex mu;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -125,7 +125,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         h->num_cus = prop.multiProcessorCount;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&h->d_work, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&h->d_work, 4 * sizeof(unsigned long long))) != hipSuccess) {
         rsbwt_close(h);
         return fail_hip(e, "creating stream/events");
     }
@@ -151,6 +151,33 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     h->view = br.view;
     h->num_runs = br.num_runs;
     h->hbm_bytes = br.hbm_bytes;
+    // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries stay within
+    // 1/16 of the index and whose T-mers still have ~1 expected occurrence (4^T <= n)
+    uint32_t T = (flags & RSBWT_KTAB_MASK) >> RSBWT_KTAB_SHIFT;
+    if (T == 31u || h->view.n == 0) T = 0;
+    else if (T == 0u) {
+        T = 1;
+        while (T < 15u && (8ull << (2u * (T + 1u))) <= h->hbm_bytes / 16 && (1ull << (2u * (T + 1u))) <= h->view.n) ++T;
+        if (T < 2u) T = 0;
+    } else if (T < 2u) T = 2;
+    if (T > 15u) T = 15;
+    if (T) {
+        uint64_t *d_tab = nullptr;
+        const uint64_t bytes = 8ull << (2u * T);
+        e = hipMalloc(&d_tab, bytes);
+        if (e == hipSuccess) {
+            e = build_ktable(h->view, T, d_tab, h->num_cus, h->stream);
+            if (e != hipSuccess) (void)hipFree(d_tab);
+        }
+        if (e != hipSuccess) {
+            rsbwt_close(h);
+            if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the k-mer table");
+            return fail_hip(e, "build_ktable");
+        }
+        h->view.ktab = d_tab;
+        h->view.ktab_depth = T;
+        h->hbm_bytes += bytes;
+    }
     *out = h;
     return RSBWT_OK;
 }
@@ -237,6 +264,7 @@ void rsbwt_close(rsbwt_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->view.blocks) (void)hipFree((void *)h->view.blocks);
     if (h->view.dir) (void)hipFree((void *)h->view.dir);
+    if (h->view.ktab) (void)hipFree((void *)h->view.ktab);
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     for (int i = 0; i < rsbwt::RING; ++i) {
@@ -262,6 +290,7 @@ uint64_t rsbwt_num_runs(const rsbwt_t *h) { return h->num_runs; }
 uint64_t rsbwt_num_strings(const rsbwt_t *h) { return h->num_strings; }
 uint64_t rsbwt_num_blocks(const rsbwt_t *h) { return h->view.nblocks; }
 uint32_t rsbwt_dir_shift(const rsbwt_t *h) { return h->view.dir_shift; }
+uint32_t rsbwt_ktab_depth(const rsbwt_t *h) { return h->view.ktab_depth; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
@@ -332,7 +361,7 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
         std::lock_guard<std::recursive_mutex> lock(h->mu);
         if (h->counting) {
             work = h->d_work;
-            HIP_OK(hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream));
+            HIP_OK(hipMemsetAsync(work, 0, 4 * sizeof(unsigned long long), stream));
         }
         const int slot = (int)(h->launches % rsbwt::RING);
         HIP_OK(hipEventRecord(h->ev_start[slot], stream));
@@ -452,11 +481,24 @@ int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups
     std::lock_guard<std::recursive_mutex> lock(h->mu);
     if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
     HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
-    unsigned long long w[3];
+    unsigned long long w[4];
     HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
     if (lf_steps) *lf_steps = w[0];
     if (occ_lookups) *occ_lookups = w[1];
     if (block_reads) *block_reads = w[2];
+    return RSBWT_OK;
+}
+
+int rsbwt_last_search_ktab_lookups(rsbwt_t *h, uint64_t *lookups) {
+    if (!h || !lookups) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
+    unsigned long long w[4];
+    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    *lookups = w[3];
     return RSBWT_OK;
 }
 

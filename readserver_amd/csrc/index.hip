@@ -259,6 +259,8 @@ hipError_t build_device_index(const void *d_runs, uint64_t num_runs, uint32_t di
         v.nwin = nwin;
         v.dir_shift = s;
         v.dir_fields = 32u / s;
+        v.ktab = nullptr;
+        v.ktab_depth = 0;
         // tot = {n, A, C, G, T}; '$' = n - (A+C+G+T).  C[] as rlebwt.cpp:129-147.
         v.total[0] = n - (tot[1] + tot[2] + tot[3] + tot[4]);
         for (int c = 1; c < 5; ++c) v.total[c] = tot[c];

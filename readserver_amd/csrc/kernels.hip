@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "bwt_device.h"
 #include "kernels.h"
 #include "synth_runs.h"
@@ -50,7 +52,7 @@ __global__ void pack_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_
 // ------------------------------------------------------------------------------------------
 // Batched backward search.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT_WORK, bool COUNTS_ONLY>
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB>
 __global__ void __launch_bounds__(256)
 search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
               const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
@@ -67,16 +69,17 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     int j = 0;           // index of the next symbol to prepend
     uint64_t word = 0;   // packed word holding symbol j
     uint64_t lo = 0, hi = 0;
-    unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0;
+    unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
 
     while (q < Q) {
+        bool done = false;
         if (fresh) {
             fresh = false;
             j = (int)k - 1;
+            const uint64_t *pq = packed + q * wpq;
             const uint8_t okb = valid[q];  // both loads issue together
-            word = packed[q * wpq + ((uint32_t)j >> 5)];
-            const bool ok = okb != 0;
-            if (!ok) {
+            word = pq[(uint32_t)j >> 5];
+            if (okb == 0) {
                 if ((lane & 7u) == 0u) {
                     if (COUNTS_ONLY) out_lower[q] = 0;
                     else { out_lower[q] = 1; out_upper[q] = 0; }
@@ -85,13 +88,36 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                 fresh = true;
                 continue;
             }
-            const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-            // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
-            lo = select_C(ix, b);
-            hi = lo + select_total(ix, b) - 1ull;
-            --j;
+            bool from_table = false;
+            if (KTAB) {
+                // the last T symbols of the k-mer select a precomputed interval
+                const uint32_t T = ix.ktab_depth;
+                const uint32_t off = 2u * (k - T);      // bit offset of symbol k-T in the packing
+                const uint32_t w0 = off >> 6, sh = off & 63u;
+                uint64_t bits = (w0 == ((uint32_t)j >> 5) ? word : pq[w0]) >> sh;
+                if (sh + 2u * T > 64u) bits |= word << (64u - sh);  // spills into the last word
+                const uint64_t code = bits & ((1ull << (2u * T)) - 1ull);
+                const uint64_t e = ix.ktab[code];
+                const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
+                if (COUNT_WORK) w_ktab += 1;
+                if (width != RSBWT_KTAB_WIDE) {
+                    from_table = true;
+                    lo = e & RSBWT_COUNT_MASK;
+                    hi = lo + width - 1ull;
+                    j = (int)(k - T) - 1;
+                    done = (width == 0u) || (j < 0);
+                    if (!done && ((uint32_t)j >> 5) != ((k - 1u) >> 5)) word = pq[(uint32_t)j >> 5];
+                }
+            }
+            if (!from_table) {
+                const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+                // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
+                lo = select_C(ix, b);
+                hi = lo + select_total(ix, b) - 1ull;
+                --j;
+                done = j < 0;
+            }
         }
-        bool done = j < 0;
         if (!done) {
             if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
@@ -109,12 +135,10 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             const uint64_t pb = select_C(ix, b);
             if (COUNT_WORK) {
                 const uint64_t oblk = dpp_mov64<DPP_ROW_HALF_MIRROR>(blk);
-                const uint32_t oskip = dpp_mov<DPP_ROW_HALF_MIRROR>(skip ? 1u : 0u);
                 if ((lane & 7u) == 0u) {  // role 0, so `skip` is the L side's
                     w_steps += 1;
                     w_occ += skip ? 1 : 2;
                     w_blocks += (skip || oblk == blk) ? 1 : 2;
-                    (void)oskip;
                 }
             }
             lo = pb + occL;
@@ -136,11 +160,34 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
         }
     }
     if (COUNT_WORK) {
-        if ((lane & 7u) == 0u && w_steps) {
+        if ((lane & 7u) == 0u && (w_steps || w_ktab)) {
             atomicAdd(&work[0], w_steps);
             atomicAdd(&work[1], w_occ);
             atomicAdd(&work[2], w_blocks);
+            atomicAdd(&work[3], w_ktab);
         }
+    }
+}
+
+// k-mer table build: codes -> packed queries, and (lower, upper) -> 8-byte entries
+__global__ void ktab_codes_kernel(uint64_t base, size_t m, uint64_t *__restrict__ packed,
+                                  uint8_t *__restrict__ valid) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        packed[i] = base + i;
+        valid[i] = 1;
+    }
+}
+
+__global__ void ktab_encode_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper,
+                                   size_t m, uint64_t *__restrict__ entries) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        const uint64_t lo = lower[i], up = upper[i];
+        uint64_t width = up + 1ull - lo;  // 0 when empty: an empty result always has upper = lower - 1
+        if (lo > up && up + 1ull != lo) width = RSBWT_KTAB_WIDE;  // never produced; stay safe
+        if (width >= RSBWT_KTAB_WIDE) width = RSBWT_KTAB_WIDE;
+        entries[i] = (lo & RSBWT_COUNT_MASK) | (width << RSBWT_COUNT_BITS);
     }
 }
 
@@ -327,6 +374,18 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
     return hipGetLastError();
 }
 
+template <bool CW, bool CO>
+static void launch_search_t(bool ktab, int grid, hipStream_t stream, const rsbwt_view &ix,
+                            const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq,
+                            uint64_t *lo, uint64_t *up, unsigned long long *work) {
+    if (ktab)
+        hipLaunchKernelGGL((search_kernel<CW, CO, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd, Q,
+                           k, wpq, lo, up, work);
+    else
+        hipLaunchKernelGGL((search_kernel<CW, CO, false>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
+                           Q, k, wpq, lo, up, work);
+}
+
 hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
                          uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream) {
@@ -337,22 +396,45 @@ hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void 
     const uint64_t *pk = (const uint64_t *)d_packed;
     const uint8_t *vd = (const uint8_t *)d_valid;
     uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
+    const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
     if (d_work) {
-        if (counts_only)
-            hipLaunchKernelGGL((search_kernel<true, true>), dim3(grid), dim3(256), 0, stream, ix, pk,
-                               vd, Q, k, wpq, lo, up, d_work);
-        else
-            hipLaunchKernelGGL((search_kernel<true, false>), dim3(grid), dim3(256), 0, stream, ix,
-                               pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_search_t<true, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_search_t<true, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
     } else {
-        if (counts_only)
-            hipLaunchKernelGGL((search_kernel<false, true>), dim3(grid), dim3(256), 0, stream, ix,
-                               pk, vd, Q, k, wpq, lo, up, d_work);
-        else
-            hipLaunchKernelGGL((search_kernel<false, false>), dim3(grid), dim3(256), 0, stream, ix,
-                               pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_search_t<false, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_search_t<false, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
     }
     return hipGetLastError();
+}
+
+// Fills ix.ktab-to-be `d_entries` (4^T entries) by searching every T-mer with the table-less
+// kernel, in slices that bound the temporary memory.  `ix` must not have a table yet.
+hipError_t build_ktable(const rsbwt_view &ix, uint32_t T, uint64_t *d_entries, int num_cus,
+                        hipStream_t stream) {
+    const uint64_t total = 1ull << (2u * T);
+    const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 22);
+    uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr;
+    uint8_t *d_ok = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc(&d_pk, SL * 8)) != hipSuccess) return e;
+    if ((e = hipMalloc(&d_lo, SL * 8)) != hipSuccess) { (void)hipFree(d_pk); return e; }
+    if ((e = hipMalloc(&d_up, SL * 8)) != hipSuccess) { (void)hipFree(d_pk); (void)hipFree(d_lo); return e; }
+    if ((e = hipMalloc(&d_ok, SL)) != hipSuccess) { (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); return e; }
+    rsbwt_view plain = ix;
+    plain.ktab = nullptr;
+    plain.ktab_depth = 0;
+    for (uint64_t base = 0; base < total && e == hipSuccess; base += SL) {
+        const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
+        const int g = (int)((m + 255) / 256);
+        hipLaunchKernelGGL(ktab_codes_kernel, dim3(g), dim3(256), 0, stream, base, m, d_pk, d_ok);
+        e = launch_search(plain, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(ktab_encode_kernel, dim3(g), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); (void)hipFree(d_ok);
+    return e;
 }
 
 hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,

@@ -217,7 +217,8 @@ def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     torch.cuda.synchronize()
     runs = d_runs.cpu().numpy()
     oix = oracle.from_runs(runs)
-    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None)  # every LF step is taken
+    assert g.ktab_depth() == 0
     Q, k = 50000, 31
     km = _random_kmers(rng, Q, k)
     d_km = torch.from_numpy(km).cuda()
@@ -274,6 +275,68 @@ def test_gpu_file_open_and_shard_set(rsb, oracle, tmp_path):
     ss.close()
     for g in shards:
         g.close()
+
+
+@pytest.mark.parametrize("T", [2, 3, 5, 8, 11])
+def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T):
+    """Searches that start from the k-mer table return exactly what the step-by-step search does
+    (early exits inside the tabulated suffix included), for k below, at and above T, and for
+    k-mers whose last T symbols straddle two packed words."""
+    import ctypes as C
+    L = rsb.lib()
+    runs = np.empty(400000, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, runs.size, 100 + T) == 0
+    oix = oracle.from_runs(runs)
+    rng = np.random.default_rng(T)
+    with rsb.GpuBWT(runs=runs, ktab_depth=T) as g, rsb.GpuBWT(runs=runs, ktab_depth=None) as plain:
+        assert g.ktab_depth() == T and plain.ktab_depth() == 0
+        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T
+        for k in sorted({1, T - 1, T, T + 1, 12, 31, 32, 33, 32 + T // 2, 64, 65, 97}):
+            if k < 1:
+                continue
+            km = _random_kmers(rng, 4000, k)
+            km[::9] = ord("A")  # poly-A: long matches
+            km[5, k // 2] = ord("N")
+            lo, up = rsb.find_intervals(g, km)
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo, elo) and np.array_equal(up, eup), (T, k)
+            plo, pup = rsb.find_intervals(plain, km)
+            assert np.array_equal(lo, plo) and np.array_equal(up, pup), (T, k)
+
+
+def test_gpu_kmer_table_auto_depth_and_counters(rsb, oracle):
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    R = 3000000
+    runs = np.empty(R, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 31) == 0
+    oix = oracle.from_runs(runs)
+    g = rsb.GpuBWT(runs=runs)
+    T = g.ktab_depth()
+    assert 2 <= T <= 15 and 8 * 4 ** T <= g.hbm_bytes() / 16 and 4 ** T <= g.getBWLen()
+    Q, k = 30000, 31
+    rng = np.random.default_rng(1)
+    km = _random_kmers(rng, Q, k)
+    d_km = torch.from_numpy(km).cuda()
+    d_pk = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_ok = torch.empty(Q, dtype=torch.uint8, device="cuda:0")
+    d_lo = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_up = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, None) == 0
+    assert L.rsbwt_set_counting(g.handle, 1) == 0
+    assert L.rsbwt_find_intervals_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), p(d_up), None) == 0
+    torch.cuda.synchronize()
+    st, oc, bl, kt = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert L.rsbwt_last_search_work(g.handle, C.byref(st), C.byref(oc), C.byref(bl)) == 0
+    assert L.rsbwt_last_search_ktab_lookups(g.handle, C.byref(kt)) == 0
+    elo, eup, steps = oix.find_intervals(km, nthreads=8, want_steps=True)
+    assert np.array_equal(d_lo.cpu().numpy().view(np.uint64), elo)
+    assert kt.value == Q
+    # the table replaces the first min(steps, T-1) LF steps of every query
+    assert st.value == int(np.maximum(steps.astype(np.int64) - (T - 1), 0).sum())
+    g.close()
 
 
 # ---- full-size properties (sizes the oracle cannot sweep exhaustively) --------------------------
