@@ -8,9 +8,11 @@
 //
 //   lane t (t = 0..3), bytes [32t, 32t+8)   header word t (u64, little endian)
 //        bits  0..39   # of symbol (t+1) in BWT[0, P0)        (A, C, G, T)
-//        bits 40..63   meta_t : t=0 P0 bits 0..23 | t=1 P0 bits 24..47
-//                               t=2 span (symbols in this block, 0..2976)
-//                               t=3 number of run bytes used (0..96)
+//        bits 40..63   meta_t : t=0  P0 bits 0..23
+//                               t=1  P0 bits 24..39 | run bytes used (0..96) << 16
+//                               t=2  span (symbols in this block, 0..2976) | start_1 << 12
+//                               t=3  start_2 | start_3 << 12
+//                      start_t = symbols of the block held by lanes 0..t-1 (start_0 = 0)
 //                 bytes [32t+8, 32t+32)     run bytes 24t .. 24t+23 of the block (unused = 0)
 //
 //   P0 = number of BWT symbols before the block.  #$ before the block = P0 - (A+C+G+T).

@@ -1,8 +1,8 @@
 // bwt_device.h -- gfx950 device primitives over the block/directory layout (block_format.h).
 //
 // One Occ lookup is served by a DPP quad: 4 adjacent lanes read one 128-B block as 4 x 32 B
-// (two global_load_dwordx4 each) and rank it with quad_perm moves only -- no LDS, no barriers.
-// A 64-lane wavefront therefore resolves 16 Occ lookups per pass.
+// (two global_load_dwordx4 each) and rank it with quad_perm moves only -- no LDS traffic for the
+// data, no barriers.  A 64-lane wavefront therefore resolves 16 Occ lookups per pass.
 #ifndef RSBWT_BWT_DEVICE_H
 #define RSBWT_BWT_DEVICE_H
 
@@ -15,9 +15,16 @@ namespace rsb {
 
 // ---- DPP moves inside a row of 16 lanes (all lanes of a quad / octet are always active
 // ---- together in the kernels below, so every source lane is valid).
+//
+// The result is made opaque (empty asm) so that hipcc's DPP combiner cannot fold the move into
+// the consuming VALU op: ROCm 7.2 folds `x - dpp(y)` into `v_subrev_u32_dpp`, and on gfx950 that
+// instruction permutes the OTHER operand (it computes dpp(x) - y with x, y swapped: measured with
+// tools/dpp_subrev_test.hip), which silently broke the hop loop below.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    asm("" : "+v"(r));
+    return r;
 }
 // quad_perm encodings: sel0 | sel1<<2 | sel2<<4 | sel3<<6
 constexpr int DPP_QUAD_BCAST0 = 0x00;
@@ -42,22 +49,36 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
 }
 
 // ---- directory: symbol position -> block (block_format.h, DIRECTORY)
-__device__ __forceinline__ uint64_t dir_lookup(const rsbwt_view &ix, uint64_t p) {
-    const uint32_t s = ix.dir_shift;
-    const uint32_t mask = (1u << s) - 1u;
-    const uint2 e = ix.dir[p >> s];
-    const uint32_t pin = (uint32_t)p & mask;
+// EXACT8: s == 8, four 8-bit fields, always exact.
+template <bool EXACT8>
+__device__ __forceinline__ uint32_t dir_decode(const rsbwt_view &ix, uint2 e, uint64_t p) {
     uint32_t j = e.x;
-    uint32_t f = e.y;
+    if (EXACT8) {
+        const uint32_t pin = (uint32_t)p & 255u;
+        // field k counts when 1 <= f_k <= pin, i.e. (f_k - 1) < pin as unsigned
+        j += (__builtin_amdgcn_ubfe(e.y, 0, 8) - 1u < pin) ? 1u : 0u;
+        j += (__builtin_amdgcn_ubfe(e.y, 8, 8) - 1u < pin) ? 1u : 0u;
+        j += (__builtin_amdgcn_ubfe(e.y, 16, 8) - 1u < pin) ? 1u : 0u;
+        j += ((e.y >> 24) - 1u < pin) ? 1u : 0u;
+    } else {
+        const uint32_t s = ix.dir_shift;
+        const uint32_t mask = (1u << s) - 1u;
+        const uint32_t pin = (uint32_t)p & mask;
+        uint32_t f = e.y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < (int)ix.dir_fields) {
-            const uint32_t fk = f & mask;
-            j += (fk != 0u && pin >= fk) ? 1u : 0u;
-            f >>= s;
+        for (int k = 0; k < 4; ++k) {
+            if (k < (int)ix.dir_fields) {
+                j += ((f & mask) - 1u < pin) ? 1u : 0u;
+                f >>= s;
+            }
         }
     }
     return j;
+}
+
+template <bool EXACT8>
+__device__ __forceinline__ const uint2 *dir_entry_ptr(const rsbwt_view &ix, uint64_t p) {
+    return ix.dir + (EXACT8 ? (p >> 8) : (p >> ix.dir_shift));
 }
 
 // One quad lane's 32 bytes of a block.
@@ -66,13 +87,13 @@ struct lane_block {
     uint32_t r[6];            // run bytes 24t .. 24t+23
 };
 
-__device__ __forceinline__ lane_block load_lane_block(const rsbwt_view &ix, uint64_t blk,
-                                                      uint32_t t) {
-    const uint4 *bp = ix.blocks + blk * 8u + t * 2u;
+// lane_base = ix.blocks + 2 * t (the lane's 32-byte slice of block 0)
+__device__ __forceinline__ lane_block load_lane_block(const uint4 *lane_base, uint64_t blk) {
+    const uint4 *bp = lane_base + blk * 8u;
     uint4 a = bp[0];
     uint4 c = bp[1];
     // Pin both 16-B loads here: left alone, hipcc fetches only the meta dword first (for the hop
-    // test below) and the rest after it -- two dependent HBM round trips instead of one.
+    // test) and the rest after it -- two dependent HBM round trips instead of one.
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
     lane_block lb;
     lb.hdr_lo = a.x;
@@ -86,71 +107,86 @@ __device__ __forceinline__ lane_block load_lane_block(const rsbwt_view &ix, uint
     return lb;
 }
 
+// What the quad needs from the four meta fields (block_format.h).
 struct block_meta {
-    uint64_t P0;    // symbols before the block
-    uint32_t span;  // symbols in the block
+    uint32_t P0_lo24;  // P0 bits 0..23
+    uint32_t span;     // symbols in the block
+    uint32_t start;    // symbols of the block held by the lanes below this one
 };
 
-__device__ __forceinline__ block_meta quad_block_meta(const lane_block &lb) {
+__device__ __forceinline__ block_meta quad_block_meta(const lane_block &lb, uint32_t t) {
     const uint32_t meta = lb.hdr_hi >> 8;
-    const uint32_t m0 = dpp_mov<DPP_QUAD_BCAST0>(meta);
-    const uint32_t m1 = dpp_mov<DPP_QUAD_BCAST1>(meta);
     block_meta bm;
-    bm.span = dpp_mov<DPP_QUAD_BCAST2>(meta);
-    bm.P0 = (uint64_t)m0 | ((uint64_t)m1 << 24);
+    bm.P0_lo24 = dpp_mov<DPP_QUAD_BCAST0>(meta);
+    const uint32_t m2 = dpp_mov<DPP_QUAD_BCAST2>(meta);
+    const uint32_t m3 = dpp_mov<DPP_QUAD_BCAST3>(meta);
+    bm.span = m2 & 0xFFFu;
+    const uint32_t s12 = (t & 1u) ? (m2 >> 12) : (m3 & 0xFFFu);  // t=1: start_1, t=2: start_2
+    bm.start = (t == 0u) ? 0u : (t == 3u) ? (m3 >> 12) : s12;
     return bm;
 }
 
-// Symbols held by this lane's 24 run bytes, and the symbols held by the quad's lower lanes.
-__device__ __forceinline__ uint32_t lane_symbols(const lane_block &lb) {
-    uint32_t tot = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) tot = __builtin_amdgcn_sad_u8(lb.r[i] & 0x1F1F1F1Fu, 0u, tot);
-    return tot;
+// Offset of position p inside the block (0-based), from 24-bit modular arithmetic: the block the
+// directory names starts at most a few blocks (<< 2^24 symbols) before p.
+__device__ __forceinline__ uint32_t offset_in_block(const block_meta &bm, uint64_t p) {
+    return ((uint32_t)p - bm.P0_lo24) & 0xFFFFFFu;
 }
 
-__device__ __forceinline__ uint32_t quad_exclusive_start(uint32_t tot, uint32_t t) {
-    const uint32_t t0 = dpp_mov<DPP_QUAD_BCAST0>(tot);
-    const uint32_t t1 = dpp_mov<DPP_QUAD_BCAST1>(tot);
-    const uint32_t t2 = dpp_mov<DPP_QUAD_BCAST2>(tot);
-    return (t > 0u ? t0 : 0u) + (t > 1u ? t1 : 0u) + (t > 2u ? t2 : 0u);
-}
-
-// Occ(b, p) for the block that holds position p: # of symbol b (rank 1..4) in BWT[0..p].
-// Follows RLEBWT::getOcc's bucket scan (src/bwt/rlebwt.cpp:281-298) with the marker replaced by
-// the block header; the 96 runs are scanned 24 per lane and summed across the quad.
-__device__ __forceinline__ uint64_t quad_rank(const lane_block &lb, const block_meta &bm,
-                                              uint32_t t, uint32_t b, uint64_t p) {
-    const uint32_t o = (uint32_t)(p - bm.P0) + 1u;  // symbols of this block to count
-    const uint32_t tot = lane_symbols(lb);
-    int rem = (int)o - (int)quad_exclusive_start(tot, t);
+// Sum over this lane's 24 runs of min(len, what is left of `rem` symbols), counting only runs of
+// symbol b.  RLEBWT::getOcc's bucket scan (src/bwt/rlebwt.cpp:281-298), 5 VALU per run byte:
+// SDWA operands pick the byte out of the pre-masked dwords.
+__device__ __forceinline__ uint32_t lane_scan(const lane_block &lb, uint32_t b, uint32_t rem) {
+    const uint32_t b5 = b << 5;
     uint32_t acc = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const uint32_t x = lb.r[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int len = (int)__builtin_amdgcn_ubfe(x, 8 * k, 5);
-            const uint32_t sym = __builtin_amdgcn_ubfe(x, 8 * k + 5, 3);
-            const int take = min(max(rem, 0), len);  // v_med3_i32
-            acc += (sym == b) ? (uint32_t)take : 0u;
-            rem -= len;
-        }
+        const uint32_t l = lb.r[i] & 0x1F1F1F1Fu;   // lengths
+        const uint32_t sy = lb.r[i] & 0xE0E0E0E0u;  // symbols << 5
+        uint32_t t0, t1;
+        asm("v_cmp_eq_u32_sdwa vcc, %[sy], %[b5] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+            "v_min_u32_sdwa %[t0], %[rem], %[l] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+            "v_sub_u32 %[rem], %[rem], %[t0]\n\t"
+            "v_cndmask_b32 %[t0], 0, %[t0], vcc\n\t"
+            "v_cmp_eq_u32_sdwa vcc, %[sy], %[b5] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+            "v_min_u32_sdwa %[t1], %[rem], %[l] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+            "v_sub_u32 %[rem], %[rem], %[t1]\n\t"
+            "v_cndmask_b32 %[t1], 0, %[t1], vcc\n\t"
+            "v_add3_u32 %[acc], %[acc], %[t0], %[t1]\n\t"
+            "v_cmp_eq_u32_sdwa vcc, %[sy], %[b5] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+            "v_min_u32_sdwa %[t0], %[rem], %[l] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+            "v_sub_u32 %[rem], %[rem], %[t0]\n\t"
+            "v_cndmask_b32 %[t0], 0, %[t0], vcc\n\t"
+            "v_cmp_eq_u32_sdwa vcc, %[sy], %[b5] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+            "v_min_u32_sdwa %[t1], %[rem], %[l] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+            "v_sub_u32 %[rem], %[rem], %[t1]\n\t"
+            "v_cndmask_b32 %[t1], 0, %[t1], vcc\n\t"
+            "v_add3_u32 %[acc], %[acc], %[t0], %[t1]"
+            : [acc] "+v"(acc), [rem] "+v"(rem), [t0] "=&v"(t0), [t1] "=&v"(t1)
+            : [l] "v"(l), [sy] "v"(sy), [b5] "v"(b5)
+            : "vcc");
     }
+    return acc;
+}
+
+// Occ(b, p) for the block that holds position p: # of symbol b (rank 1..4) in BWT[0..p].
+// The 96 runs are scanned 24 per lane and summed across the quad together with the header count.
+__device__ __forceinline__ uint64_t quad_rank(const lane_block &lb, const block_meta &bm,
+                                              uint32_t t, uint32_t b, uint32_t off) {
+    const uint32_t o = off + 1u;  // symbols of this block to count
+    const uint32_t rem = o > bm.start ? o - bm.start : 0u;
+    const uint32_t acc = lane_scan(lb, b, rem);
     const uint64_t cnt = ((uint64_t)(lb.hdr_hi & 0xFFu) << 32) | lb.hdr_lo;
     uint64_t mine = (t + 1u == b) ? cnt : 0ull;
     mine += acc;
     return quad_sum64(mine);
 }
 
-// Rank (0..4) of the symbol at position p of the block that holds it
+// Rank (0..4) of the symbol at offset `off` of the block
 // (RLEBWT::getChar's bucket scan, src/bwt/rlebwt.cpp:213-224).
 __device__ __forceinline__ uint32_t quad_char(const lane_block &lb, const block_meta &bm,
-                                              uint32_t t, uint64_t p) {
-    const uint32_t o = (uint32_t)(p - bm.P0) + 1u;
-    const uint32_t tot = lane_symbols(lb);
-    int rem = (int)o - (int)quad_exclusive_start(tot, t);
-    uint32_t found = 0;  // sym + 1 of the run holding offset o, if it is in this lane
+                                              uint32_t t, uint32_t off) {
+    int rem = (int)(off + 1u) - (int)bm.start;
+    uint32_t found = 0;  // sym + 1 of the run holding the offset, if it is in this lane
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const uint32_t x = lb.r[i];
@@ -167,39 +203,33 @@ __device__ __forceinline__ uint32_t quad_char(const lane_block &lb, const block_
     return found - 1u;
 }
 
-// Fetch the block holding position p (directory estimate, then forward hops in the rare
-// windows that hold more block starts than the entry has fields).
-__device__ __forceinline__ uint64_t quad_fetch(const rsbwt_view &ix, uint64_t p, uint32_t t,
-                                               lane_block &lb, block_meta &bm) {
-    uint64_t blk = dir_lookup(ix, p);
-    lb = load_lane_block(ix, blk, t);
-    bm = quad_block_meta(lb);
-    if (__builtin_expect(p >= bm.P0 + bm.span, 0)) {
-        while (p >= bm.P0 + bm.span && blk + 1 < ix.nblocks) {
-            ++blk;
-            lb = load_lane_block(ix, blk, t);
-            bm = quad_block_meta(lb);
+// Fetch the block holding position p: directory entry, then the block it names; when the entry
+// is not exact (windows with more block starts than fields) advance while p is beyond the block.
+// Returns the block id; `off` receives p's offset inside it.
+template <bool EXACT8>
+__device__ __forceinline__ uint64_t quad_fetch(const rsbwt_view &ix, const uint4 *lane_base,
+                                               uint64_t p, uint32_t t, lane_block &lb,
+                                               block_meta &bm, uint32_t &off) {
+    const uint2 e = *dir_entry_ptr<EXACT8>(ix, p);
+    uint64_t blk = dir_decode<EXACT8>(ix, e, p);
+    lb = load_lane_block(lane_base, blk);
+    bm = quad_block_meta(lb, t);
+    off = offset_in_block(bm, p);
+    if (!EXACT8) {
+        // Rare: the window holds more block starts than the entry has fields, so the entry named
+        // an earlier block.  Every p < n lies in some block at or after it, so advancing while p
+        // is beyond the block ends.  The loop is wave-uniform (ballot) with a predicated body: all
+        // lanes of every quad stay active for the DPP moves whatever their neighbours need.
+        bool need = off >= bm.span;
+        while (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+            blk += need ? 1u : 0u;
+            lb = load_lane_block(lane_base, blk);
+            bm = quad_block_meta(lb, t);
+            off = offset_in_block(bm, p);
+            need = off >= bm.span && blk + 1 < ix.nblocks;
         }
     }
     return blk;
-}
-
-__device__ __forceinline__ uint64_t select_C(const rsbwt_view &ix, uint32_t b) {
-    uint64_t c = ix.C[1];
-    c = (b == 2u) ? ix.C[2] : c;
-    c = (b == 3u) ? ix.C[3] : c;
-    c = (b == 4u) ? ix.C[4] : c;
-    c = (b == 0u) ? ix.C[0] : c;
-    return c;
-}
-
-__device__ __forceinline__ uint64_t select_total(const rsbwt_view &ix, uint32_t b) {
-    uint64_t c = ix.total[1];
-    c = (b == 2u) ? ix.total[2] : c;
-    c = (b == 3u) ? ix.total[3] : c;
-    c = (b == 4u) ? ix.total[4] : c;
-    c = (b == 0u) ? ix.total[0] : c;
-    return c;
 }
 
 }  // namespace rsb

@@ -156,8 +156,17 @@ write_blocks_kernel(const uint8_t *__restrict__ runs, uint64_t R, uint64_t nbloc
     const uint64_t P0 = before[0];
     uint64_t used = R - j * RSBWT_BLOCK_RUNS;
     if (used > RSBWT_BLOCK_RUNS) used = RSBWT_BLOCK_RUNS;
-    const uint32_t meta[4] = {(uint32_t)(P0 & 0xFFFFFFu), (uint32_t)((P0 >> 24) & 0xFFFFFFu), t.v[0],
-                              (uint32_t)used};
+    uint32_t start[4] = {0, 0, 0, 0};  // symbols held by the lanes below lane q
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sum = __builtin_amdgcn_sad_u8(w[6 * (q - 1) + i] & 0x1F1F1F1Fu, 0u, sum);
+        start[q] = start[q - 1] + sum;
+    }
+    const uint32_t meta[4] = {(uint32_t)(P0 & 0xFFFFFFu),
+                              (uint32_t)((P0 >> 24) & 0xFFFFu) | ((uint32_t)used << 16),
+                              t.v[0] | (start[1] << 12), start[2] | (start[3] << 12)};
     uint4 *dst = blocks + j * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -52,7 +52,7 @@ __global__ void pack_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_
 // ------------------------------------------------------------------------------------------
 // Batched backward search.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB>
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool EXACT8>
 __global__ void __launch_bounds__(256)
 search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
               const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
@@ -63,6 +63,16 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     const uint32_t role = (lane >> 2) & 1u;  // 0: lower-1 side, 1: upper side
     const size_t octet = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const size_t noctets = ((size_t)gridDim.x * blockDim.x) >> 3;
+    const uint4 *lane_base = ix.blocks + 2u * t;
+
+    // C[] and the symbol totals, indexed by symbol rank, in LDS: a dynamically indexed kernel
+    // argument would otherwise become a dependent global load at the end of every step.
+    __shared__ uint64_t s_C[8], s_total[8];
+    if (threadIdx.x < 5) {
+        s_C[threadIdx.x] = ix.C[threadIdx.x];
+        s_total[threadIdx.x] = ix.total[threadIdx.x];
+    }
+    __syncthreads();
 
     size_t q = octet;
     bool fresh = true;   // the next iteration starts query q
@@ -112,8 +122,8 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             if (!from_table) {
                 const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
                 // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
-                lo = select_C(ix, b);
-                hi = lo + select_total(ix, b) - 1ull;
+                lo = s_C[b];
+                hi = lo + s_total[b] - 1ull;
                 --j;
                 done = j < 0;
             }
@@ -122,17 +132,18 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
             // updateInterval (query.cpp:11-15)
+            const uint64_t pb = s_C[b];
             const bool skip = (role == 0u) && (lo == 0ull);  // Occ(b, -1) = 0
             const uint64_t p = role ? hi : (skip ? 0ull : lo - 1ull);
             lane_block lb;
             block_meta bm;
-            const uint64_t blk = quad_fetch(ix, p, t, lb, bm);
-            uint64_t occ = quad_rank(lb, bm, t, b, p);
+            uint32_t off;
+            const uint64_t blk = quad_fetch<EXACT8>(ix, lane_base, p, t, lb, bm, off);
+            uint64_t occ = quad_rank(lb, bm, t, b, off);
             occ = skip ? 0ull : occ;
             const uint64_t other = dpp_mov64<DPP_ROW_HALF_MIRROR>(occ);
             const uint64_t occL = role ? other : occ;
             const uint64_t occU = role ? occ : other;
-            const uint64_t pb = select_C(ix, b);
             if (COUNT_WORK) {
                 const uint64_t oblk = dpp_mov64<DPP_ROW_HALF_MIRROR>(blk);
                 if ((lane & 7u) == 0u) {  // role 0, so `skip` is the L side's
@@ -203,11 +214,12 @@ __device__ __forceinline__ uint64_t quad_occ_any(const rsbwt_view &ix, uint32_t 
                                                  uint32_t t) {
     lane_block lb;
     block_meta bm;
-    quad_fetch(ix, p, t, lb, bm);
-    uint64_t r = quad_rank(lb, bm, t, b, p);  // for b == 0: just the in-block '$' symbols
+    uint32_t off;
+    quad_fetch<false>(ix, ix.blocks + 2u * t, p, t, lb, bm, off);
+    uint64_t r = quad_rank(lb, bm, t, b, off);  // for b == 0: just the in-block '$' symbols
     if (b == 0u) {
         const uint64_t cnt = ((uint64_t)(lb.hdr_hi & 0xFFu) << 32) | lb.hdr_lo;
-        r += bm.P0 - quad_sum64(cnt);
+        r += (p - off) - quad_sum64(cnt);  // P0 = p - off
     }
     return r;
 }
@@ -240,8 +252,9 @@ __global__ void char_batch_kernel(const rsbwt_view ix, const uint64_t *__restric
         if (p >= ix.n) p = ix.n - 1;
         lane_block lb;
         block_meta bm;
-        quad_fetch(ix, p, t, lb, bm);
-        const uint32_t c = quad_char(lb, bm, t, p);
+        uint32_t off;
+        quad_fetch<false>(ix, ix.blocks + 2u * t, p, t, lb, bm, off);
+        const uint32_t c = quad_char(lb, bm, t, off);
         if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
     }
 }
@@ -251,7 +264,7 @@ __device__ __forceinline__ uint64_t block_count_before(const rsbwt_view &ix, uin
     const uint64_t *w = (const uint64_t *)ix.blocks;  // header word t at u64 index 16*j + 4*t
     if (b != 0u) return w[16 * j + 4 * (b - 1u)] & RSBWT_COUNT_MASK;
     const uint64_t w0 = w[16 * j], w1 = w[16 * j + 4], w2 = w[16 * j + 8], w3 = w[16 * j + 12];
-    const uint64_t P0 = (w0 >> 40) | ((w1 >> 40) << 24);
+    const uint64_t P0 = (w0 >> 40) | (((w1 >> 40) & 0xFFFFull) << 24);
     return P0 - ((w0 & RSBWT_COUNT_MASK) + (w1 & RSBWT_COUNT_MASK) + (w2 & RSBWT_COUNT_MASK) +
                  (w3 & RSBWT_COUNT_MASK));
 }
@@ -268,7 +281,7 @@ __device__ uint64_t thread_occ_at(const rsbwt_view &ix, uint32_t b, uint64_t bc)
     }
     const uint64_t j = lo;
     const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
-    const uint64_t P0 = (w[0] >> 40) | ((w[4] >> 40) << 24);
+    const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
     uint64_t offset = bc - block_count_before(ix, j, b);
     uint64_t index = P0;
     const uint8_t *bytes = (const uint8_t *)w;
@@ -291,7 +304,7 @@ __global__ void occ_at_batch_kernel(const rsbwt_view ix, const uint8_t *__restri
     for (size_t i = gid; i < n; i += nthreads) {
         const uint32_t b = ascii_rank(syms[i]);
         uint64_t c = bc[i];
-        const uint64_t tot = select_total(ix, b);
+        const uint64_t tot = ix.total[b];
         uint64_t r = ix.n;  // out of range -> n
         if (c >= 1 && c <= tot) r = thread_occ_at(ix, b, c);
         out[i] = r;
@@ -342,10 +355,11 @@ __global__ void sample_present_kernel(const rsbwt_view ix, size_t Q, uint32_t k,
             for (int i = (int)k - 2; i >= 0; --i) {
                 lane_block lb;
                 block_meta bm;
-                quad_fetch(ix, r, t, lb, bm);
-                const uint32_t c = quad_char(lb, bm, t, r);
+                uint32_t off;
+                quad_fetch<false>(ix, ix.blocks + 2u * t, r, t, lb, bm, off);
+                const uint32_t c = quad_char(lb, bm, t, off);
                 if (c == 0u) { ok = false; break; }
-                r = select_C(ix, c) + quad_rank(lb, bm, t, c, r) - 1ull;  // LF(r)
+                r = ix.C[c] + quad_rank(lb, bm, t, c, off) - 1ull;  // LF(r)
                 if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
             }
         }
@@ -374,16 +388,25 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
     return hipGetLastError();
 }
 
+template <bool CW, bool CO, bool KT>
+static void launch_search_e(bool exact8, int grid, hipStream_t stream, const rsbwt_view &ix,
+                            const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq,
+                            uint64_t *lo, uint64_t *up, unsigned long long *work) {
+    if (exact8)
+        hipLaunchKernelGGL((search_kernel<CW, CO, KT, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
+                           Q, k, wpq, lo, up, work);
+    else
+        hipLaunchKernelGGL((search_kernel<CW, CO, KT, false>), dim3(grid), dim3(256), 0, stream, ix, pk,
+                           vd, Q, k, wpq, lo, up, work);
+}
+
 template <bool CW, bool CO>
 static void launch_search_t(bool ktab, int grid, hipStream_t stream, const rsbwt_view &ix,
                             const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq,
                             uint64_t *lo, uint64_t *up, unsigned long long *work) {
-    if (ktab)
-        hipLaunchKernelGGL((search_kernel<CW, CO, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd, Q,
-                           k, wpq, lo, up, work);
-    else
-        hipLaunchKernelGGL((search_kernel<CW, CO, false>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
-                           Q, k, wpq, lo, up, work);
+    const bool exact8 = ix.dir_shift == 8;
+    if (ktab) launch_search_e<CW, CO, true>(exact8, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
+    else launch_search_e<CW, CO, false>(exact8, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
 }
 
 hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
