@@ -15,6 +15,10 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
 hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
                          uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream);
+// search_wave.hip: the wave-cooperative form of the same search (needs dir_shift == 8)
+hipError_t launch_search_wave(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
+                              uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                              unsigned long long *d_work, int num_cus, hipStream_t stream);
 hipError_t build_ktable(const rsbwt_view &ix, uint32_t T, uint64_t *d_entries, int num_cus,
                         hipStream_t stream);
 hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "bwt_device.h"
@@ -409,10 +411,21 @@ static void launch_search_t(bool ktab, int grid, hipStream_t stream, const rsbwt
     else launch_search_e<CW, CO, false>(exact8, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
 }
 
+// RSBWT_SEARCH_KERNEL=octet|wave picks the kernel form (default: wave where the index allows it)
+static bool prefer_wave_kernel() {
+    static const int v = [] {
+        const char *e = getenv("RSBWT_SEARCH_KERNEL");
+        return (e && e[0] == 'o') ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
                          uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
+    if (ix.dir_shift == 8 && prefer_wave_kernel())
+        return launch_search_wave(ix, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, d_work, num_cus, stream);
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.
     const int grid = grid_for(32, Q, num_cus * 8);

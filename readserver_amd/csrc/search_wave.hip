@@ -1,0 +1,255 @@
+// search_wave.hip -- batched findInterval, wave-cooperative form (gfx950).
+//
+// Same algorithm and layout as kernels.hip's octet kernel (findInterval, src/bwt/query.cpp:24-41;
+// one directory entry + one 128-B block per Occ lookup), different work split.  The octet kernel
+// spends ~20 VALU instructions per lookup, most of them per-quad overhead replicated 16 times per
+// wave, and is VALU-issue bound.  Here
+//   * a wavefront carries 32 queries: lane i resolves Occ(b, lower-1) of query i, lane i+32
+//     Occ(b, upper); each lane does its own directory lookup;
+//   * blocks are still fetched the way the memory system likes them (tools/gather_bench.hip): in
+//     four rounds, DPP-quad q of the wave reads the 128-B block wanted by lane 16r+q as
+//     4 x 32 B, and parks it in LDS (144-B slots: conflict-free for 16-B reads at one offset);
+//   * every lane then ranks ITS block out of LDS: the header names the quarter (24 runs) holding
+//     the position, the quarters before it are summed 4 bytes at a time (v_dot4_u32_u8 against a
+//     0/1 match mask), and only the one quarter is scanned run by run (SDWA, 5 VALU per run).
+// Overhead is shared by 64 lookups instead of 16 and the scan is 24 bytes instead of 96 per lookup.
+// Requires the exact (s = 8) directory; other indexes use the octet kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bwt_device.h"
+#include "kernels.h"
+
+namespace rsb {
+
+constexpr int SLOT_U4 = 9;  // 144-byte LDS slot per lane = 9 uint4
+
+// matched symbols in one dword of 4 runs: sum of len over the bytes whose symbol == b
+__device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint32_t acc) {
+    const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;          // 0 where the symbol matches
+    const uint32_t m01 = ((0x80808080u - z) >> 7) & 0x01010101u;  // 1 where it matches
+    return __builtin_amdgcn_udot4(x & 0x1F1F1F1Fu, m01, acc, false);
+}
+
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB>
+__global__ void __launch_bounds__(256)
+search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
+                   const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
+                   uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
+                   unsigned long long *__restrict__ work) {
+    __shared__ uint4 s_stage[4][64 * SLOT_U4];
+    __shared__ uint64_t s_C[8], s_total[8];
+    if (threadIdx.x < 5) {
+        s_C[threadIdx.x] = ix.C[threadIdx.x];
+        s_total[threadIdx.x] = ix.total[threadIdx.x];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t side = lane >> 5;  // 0: lower-1 side, 1: upper side
+    const uint32_t t = lane & 3u;     // which 32 B of a block this lane fetches
+    const uint32_t quad = lane >> 2;
+    uint4 *stage = s_stage[wave];
+    const uint4 *lane_base = ix.blocks + 2u * t;
+    const size_t nslots = (size_t)gridDim.x * 128u;
+
+    size_t q = ((size_t)blockIdx.x * 4u + wave) * 32u + (lane & 31u);
+    bool fresh = true;
+    int j = 0;
+    uint64_t word = 0, lo = 0, hi = 0;
+    unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
+
+    while (__builtin_amdgcn_ballot_w64(q < Q) != 0ull) {
+        const bool alive = q < Q;
+        bool done = false;
+        if (alive && fresh) {
+            fresh = false;
+            j = (int)k - 1;
+            const uint64_t *pq = packed + q * wpq;
+            const uint8_t okb = valid[q];
+            word = pq[(uint32_t)j >> 5];
+            if (okb == 0) {
+                lo = 1;
+                hi = 0;
+                done = true;
+            } else {
+                bool from_table = false;
+                if (KTAB) {
+                    const uint32_t T = ix.ktab_depth;
+                    const uint32_t off = 2u * (k - T);
+                    const uint32_t w0 = off >> 6, sh = off & 63u;
+                    uint64_t bits = (w0 == ((uint32_t)j >> 5) ? word : pq[w0]) >> sh;
+                    if (sh + 2u * T > 64u) bits |= word << (64u - sh);
+                    const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
+                    const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
+                    if (COUNT_WORK) w_ktab += 1;
+                    if (width != RSBWT_KTAB_WIDE) {
+                        from_table = true;
+                        lo = e & RSBWT_COUNT_MASK;
+                        hi = lo + width - 1ull;
+                        j = (int)(k - T) - 1;
+                        done = (width == 0u) || (j < 0);
+                        if (!done && ((uint32_t)j >> 5) != ((k - 1u) >> 5)) word = pq[(uint32_t)j >> 5];
+                    }
+                }
+                if (!from_table) {
+                    const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+                    lo = s_C[b];                    // initInterval, query.cpp:18-21
+                    hi = lo + s_total[b] - 1ull;
+                    --j;
+                    done = j < 0;
+                }
+            }
+        }
+        const bool stepping = alive && !done;
+
+        // ---- this lane's lookup: symbol, position, directory entry -> block id
+        uint32_t b = 1, blk = 0;
+        uint64_t p = 0, pb = 0;
+        bool skip = false;
+        if (stepping) {
+            if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+            b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+            pb = s_C[b];
+            skip = (side == 0u) && (lo == 0ull);  // Occ(b, -1) = 0
+            p = side ? hi : (skip ? 0ull : lo - 1ull);
+            const uint2 e = ix.dir[p >> 8];
+            blk = dir_decode<true>(ix, e, p);
+        }
+
+        // ---- cooperative fetch: quad `quad` reads the block of lane 16r + quad, round r
+        uint4 a[4], c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)blk);
+            const uint4 *bp = lane_base + (uint64_t)tb * 8u;
+            a[r] = bp[0];
+            c[r] = bp[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(a[r].z), "+v"(a[r].w), "+v"(c[r].x), "+v"(c[r].y), "+v"(c[r].z), "+v"(c[r].w));
+            uint4 *dst = stage + (16u * r + quad) * SLOT_U4 + 2u * t;
+            dst[0] = a[r];
+            dst[1] = c[r];
+        }
+        // LDS operations of one wave execute in order: the reads below see the writes above.
+
+        uint64_t occ = 0;
+        if (stepping) {
+            const uint32_t *mine = reinterpret_cast<const uint32_t *>(stage + lane * SLOT_U4);
+            // header: meta of words 0, 2, 3 and the count word of symbol b (block_format.h)
+            const uint32_t P0lo = mine[1] >> 8;
+            const uint32_t m2 = mine[17] >> 8, m3 = mine[25] >> 8;
+            const uint2 cw = *reinterpret_cast<const uint2 *>(mine + 8u * (b - 1u));
+            const uint32_t off = ((uint32_t)p - P0lo) & 0xFFFFFFu;  // exact directory: inside the block
+            const uint32_t o = off + 1u;
+            const uint32_t s1 = m2 >> 12, s2 = m3 & 0xFFFu, s3 = m3 >> 12;
+            const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
+            const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+            const uint32_t bb = b * 0x01010101u;
+            // quarters before the one holding the position: matched lengths, 4 runs per dot4
+            uint32_t before = 0;
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt) {
+                const uint2 x0 = *reinterpret_cast<const uint2 *>(mine + 8 * qt + 2);
+                const uint4 x1 = *reinterpret_cast<const uint4 *>(mine + 8 * qt + 4);
+                uint32_t m = dword_matched(x0.x, bb, 0u);
+                m = dword_matched(x0.y, bb, m);
+                m = dword_matched(x1.x, bb, m);
+                m = dword_matched(x1.y, bb, m);
+                m = dword_matched(x1.z, bb, m);
+                m = dword_matched(x1.w, bb, m);
+                before += (cq > (uint32_t)qt) ? m : 0u;
+            }
+            // the quarter holding it: run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
+            lane_block lb;
+            {
+                const uint2 x0 = *reinterpret_cast<const uint2 *>(mine + 8u * cq + 2u);
+                const uint4 x1 = *reinterpret_cast<const uint4 *>(mine + 8u * cq + 4u);
+                lb.r[0] = x0.x; lb.r[1] = x0.y; lb.r[2] = x1.x; lb.r[3] = x1.y; lb.r[4] = x1.z; lb.r[5] = x1.w;
+                lb.hdr_lo = 0; lb.hdr_hi = 0;
+            }
+            const uint32_t inq = lane_scan(lb, b, o - start);
+            const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
+            occ = skip ? 0ull : cnt + before + inq;
+        }
+
+        // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
+        const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ, (uint32_t)occ, false, false);
+        const auto sw_hi = __builtin_amdgcn_permlane32_swap((uint32_t)(occ >> 32), (uint32_t)(occ >> 32), false, false);
+        const uint64_t other = side ? (((uint64_t)sw_hi[0] << 32) | sw_lo[0]) : (((uint64_t)sw_hi[1] << 32) | sw_lo[1]);
+        if (stepping) {
+            const uint64_t occL = side ? other : occ;
+            const uint64_t occU = side ? occ : other;
+            if (COUNT_WORK && side == 0u) {
+                const auto sb = __builtin_amdgcn_permlane32_swap(blk, blk, false, false);
+                w_steps += 1;
+                w_occ += skip ? 1 : 2;
+                w_blocks += (skip || sb[1] == blk) ? 1 : 2;
+            }
+            lo = pb + occL;
+            hi = pb + occU - 1ull;
+            --j;
+            done = (lo > hi) || (j < 0);  // query.cpp:35-37
+        }
+        if (alive && done) {
+            if (side == 0u) {
+                if (COUNTS_ONLY) {
+                    out_lower[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                } else {
+                    out_lower[q] = lo;
+                    out_upper[q] = hi;
+                }
+            }
+            q += nslots;
+            fresh = true;
+        }
+    }
+    if (COUNT_WORK) {
+        if (side == 0u && (w_steps || w_ktab)) {
+            atomicAdd(&work[0], w_steps);
+            atomicAdd(&work[1], w_occ);
+            atomicAdd(&work[2], w_blocks);
+            atomicAdd(&work[3], w_ktab);
+        }
+    }
+}
+
+template <bool CW, bool CO>
+static void launch_w(bool ktab, int grid, hipStream_t stream, const rsbwt_view &ix, const uint64_t *pk,
+                     const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo, uint64_t *up,
+                     unsigned long long *work) {
+    if (ktab)
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
+                           Q, k, wpq, lo, up, work);
+    else
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, false>), dim3(grid), dim3(256), 0, stream, ix, pk,
+                           vd, Q, k, wpq, lo, up, work);
+}
+
+hipError_t launch_search_wave(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
+                              uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                              unsigned long long *d_work, int num_cus, hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    // 128 queries per 256-thread workgroup; LDS (36.9 KB per workgroup) admits 4 workgroups per CU
+    size_t g = (Q + 127) / 128;
+    if (g > (size_t)num_cus * 4) g = (size_t)num_cus * 4;
+    const int grid = (int)g;
+    const uint64_t *pk = (const uint64_t *)d_packed;
+    const uint8_t *vd = (const uint8_t *)d_valid;
+    uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
+    const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
+    if (d_work) {
+        if (counts_only) launch_w<true, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_w<true, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+    } else {
+        if (counts_only) launch_w<false, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_w<false, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rsb

@@ -26,12 +26,12 @@ counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "search_kernel<false, false>" in r["Kernel_Name"]:
+        if "search_kernel<false, false, true" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         counters[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -f csv -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0",
-           "kernel": "rsb::search_kernel<false, false>", "counters": counters},
+           "kernel": "rsb::search_kernel<false, false, true, true> (the timed launches; table-build launches excluded)" , "counters": counters},
           open(os.path.join(dst, f"{tag}_pmc_search_kernel.json"), "w"), indent=1)
 fetch_kb = counters["FETCH_SIZE"]["mean_per_launch"]
 write_kb = counters["WRITE_SIZE"]["mean_per_launch"]
