@@ -52,6 +52,18 @@ extern "C" {
 #define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_DEPTH(t) ((uint32_t)(t) << RSBWT_KTAB_SHIFT)
+/* bits 10..11: the single-request search layout ("slots": fixed-span blocks addressed from the
+ * position, one HBM request per Occ lookup instead of two; about as large as the index itself and
+ * kept next to it).  AUTO builds it when index + slots stay within ~30 % of the device's HBM and
+ * the allocation succeeds -- right for one shard per GPU; open many shards per GPU with OFF.
+ * bits 12..23: symbols per slot (0 = from the mean run length). */
+#define RSBWT_SLOTS_SHIFT 10
+#define RSBWT_SLOTS_AUTO (0u << RSBWT_SLOTS_SHIFT)
+#define RSBWT_SLOTS_ON (1u << RSBWT_SLOTS_SHIFT)
+#define RSBWT_SLOTS_OFF (2u << RSBWT_SLOTS_SHIFT)
+#define RSBWT_SLOTS_MASK (3u << RSBWT_SLOTS_SHIFT)
+#define RSBWT_SLOT_SPAN_SHIFT 12
+#define RSBWT_SLOT_SPAN_MASK (0xFFFu << RSBWT_SLOT_SPAN_SHIFT)
 
 typedef struct rsbwt rsbwt_t;         /* one BWT shard resident in one GPU's HBM */
 typedef struct rsbwt_set rsbwt_set_t; /* several shards on this process's GPU(s) */
@@ -96,6 +108,8 @@ uint64_t rsbwt_num_strings(const rsbwt_t *h);
 uint64_t rsbwt_num_blocks(const rsbwt_t *h);
 uint32_t rsbwt_dir_shift(const rsbwt_t *h);
 uint32_t rsbwt_ktab_depth(const rsbwt_t *h); /* 0 = no k-mer table */
+uint32_t rsbwt_slot_span(const rsbwt_t *h);  /* symbols per slot, 0 = slots not built */
+uint64_t rsbwt_slot_overflow_blocks(const rsbwt_t *h);
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h); /* blocks + directory + tables */
 int rsbwt_device(const rsbwt_t *h);
 

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rsbwt_num_blocks": (C.c_uint64, [_vp]),
     "rsbwt_dir_shift": (C.c_uint32, [_vp]),
     "rsbwt_ktab_depth": (C.c_uint32, [_vp]),
+    "rsbwt_slot_span": (C.c_uint32, [_vp]),
+    "rsbwt_slot_overflow_blocks": (C.c_uint64, [_vp]),
     "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
     "rsbwt_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),

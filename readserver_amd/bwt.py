@@ -46,12 +46,15 @@ class GpuBWT:
     """
 
     def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
-                 dir_shift=0, ktab_depth=0):
+                 dir_shift=0, ktab_depth=0, slots="auto", slot_span=0):
         """dir_shift: log2 symbols per directory window (0 = auto).  ktab_depth: depth of the k-mer
-        table (0 = auto, None = no table)."""
+        table (0 = auto, None = no table).  slots: "auto" | True | False -- the single-request
+        search layout; slot_span: symbols per slot (0 = from the mean run length)."""
         self._h = C.c_void_p()
         L = lib()
         flags = (int(dir_shift) & 0x1F) | ((31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5)
+        flags |= {"auto": 0, True: 1, False: 2}[slots] << 10
+        flags |= (int(slot_span) & 0xFFF) << 12
         if filename is not None:
             check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
         elif runs is not None:
@@ -154,6 +157,12 @@ class GpuBWT:
 
     def ktab_depth(self):
         return lib().rsbwt_ktab_depth(self._h)
+
+    def slot_span(self):
+        return lib().rsbwt_slot_span(self._h)
+
+    def slot_overflow_blocks(self):
+        return lib().rsbwt_slot_overflow_blocks(self._h)
 
     def hbm_bytes(self):
         return lib().rsbwt_hbm_bytes(self._h)

@@ -62,4 +62,19 @@ struct rsbwt_view {
 
 #define RSBWT_KTAB_WIDE 0xFFFFFFu
 
+// Single-request search layout (slots.hip): slot(p) = mulhi(p >> a, magic) >> shift = p / S.
+struct slot_params {
+    uint32_t S;      // symbols per slot = m << a
+    uint32_t a;      // 7 or 8: p >> a fits 32 bits
+    uint32_t magic;  // exact 32-bit reciprocal of m
+    uint32_t shift;
+    uint64_t nslots;
+};
+
+struct slot_view {
+    const uint4 *slots;  // nslots slots followed by the overflow blocks; nullptr = not built
+    slot_params p;
+    uint64_t noverflow;
+};
+
 #endif

@@ -57,6 +57,7 @@ struct rsbwt {
     int device = 0;
     int num_cus = 256;
     rsbwt_view view;
+    slot_view slots = {};
     uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
     hipStream_t stream = nullptr;  // host-buffer calls run here
     static constexpr int RING = 64;  // HIP-event pairs of the most recent search launches
@@ -151,6 +152,36 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     h->view = br.view;
     h->num_runs = br.num_runs;
     h->hbm_bytes = br.hbm_bytes;
+    // single-request search layout: on request, or (auto) when it is affordable and fits
+    {
+        const uint32_t mode = flags & RSBWT_SLOTS_MASK;
+        const uint32_t want_S = (flags & RSBWT_SLOT_SPAN_MASK) >> RSBWT_SLOT_SPAN_SHIFT;
+        bool build = mode == RSBWT_SLOTS_ON;
+        slot_params sp;
+        if (mode == RSBWT_SLOTS_AUTO && h->view.n > 0 && choose_slot_span(h->view.n, h->num_runs, want_S, &sp)) {
+            size_t free_b = 0, total_b = 0;
+            const uint64_t est = sp.nslots * RSBWT_BLOCK_BYTES * 21 / 20;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                build = (h->hbm_bytes + est) <= total_b * 3 / 10 && est <= free_b / 2;
+        }
+        if (build && h->view.n > 0) {
+            uint64_t bytes = 0;
+            int rerr = 0;
+            e = build_slots(h->view, h->num_runs, want_S, h->stream, &h->slots, &bytes, &rerr);
+            if (e != hipSuccess || rerr) {
+                h->slots = slot_view{};
+                (void)hipGetLastError();
+                if (mode == RSBWT_SLOTS_ON) {
+                    rsbwt_close(h);
+                    if (rerr) return fail(RSBWT_ERANGE, "slot layout does not fit this shard (2^32 blocks, span < 4096)");
+                    if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the slot layout");
+                    return fail_hip(e, "build_slots");
+                }
+            } else {
+                h->hbm_bytes += bytes;
+            }
+        }
+    }
     // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries stay within
     // 1/16 of the index and whose T-mers still have ~1 expected occurrence (4^T <= n)
     uint32_t T = (flags & RSBWT_KTAB_MASK) >> RSBWT_KTAB_SHIFT;
@@ -166,7 +197,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         const uint64_t bytes = 8ull << (2u * T);
         e = hipMalloc(&d_tab, bytes);
         if (e == hipSuccess) {
-            e = build_ktable(h->view, T, d_tab, h->num_cus, h->stream);
+            e = build_ktable(h->view, &h->slots, T, d_tab, h->num_cus, h->stream);
             if (e != hipSuccess) (void)hipFree(d_tab);
         }
         if (e != hipSuccess) {
@@ -265,6 +296,7 @@ void rsbwt_close(rsbwt_t *h) {
     if (h->view.blocks) (void)hipFree((void *)h->view.blocks);
     if (h->view.dir) (void)hipFree((void *)h->view.dir);
     if (h->view.ktab) (void)hipFree((void *)h->view.ktab);
+    if (h->slots.slots) (void)hipFree((void *)h->slots.slots);
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     for (int i = 0; i < rsbwt::RING; ++i) {
@@ -291,6 +323,8 @@ uint64_t rsbwt_num_strings(const rsbwt_t *h) { return h->num_strings; }
 uint64_t rsbwt_num_blocks(const rsbwt_t *h) { return h->view.nblocks; }
 uint32_t rsbwt_dir_shift(const rsbwt_t *h) { return h->view.dir_shift; }
 uint32_t rsbwt_ktab_depth(const rsbwt_t *h) { return h->view.ktab_depth; }
+uint32_t rsbwt_slot_span(const rsbwt_t *h) { return h->slots.slots ? h->slots.p.S : 0u; }
+uint64_t rsbwt_slot_overflow_blocks(const rsbwt_t *h) { return h->slots.slots ? h->slots.noverflow : 0; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
@@ -365,7 +399,7 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
         }
         const int slot = (int)(h->launches % rsbwt::RING);
         HIP_OK(hipEventRecord(h->ev_start[slot], stream));
-        hipError_t e = launch_search(h->view, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream);
+        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream);
         if (e != hipSuccess) return fail_hip(e, "search kernel launch");
         HIP_OK(hipEventRecord(h->ev_stop[slot], stream));
         h->launches++;
@@ -536,7 +570,9 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
     s->owns = true;
     for (size_t i = 0; i < num_shards; ++i) {
         rsbwt_t *h = nullptr;
-        int rc = rsbwt_open(bwt_paths[i], device_map ? device_map[i] : 0, flags, &h);
+        // many shards per GPU: the slot layout (about as large as the index) only on explicit request
+        const uint32_t f = (num_shards > 1 && (flags & RSBWT_SLOTS_MASK) == RSBWT_SLOTS_AUTO) ? (flags | RSBWT_SLOTS_OFF) : flags;
+        int rc = rsbwt_open(bwt_paths[i], device_map ? device_map[i] : 0, f, &h);
         if (rc) { rsbwt_set_close(s); return rc; }
         s->shards.push_back(h);
     }

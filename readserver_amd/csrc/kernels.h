@@ -12,15 +12,20 @@ namespace rsb {
 
 hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
                        void *d_valid, hipStream_t stream);
-hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
-                         uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+// `sv` may be null or hold no slots: the search then runs on the classic blocks + directory
+hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
+                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream);
 // search_wave.hip: the wave-cooperative form of the same search (needs dir_shift == 8)
-hipError_t launch_search_wave(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
-                              uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                              unsigned long long *d_work, int num_cus, hipStream_t stream);
-hipError_t build_ktable(const rsbwt_view &ix, uint32_t T, uint64_t *d_entries, int num_cus,
-                        hipStream_t stream);
+hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
+                              const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
+                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream);
+// slots.hip
+bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp);
+hipError_t build_slots(const rsbwt_view &ix, uint64_t num_runs, uint32_t want_S, hipStream_t stream,
+                       slot_view *out, uint64_t *bytes, int *range_error);
+hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, uint64_t *d_entries,
+                        int num_cus, hipStream_t stream);
 hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,
                             void *d_out, hipStream_t stream);
 hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n, void *d_out,

@@ -135,8 +135,12 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
             // updateInterval (query.cpp:11-15)
             const uint64_t pb = s_C[b];
-            const bool skip = (role == 0u) && (lo == 0ull);  // Occ(b, -1) = 0
-            const uint64_t p = role ? hi : (skip ? 0ull : lo - 1ull);
+            // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
+            // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
+            // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
+            const uint64_t p_raw = role ? hi : lo - 1ull;
+            const bool skip = p_raw == ~0ull;
+            const uint64_t p = skip ? 0ull : p_raw;
             lane_block lb;
             block_meta bm;
             uint32_t off;
@@ -151,7 +155,7 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                 if ((lane & 7u) == 0u) {  // role 0, so `skip` is the L side's
                     w_steps += 1;
                     w_occ += skip ? 1 : 2;
-                    w_blocks += (skip || oblk == blk) ? 1 : 2;
+                    w_blocks += (skip || oblk == blk) ? 1 : 2;  // (an upper-side skip counts as a read of block 0)
                 }
             }
             lo = pb + occL;
@@ -420,12 +424,14 @@ static bool prefer_wave_kernel() {
     return v != 0;
 }
 
-hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
-                         uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
+                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
-    if (ix.dir_shift == 8 && prefer_wave_kernel())
-        return launch_search_wave(ix, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, d_work, num_cus, stream);
+    const bool have_slots = sv && sv->slots;
+    if ((have_slots || ix.dir_shift == 8) && prefer_wave_kernel())
+        return launch_search_wave(ix, have_slots ? sv : nullptr, d_packed, d_valid, Q, k, d_lower, d_upper,
+                                  counts_only, d_work, num_cus, stream);
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.
     const int grid = grid_for(32, Q, num_cus * 8);
@@ -445,8 +451,8 @@ hipError_t launch_search(const rsbwt_view &ix, const void *d_packed, const void 
 
 // Fills ix.ktab-to-be `d_entries` (4^T entries) by searching every T-mer with the table-less
 // kernel, in slices that bound the temporary memory.  `ix` must not have a table yet.
-hipError_t build_ktable(const rsbwt_view &ix, uint32_t T, uint64_t *d_entries, int num_cus,
-                        hipStream_t stream) {
+hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, uint64_t *d_entries,
+                        int num_cus, hipStream_t stream) {
     const uint64_t total = 1ull << (2u * T);
     const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 22);
     uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr;
@@ -463,7 +469,7 @@ hipError_t build_ktable(const rsbwt_view &ix, uint32_t T, uint64_t *d_entries, i
         const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
         const int g = (int)((m + 255) / 256);
         hipLaunchKernelGGL(ktab_codes_kernel, dim3(g), dim3(256), 0, stream, base, m, d_pk, d_ok);
-        e = launch_search(plain, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
+        e = launch_search(plain, sv, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(ktab_encode_kernel, dim3(g), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
         e = hipGetLastError();

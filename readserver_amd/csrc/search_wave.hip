@@ -24,6 +24,12 @@ namespace rsb {
 
 constexpr int SLOT_U4 = 9;  // 144-byte LDS slot per lane = 9 uint4
 
+// The stage is written as uint4 and parsed as dwords / 8- / 16-byte pieces: the read types may
+// alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
+typedef uint32_t __attribute__((may_alias)) lds_u32;
+typedef uint2 __attribute__((may_alias)) lds_u2;
+typedef uint4 __attribute__((may_alias)) lds_u4;
+
 // matched symbols in one dword of 4 runs: sum of len over the bytes whose symbol == b
 __device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint32_t acc) {
     const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;          // 0 where the symbol matches
@@ -31,9 +37,38 @@ __device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint3
     return __builtin_amdgcn_udot4(x & 0x1F1F1F1Fu, m01, acc, false);
 }
 
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB>
+// Cooperative fetch of up to 64 blocks into the wave's LDS stage: round r, DPP-quad `quad` reads the
+// 128-B block `want` of lane 16r + quad as 4 x 32 B (want == ~0u: that lane needs nothing).
+__device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want, uint32_t quad,
+                                           uint32_t t, uint4 *stage) {
+    uint4 a[4], c[4];
+    uint32_t tb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
+        if (tb[r] != ~0u) {
+            const uint4 *bp = lane_base + (uint64_t)tb[r] * 8u;
+            a[r] = bp[0];
+            c[r] = bp[1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (tb[r] != ~0u) {
+            // pinned: hipcc must not split or sink these loads (two dependent round trips otherwise)
+            asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(a[r].z), "+v"(a[r].w), "+v"(c[r].x), "+v"(c[r].y), "+v"(c[r].z), "+v"(c[r].w));
+            uint4 *dst = stage + (16u * r + quad) * SLOT_U4 + 2u * t;
+            dst[0] = a[r];
+            dst[1] = c[r];
+        }
+    }
+    // LDS operations of one wave execute in order: later reads of `stage` see these writes.
+    asm volatile("" ::: "memory");
+}
+
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS>
 __global__ void __launch_bounds__(256)
-search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
+search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__restrict__ packed,
                    const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work) {
@@ -51,8 +86,9 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     const uint32_t t = lane & 3u;     // which 32 B of a block this lane fetches
     const uint32_t quad = lane >> 2;
     uint4 *stage = s_stage[wave];
-    const uint4 *lane_base = ix.blocks + 2u * t;
+    const uint4 *lane_base = (SLOTS ? sv.slots : ix.blocks) + 2u * t;
     const size_t nslots = (size_t)gridDim.x * 128u;
+    const uint32_t nblk_total = SLOTS ? (uint32_t)(sv.p.nslots + sv.noverflow) : 0u;
 
     size_t q = ((size_t)blockIdx.x * 4u + wave) * 32u + (lane & 31u);
     bool fresh = true;
@@ -105,45 +141,63 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
         const bool stepping = alive && !done;
 
         // ---- this lane's lookup: symbol, position, directory entry -> block id
-        uint32_t b = 1, blk = 0;
+        uint32_t b = 1, blk = 0, pin = 0;
         uint64_t p = 0, pb = 0;
         bool skip = false;
         if (stepping) {
             if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
             pb = s_C[b];
-            skip = (side == 0u) && (lo == 0ull);  // Occ(b, -1) = 0
-            p = side ? hi : (skip ? 0ull : lo - 1ull);
-            const uint2 e = ix.dir[p >> 8];
-            blk = dir_decode<true>(ix, e, p);
+            // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
+            // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
+            // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
+            p = side ? hi : lo - 1ull;
+            skip = p == ~0ull;
+            if (skip) p = 0;
+            if (SLOTS) {
+                blk = __umulhi((uint32_t)(p >> sv.p.a), sv.p.magic) >> sv.p.shift;  // p / S
+                pin = (uint32_t)p - blk * sv.p.S;
+                if (blk >= nblk_total) blk = 0;  // never for p < n; keeps a bad position from faulting
+            } else {
+                const uint2 e = ix.dir[p >> 8];
+                blk = dir_decode<true>(ix, e, p);
+            }
         }
+        const uint32_t first_blk = blk;
 
-        // ---- cooperative fetch: quad `quad` reads the block of lane 16r + quad, round r
-        uint4 a[4], c[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)blk);
-            const uint4 *bp = lane_base + (uint64_t)tb * 8u;
-            a[r] = bp[0];
-            c[r] = bp[1];
+        // ---- fetch every lane's block (idle lanes ask for block 0: all four rounds stay uniform)
+        coop_fetch(lane_base, blk, quad, t, stage);
+        const lds_u32 *mine = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
+        uint32_t off = 0, hops = 0;
+        if (SLOTS) {
+            // the slot may continue in overflow blocks: follow `next` while the position is beyond
+            // this block (wave-uniform loop; only the lanes that need it fetch again)
+            off = pin;
+            bool need = stepping && off >= ((mine[17] >> 8) & 0xFFFu);
+            // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
+            // corrupt chain, so that every wave drains
+            for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
+                uint32_t want = ~0u;
+                if (need) {
+                    const uint32_t m1 = mine[9] >> 8;
+                    want = (mine[1] >> 8) | ((m1 & 0xFFu) << 24);  // next
+                    if (want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
+                    else { blk = want; ++hops; }
+                }
+                coop_fetch(lane_base, want, quad, t, stage);
+                if (need) {
+                    off = pin - ((mine[9] >> 16) & 0xFFFu);  // ostart of the block just fetched
+                    need = off >= ((mine[17] >> 8) & 0xFFFu);
+                }
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(a[r].z), "+v"(a[r].w), "+v"(c[r].x), "+v"(c[r].y), "+v"(c[r].z), "+v"(c[r].w));
-            uint4 *dst = stage + (16u * r + quad) * SLOT_U4 + 2u * t;
-            dst[0] = a[r];
-            dst[1] = c[r];
-        }
-        // LDS operations of one wave execute in order: the reads below see the writes above.
 
         uint64_t occ = 0;
         if (stepping) {
-            const uint32_t *mine = reinterpret_cast<const uint32_t *>(stage + lane * SLOT_U4);
             // header: meta of words 0, 2, 3 and the count word of symbol b (block_format.h)
-            const uint32_t P0lo = mine[1] >> 8;
             const uint32_t m2 = mine[17] >> 8, m3 = mine[25] >> 8;
-            const uint2 cw = *reinterpret_cast<const uint2 *>(mine + 8u * (b - 1u));
-            const uint32_t off = ((uint32_t)p - P0lo) & 0xFFFFFFu;  // exact directory: inside the block
+            const uint2 cw = *reinterpret_cast<const lds_u2 *>(mine + 8u * (b - 1u));
+            if (!SLOTS) off = ((uint32_t)p - (mine[1] >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
             const uint32_t o = off + 1u;
             const uint32_t s1 = m2 >> 12, s2 = m3 & 0xFFFu, s3 = m3 >> 12;
             const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
@@ -153,8 +207,8 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             uint32_t before = 0;
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt) {
-                const uint2 x0 = *reinterpret_cast<const uint2 *>(mine + 8 * qt + 2);
-                const uint4 x1 = *reinterpret_cast<const uint4 *>(mine + 8 * qt + 4);
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(mine + 8 * qt + 2);
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(mine + 8 * qt + 4);
                 uint32_t m = dword_matched(x0.x, bb, 0u);
                 m = dword_matched(x0.y, bb, m);
                 m = dword_matched(x1.x, bb, m);
@@ -166,8 +220,8 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
             // the quarter holding it: run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
             lane_block lb;
             {
-                const uint2 x0 = *reinterpret_cast<const uint2 *>(mine + 8u * cq + 2u);
-                const uint4 x1 = *reinterpret_cast<const uint4 *>(mine + 8u * cq + 4u);
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(mine + 8u * cq + 2u);
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(mine + 8u * cq + 4u);
                 lb.r[0] = x0.x; lb.r[1] = x0.y; lb.r[2] = x1.x; lb.r[3] = x1.y; lb.r[4] = x1.z; lb.r[5] = x1.w;
                 lb.hdr_lo = 0; lb.hdr_hi = 0;
             }
@@ -180,14 +234,20 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
         const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ, (uint32_t)occ, false, false);
         const auto sw_hi = __builtin_amdgcn_permlane32_swap((uint32_t)(occ >> 32), (uint32_t)(occ >> 32), false, false);
         const uint64_t other = side ? (((uint64_t)sw_hi[0] << 32) | sw_lo[0]) : (((uint64_t)sw_hi[1] << 32) | sw_lo[1]);
+        uint32_t other_blk = 0, other_hops = 0;
+        if (COUNT_WORK) {  // swapped with every lane active
+            const auto sb = __builtin_amdgcn_permlane32_swap(first_blk, first_blk, false, false);
+            other_blk = side ? sb[0] : sb[1];
+            const auto sh = __builtin_amdgcn_permlane32_swap(hops, hops, false, false);
+            other_hops = side ? sh[0] : sh[1];
+        }
         if (stepping) {
             const uint64_t occL = side ? other : occ;
             const uint64_t occU = side ? occ : other;
             if (COUNT_WORK && side == 0u) {
-                const auto sb = __builtin_amdgcn_permlane32_swap(blk, blk, false, false);
                 w_steps += 1;
                 w_occ += skip ? 1 : 2;
-                w_blocks += (skip || sb[1] == blk) ? 1 : 2;
+                w_blocks += ((skip || other_blk == first_blk) ? 1 : 2) + hops + other_hops;
             }
             lo = pb + occL;
             hi = pb + occU - 1ull;
@@ -217,21 +277,31 @@ search_wave_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     }
 }
 
-template <bool CW, bool CO>
-static void launch_w(bool ktab, int grid, hipStream_t stream, const rsbwt_view &ix, const uint64_t *pk,
-                     const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo, uint64_t *up,
-                     unsigned long long *work) {
-    if (ktab)
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
-                           Q, k, wpq, lo, up, work);
-    else
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, false>), dim3(grid), dim3(256), 0, stream, ix, pk,
-                           vd, Q, k, wpq, lo, up, work);
+template <bool CW, bool CO, bool KT>
+static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
+                      const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo,
+                      uint64_t *up, unsigned long long *work) {
+    if (sv)
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, true>), dim3(grid), dim3(256), 0, stream, ix, *sv,
+                           pk, vd, Q, k, wpq, lo, up, work);
+    else {
+        slot_view none = {};
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, false>), dim3(grid), dim3(256), 0, stream, ix,
+                           none, pk, vd, Q, k, wpq, lo, up, work);
+    }
 }
 
-hipError_t launch_search_wave(const rsbwt_view &ix, const void *d_packed, const void *d_valid, size_t Q,
-                              uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                              unsigned long long *d_work, int num_cus, hipStream_t stream) {
+template <bool CW, bool CO>
+static void launch_w(bool ktab, const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
+                     const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo,
+                     uint64_t *up, unsigned long long *work) {
+    if (ktab) launch_w2<CW, CO, true>(sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
+    else launch_w2<CW, CO, false>(sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
+}
+
+hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
+                              const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
+                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 128 queries per 256-thread workgroup; LDS (36.9 KB per workgroup) admits 4 workgroups per CU
@@ -243,11 +313,11 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const void *d_packed, const 
     uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
     const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
     if (d_work) {
-        if (counts_only) launch_w<true, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_w<true, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
     } else {
-        if (counts_only) launch_w<false, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_w<false, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<false, true>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
     }
     return hipGetLastError();
 }

@@ -131,12 +131,14 @@ def test_gpu_dense_runs_force_directory_hops(rsb, oracle):
             assert np.array_equal(lo, elo) and np.array_equal(up, eup)
 
 
+@pytest.mark.parametrize("slots", [True, False])
 @pytest.mark.parametrize("R,with_dollar", [(50, True), (3000, False), (200000, True), (4000000, True)])
-def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar):
+def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar, slots):
     rng = np.random.default_rng(77 + R)
     runs = _random_runs(rng, R, with_dollar)
     oix = oracle.from_runs(runs)
-    with rsb.GpuBWT(runs=runs) as g:
+    with rsb.GpuBWT(runs=runs, slots=slots) as g:
+        assert (g.slot_span() > 0) == slots
         for k in (1, 2, 7, 16, 31, 32, 33, 64, 65, 100):
             Q = 3000 if R < 1000000 else 20000
             km = _random_kmers(rng, Q, k)
@@ -146,6 +148,24 @@ def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar):
             assert np.array_equal(up, eup), (R, k)
             cnt = rsb.count_kmers(g, km)
             assert np.array_equal(cnt, np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64))
+
+
+@pytest.mark.parametrize("slots", [True, False])
+@pytest.mark.parametrize("dir_shift", [8, 10])
+def test_gpu_interval_at_the_top_of_a_bwt_without_terminators(rsb, oracle, slots, dir_shift):
+    """No '$' => C[A] = 0, so searches can sit at lower == 0, and a step that finds no b there gives
+    upper = 0 + 0 - 1 = 2^64 - 1.  The reference does not see that as empty (unsigned compare,
+    query.cpp:35) and takes one more step with Occ(b, 2^64 - 1) = 0 (rlebwt.cpp:269); so must we."""
+    rng = np.random.default_rng(12)
+    runs = (rng.integers(1, 5, 60000).astype(np.uint8) << 5) | 31   # long runs: many such cases
+    oix = oracle.from_runs(runs)
+    with rsb.GpuBWT(runs=runs, slots=slots, dir_shift=dir_shift, ktab_depth=None) as g:
+        km = _random_kmers(rng, 30000, 24)
+        km[:, 12:23] = ord("A")      # ...AAAAAAAAAAAX: the poly-A suffix keeps lower at 0
+        lo, up, steps = oix.find_intervals(km, want_steps=True)
+        assert (steps > 12).any()
+        glo, gup = rsb.find_intervals(g, km)
+        assert np.array_equal(glo, lo) and np.array_equal(gup, up)
 
 
 def test_gpu_invalid_and_ragged_inputs(rsb, oracle):
@@ -217,8 +237,8 @@ def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     torch.cuda.synchronize()
     runs = d_runs.cpu().numpy()
     oix = oracle.from_runs(runs)
-    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None)  # every LF step is taken
-    assert g.ktab_depth() == 0
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None, slots=False)  # every LF step is taken
+    assert g.ktab_depth() == 0 and g.slot_span() == 0
     Q, k = 50000, 31
     km = _random_kmers(rng, Q, k)
     d_km = torch.from_numpy(km).cuda()
@@ -240,6 +260,10 @@ def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     assert np.array_equal(d_up.cpu().numpy().view(np.uint64), eup)
     assert st.value == int(steps.sum())
     assert oc.value == 2 * st.value and st.value <= bl.value <= oc.value
+    # distinct blocks, independently: lower-1 and upper share a block iff no block starts in between
+    ends = np.cumsum((runs & 31).astype(np.int64))
+    P0 = np.concatenate([[0], ends[95::96]])
+    assert bl.value > st.value  # wide intervals early in a search do span blocks
     assert L.rsbwt_set_counting(g.handle, 0) == 0
     d_cnt = torch.empty(Q, dtype=torch.int64, device="cuda:0")
     assert L.rsbwt_count_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_cnt), s) == 0
@@ -277,6 +301,58 @@ def test_gpu_file_open_and_shard_set(rsb, oracle, tmp_path):
         g.close()
 
 
+@pytest.mark.parametrize("style,span", [("synth", 0), ("synth", 256), ("synth", 1536), ("synth", 3968),
+                                        ("dense", 0), ("dense", 3968), ("long", 0), ("long", 256),
+                                        ("mixed", 0), ("mixed", 768)])
+def test_gpu_slot_layout_is_bit_exact(rsb, oracle, style, span):
+    """The single-request layout: runs split at slot borders, overflow chains for windows with more
+    than 96 pieces (forced by large spans over short runs), half-empty slots (small spans over long
+    runs) -- the same intervals as the oracle and as the classic layout."""
+    L = rsb.lib()
+    rng = np.random.default_rng(len(style) * 1000 + span)
+    R = 300000
+    if style == "synth":
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 555) == 0
+    elif style == "dense":   # every run of length 1: 96 symbols per 96 pieces
+        runs = (rng.integers(1, 5, R).astype(np.uint8) << 5) | 1
+    elif style == "long":    # every unit full: 31 symbols per piece
+        runs = (rng.integers(1, 5, R).astype(np.uint8) << 5) | 31
+    else:                    # alternating dense and sparse stretches
+        ln = np.where((np.arange(R) // 5000) % 2 == 0, 1, 31).astype(np.uint8)
+        runs = (rng.integers(0, 5, R).astype(np.uint8) << 5) | ln
+    oix = oracle.from_runs(runs)
+    with rsb.GpuBWT(runs=runs, slots=True, slot_span=span, ktab_depth=None) as g, \
+            rsb.GpuBWT(runs=runs, slots=False, ktab_depth=None) as classic:
+        S = g.slot_span()
+        assert S > 0 and S % 128 == 0 and S < 4096
+        if span:
+            assert S <= span * 1.04
+        if style == "dense" or (style in ("synth", "mixed") and span >= 1536):
+            assert g.slot_overflow_blocks() > 0
+        if style == "long":
+            assert g.slot_overflow_blocks() == 0
+        n = g.getBWLen()
+        for k in (1, 2, 9, 31, 40):
+            km = _random_kmers(rng, 20000, k)
+            km[::11] = km[0]
+            lo, up = rsb.find_intervals(g, km)
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo, elo) and np.array_equal(up, eup), (style, span, k)
+            clo, cup = rsb.find_intervals(classic, km)
+            assert np.array_equal(lo, clo) and np.array_equal(up, cup)
+        # k-mers that exist (long matches walk through many slots)
+        import ctypes as C
+        import torch
+        d = torch.empty((4000, 31), dtype=torch.uint8, device="cuda:0")
+        if L.rsbwt_sample_present_kmers_dev(g.handle, 4000, 31, 31, 5, C.c_void_p(d.data_ptr()), None) == 0:
+            torch.cuda.synchronize()
+            km = d.cpu().numpy()
+            lo, up = rsb.find_intervals(g, km)
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+
+
 @pytest.mark.parametrize("T", [2, 3, 5, 8, 11])
 def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T):
     """Searches that start from the k-mer table return exactly what the step-by-step search does
@@ -290,7 +366,7 @@ def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T):
     rng = np.random.default_rng(T)
     with rsb.GpuBWT(runs=runs, ktab_depth=T) as g, rsb.GpuBWT(runs=runs, ktab_depth=None) as plain:
         assert g.ktab_depth() == T and plain.ktab_depth() == 0
-        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T
+        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T  # both carry the same slot layout
         for k in sorted({1, T - 1, T, T + 1, 12, 31, 32, 33, 32 + T // 2, 64, 65, 97}):
             if k < 1:
                 continue
