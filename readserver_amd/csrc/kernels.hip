@@ -117,7 +117,9 @@ search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                     lo = e & RSBWT_COUNT_MASK;
                     hi = lo + width - 1ull;
                     j = (int)(k - T) - 1;
-                    done = (width == 0u) || (j < 0);
+                    // an already-empty tabulated suffix ends the search (query.cpp:35-37); the
+                    // unsigned compare keeps the reference's (0, 2^64-1) corner going, as it does
+                    done = (lo > hi) || (j < 0);
                     if (!done && ((uint32_t)j >> 5) != ((k - 1u) >> 5)) word = pq[(uint32_t)j >> 5];
                 }
             }

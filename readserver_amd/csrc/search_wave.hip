@@ -23,6 +23,7 @@
 namespace rsb {
 
 constexpr int SLOT_U4 = 9;  // 144-byte LDS slot per lane = 9 uint4
+constexpr int WG_WAVES = 4; // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
 
 // The stage is written as uint4 and parsed as dwords / 8- / 16-byte pieces: the read types may
 // alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
@@ -66,13 +67,57 @@ __device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want
     asm volatile("" ::: "memory");
 }
 
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS>
+// Start state of every query, computed ahead of the search so that a query entering the wave
+// costs one independent 16-byte load instead of a chain (validity byte + packed word -> k-mer
+// table entry) in front of every pass.  Record = { lower | flags, upper }.
+constexpr uint64_t INIT_INVALID = 1ull << 63;   // symbol outside ACGT: result (1, 0)
+constexpr uint64_t INIT_FALLBACK = 1ull << 62;  // not from the k-mer table: continue at symbol k-2
+
+template <bool KTAB>
 __global__ void __launch_bounds__(256)
-search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__restrict__ packed,
+search_init_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                    const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
+                   ulonglong2 *__restrict__ init) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const uint64_t *pq = packed + q * wpq;
+    ulonglong2 rec;
+    if (valid[q] == 0) {
+        rec.x = INIT_INVALID;
+        rec.y = 0;
+    } else {
+        const uint64_t last = pq[(k - 1u) >> 5];
+        bool from_table = false;
+        if (KTAB) {
+            const uint32_t T = ix.ktab_depth;
+            const uint32_t off = 2u * (k - T);
+            const uint32_t w0 = off >> 6, sh = off & 63u;
+            uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
+            if (sh + 2u * T > 64u) bits |= last << (64u - sh);
+            const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
+            const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
+            if (width != RSBWT_KTAB_WIDE) {
+                from_table = true;
+                rec.x = e & RSBWT_COUNT_MASK;
+                rec.y = rec.x + width - 1ull;
+            }
+        }
+        if (!from_table) {  // initInterval, query.cpp:18-21
+            const uint32_t b = (uint32_t)((last >> (2u * ((k - 1u) & 31u))) & 3u) + 1u;
+            rec.x = ix.C[b] | INIT_FALLBACK;
+            rec.y = ix.C[b] + ix.total[b] - 1ull;
+        }
+    }
+    init[q] = rec;
+}
+
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS>
+__global__ void __launch_bounds__(64 * WG_WAVES)
+search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__restrict__ packed,
+                   const ulonglong2 *__restrict__ init, size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work) {
-    __shared__ uint4 s_stage[4][64 * SLOT_U4];
+    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     __shared__ uint64_t s_C[8], s_total[8];
     if (threadIdx.x < 5) {
         s_C[threadIdx.x] = ix.C[threadIdx.x];
@@ -87,58 +132,32 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     const uint32_t quad = lane >> 2;
     uint4 *stage = s_stage[wave];
     const uint4 *lane_base = (SLOTS ? sv.slots : ix.blocks) + 2u * t;
-    const size_t nslots = (size_t)gridDim.x * 128u;
+    const size_t nslots = (size_t)gridDim.x * (32u * WG_WAVES);
     const uint32_t nblk_total = SLOTS ? (uint32_t)(sv.p.nslots + sv.noverflow) : 0u;
 
-    size_t q = ((size_t)blockIdx.x * 4u + wave) * 32u + (lane & 31u);
+    size_t q = ((size_t)blockIdx.x * WG_WAVES + wave) * 32u + (lane & 31u);
     bool fresh = true;
     int j = 0;
     uint64_t word = 0, lo = 0, hi = 0;
     unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
 
+    // symbol a table-started query continues with, and the packed word holding it
+    const int j_table = KTAB ? (int)(k - ix.ktab_depth) - 1 : (int)k - 2;
+    const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
+
     while (__builtin_amdgcn_ballot_w64(q < Q) != 0ull) {
         const bool alive = q < Q;
         bool done = false;
-        if (alive && fresh) {
-            fresh = false;
-            j = (int)k - 1;
-            const uint64_t *pq = packed + q * wpq;
-            const uint8_t okb = valid[q];
-            word = pq[(uint32_t)j >> 5];
-            if (okb == 0) {
-                lo = 1;
-                hi = 0;
-                done = true;
-            } else {
-                bool from_table = false;
-                if (KTAB) {
-                    const uint32_t T = ix.ktab_depth;
-                    const uint32_t off = 2u * (k - T);
-                    const uint32_t w0 = off >> 6, sh = off & 63u;
-                    uint64_t bits = (w0 == ((uint32_t)j >> 5) ? word : pq[w0]) >> sh;
-                    if (sh + 2u * T > 64u) bits |= word << (64u - sh);
-                    const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
-                    const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
-                    if (COUNT_WORK) w_ktab += 1;
-                    if (width != RSBWT_KTAB_WIDE) {
-                        from_table = true;
-                        lo = e & RSBWT_COUNT_MASK;
-                        hi = lo + width - 1ull;
-                        j = (int)(k - T) - 1;
-                        done = (width == 0u) || (j < 0);
-                        if (!done && ((uint32_t)j >> 5) != ((k - 1u) >> 5)) word = pq[(uint32_t)j >> 5];
-                    }
-                }
-                if (!from_table) {
-                    const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-                    lo = s_C[b];                    // initInterval, query.cpp:18-21
-                    hi = lo + s_total[b] - 1ull;
-                    --j;
-                    done = j < 0;
-                }
-            }
+        // A query entering the wave only issues its two start-up loads in this pass -- they fly
+        // together with the block fetches of the other lanes -- and steps from the next pass on.
+        const bool starting = alive && fresh;
+        ulonglong2 rec = {0, 0};
+        uint64_t first_word = 0;
+        if (starting) {
+            rec = init[q];
+            first_word = packed[q * wpq + w_table];
         }
-        const bool stepping = alive && !done;
+        const bool stepping = alive && !fresh;
 
         // ---- this lane's lookup: symbol, position, directory entry -> block id
         uint32_t b = 1, blk = 0, pin = 0;
@@ -254,6 +273,24 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             --j;
             done = (lo > hi) || (j < 0);  // query.cpp:35-37
         }
+        if (starting) {
+            fresh = false;
+            if (rec.x & INIT_INVALID) {
+                lo = 1;
+                hi = 0;
+                done = true;
+            } else {
+                const bool fallback = !KTAB || (rec.x & INIT_FALLBACK) != 0ull;
+                lo = rec.x & RSBWT_COUNT_MASK;
+                hi = rec.y;
+                j = fallback ? (int)k - 2 : j_table;
+                word = first_word;
+                if (COUNT_WORK && !fallback) w_ktab += 1;
+                // a tabulated suffix that is already empty ends the search (query.cpp:35-37)
+                done = (j < 0) || (!fallback && lo > hi);
+                if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+            }
+        }
         if (alive && done) {
             if (side == 0u) {
                 if (COUNTS_ONLY) {
@@ -279,24 +316,24 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
 
 template <bool CW, bool CO, bool KT>
 static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
-                      const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo,
-                      uint64_t *up, unsigned long long *work) {
+                      const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
+                      uint64_t *lo, uint64_t *up, unsigned long long *work) {
     if (sv)
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, true>), dim3(grid), dim3(256), 0, stream, ix, *sv,
-                           pk, vd, Q, k, wpq, lo, up, work);
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix, *sv,
+                           pk, init, Q, k, wpq, lo, up, work);
     else {
         slot_view none = {};
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, false>), dim3(grid), dim3(256), 0, stream, ix,
-                           none, pk, vd, Q, k, wpq, lo, up, work);
+        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix,
+                           none, pk, init, Q, k, wpq, lo, up, work);
     }
 }
 
 template <bool CW, bool CO>
 static void launch_w(bool ktab, const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
-                     const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq, uint64_t *lo,
-                     uint64_t *up, unsigned long long *work) {
-    if (ktab) launch_w2<CW, CO, true>(sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
-    else launch_w2<CW, CO, false>(sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
+                     const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
+                     uint64_t *lo, uint64_t *up, unsigned long long *work) {
+    if (ktab) launch_w2<CW, CO, true>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work);
+    else launch_w2<CW, CO, false>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work);
 }
 
 hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
@@ -304,22 +341,33 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
                               bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    // 128 queries per 256-thread workgroup; LDS (36.9 KB per workgroup) admits 4 workgroups per CU
-    size_t g = (Q + 127) / 128;
-    if (g > (size_t)num_cus * 4) g = (size_t)num_cus * 4;
+    // 32 queries per wave; 36.9 KB of LDS per 4-wave workgroup admits 4 workgroups (16 waves) per CU
+    const size_t per_wg = 32u * WG_WAVES;
+    size_t g = (Q + per_wg - 1) / per_wg;
+    const size_t cap = (size_t)num_cus * (WG_WAVES == 1 ? 17 : 16 / WG_WAVES);
+    if (g > cap) g = cap;
     const int grid = (int)g;
     const uint64_t *pk = (const uint64_t *)d_packed;
     const uint8_t *vd = (const uint8_t *)d_valid;
     uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
     const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
+    // start records of this batch: stream-ordered scratch, so concurrent calls do not share state
+    ulonglong2 *init = nullptr;
+    hipError_t e = hipMallocAsync((void **)&init, Q * sizeof(ulonglong2), stream);
+    if (e != hipSuccess) return e;
+    const int ig = (int)((Q + 255) / 256);
+    if (ktab) hipLaunchKernelGGL(search_init_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
+    else hipLaunchKernelGGL(search_init_kernel<false>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
     if (d_work) {
-        if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
+        else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
     } else {
-        if (counts_only) launch_w<false, true>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<false, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
+        else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
     }
-    return hipGetLastError();
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(init, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace rsb
