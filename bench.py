@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
     ap.add_argument("--dir-shift", type=int, default=0)
+    ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
+    ap.add_argument("--slots", choices=["auto", "on", "off"], default=None,
+                    help="single-request search layout (default: auto at 1 shard per GPU, else off)")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -87,7 +90,10 @@ def main():
         d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
         ok(L.rsbwt_synth_runs_dev(ptr(d_runs), R, seed, local, sp))
         torch.cuda.synchronize()
-        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local, dir_shift=a.dir_shift)
+        slots = a.slots or ("auto" if S == 1 else "off")
+        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local, dir_shift=a.dir_shift,
+                       ktab_depth=None if a.ktab_depth < 0 else a.ktab_depth,
+                       slots={"auto": "auto", "on": True, "off": False}[slots])
         if rank == 0 and s == 0 and world == 1 and a.cpu_sample > 0:
             host_runs = d_runs.cpu().numpy()
         del d_runs
@@ -203,13 +209,17 @@ def main():
             "run_bytes_per_shard": R, "symbols_per_shard": int(n_sym), "shards_per_gpu": S,
             "queries_per_batch": Q, "k": k, "present_fraction": a.present_frac,
             "mean_lf_steps_per_search": lf / (S * Q), "dir_shift": shards[0].dir_shift(),
+            "ktab_depth": shards[0].ktab_depth(), "slot_span": shards[0].slot_span(),
+            "slot_overflow_blocks": int(shards[0].slot_overflow_blocks()),
             "index_hbm_bytes_per_shard": int(shards[0].hbm_bytes()), "index_build_s": round(t_build, 2),
             "value_counts": "query x shard searches (= queries at 1 shard)",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(R, Q),
-            "kernel": "search_kernel", "kernel_ms": avg_kernel_ms,
+            "kernel": ("search_wave_kernel" if (shards[0].slot_span() or shards[0].dir_shift() == 8)
+                       and os.environ.get("RSBWT_SEARCH_KERNEL", "w")[0] != "o" else "search_kernel"),
+            "kernel_ms": avg_kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "block_reads_per_launch": bl / S,
             "occ_lookups_per_launch": oc / S,
         },

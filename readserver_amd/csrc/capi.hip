@@ -398,10 +398,8 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
             HIP_OK(hipMemsetAsync(work, 0, 4 * sizeof(unsigned long long), stream));
         }
         const int slot = (int)(h->launches % rsbwt::RING);
-        HIP_OK(hipEventRecord(h->ev_start[slot], stream));
-        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream);
+        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream, h->ev_start[slot], h->ev_stop[slot]);
         if (e != hipSuccess) return fail_hip(e, "search kernel launch");
-        HIP_OK(hipEventRecord(h->ev_stop[slot], stream));
         h->launches++;
     }
     return RSBWT_OK;

@@ -13,13 +13,16 @@ namespace rsb {
 hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
                        void *d_valid, hipStream_t stream);
 // `sv` may be null or hold no slots: the search then runs on the classic blocks + directory
+// ev0/ev1 (optional) are recorded on `stream` immediately around the search kernel itself.
 hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
                          size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                         unsigned long long *d_work, int num_cus, hipStream_t stream);
+                         unsigned long long *d_work, int num_cus, hipStream_t stream,
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // search_wave.hip: the wave-cooperative form of the same search (needs dir_shift == 8)
 hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
                               const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
-                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream);
+                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream,
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // slots.hip
 bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp);
 hipError_t build_slots(const rsbwt_view &ix, uint64_t num_runs, uint32_t want_S, hipStream_t stream,

@@ -428,12 +428,14 @@ static bool prefer_wave_kernel() {
 
 hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
                          size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                         unsigned long long *d_work, int num_cus, hipStream_t stream) {
+                         unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1) {
     if (Q == 0) return hipSuccess;
     const bool have_slots = sv && sv->slots;
     if ((have_slots || ix.dir_shift == 8) && prefer_wave_kernel())
         return launch_search_wave(ix, have_slots ? sv : nullptr, d_packed, d_valid, Q, k, d_lower, d_upper,
-                                  counts_only, d_work, num_cus, stream);
+                                  counts_only, d_work, num_cus, stream, ev0, ev1);
+    if (ev0) (void)hipEventRecord(ev0, stream);
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.
     const int grid = grid_for(32, Q, num_cus * 8);
@@ -448,7 +450,9 @@ hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *
         if (counts_only) launch_search_t<false, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
         else launch_search_t<false, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
     }
-    return hipGetLastError();
+    const hipError_t le = hipGetLastError();
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    return le;
 }
 
 // Fills ix.ktab-to-be `d_entries` (4^T entries) by searching every T-mer with the table-less

@@ -338,7 +338,8 @@ static void launch_w(bool ktab, const slot_view *sv, int grid, hipStream_t strea
 
 hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
                               const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
-                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream) {
+                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream,
+                              hipEvent_t ev0, hipEvent_t ev1) {
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per wave; 36.9 KB of LDS per 4-wave workgroup admits 4 workgroups (16 waves) per CU
@@ -358,6 +359,7 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
     const int ig = (int)((Q + 255) / 256);
     if (ktab) hipLaunchKernelGGL(search_init_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
     else hipLaunchKernelGGL(search_init_kernel<false>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
+    if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_work) {
         if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
         else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
@@ -366,6 +368,7 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
         else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
     }
     e = hipGetLastError();
+    if (ev1) (void)hipEventRecord(ev1, stream);
     const hipError_t e2 = hipFreeAsync(init, stream);
     return e != hipSuccess ? e : e2;
 }
