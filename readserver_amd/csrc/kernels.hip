@@ -51,6 +51,46 @@ __global__ void pack_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_
     }
 }
 
+// Dense input (stride == k): a workgroup's 256 k-mers are one contiguous byte range; it is
+// read with aligned 16-byte loads into LDS and packed from there.
+__global__ void __launch_bounds__(256)
+pack_dense_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_t k, uint32_t wpq,
+                  uint64_t *__restrict__ packed, uint8_t *__restrict__ valid) {
+    extern __shared__ uint4 s_bytes[];  // 256 * k + 32 bytes
+    const size_t q0 = (size_t)blockIdx.x * 256;
+    const size_t nq = (Q - q0) < 256 ? (Q - q0) : 256;
+    const size_t begin = q0 * k, end = begin + nq * k;
+    const uintptr_t base = (uintptr_t)kmers;
+    const size_t a0 = (base + begin) & ~(size_t)15;          // aligned address of the first chunk
+    const size_t skew = (base + begin) - a0;
+    const size_t nchunks = (skew + (end - begin) + 15) / 16;
+    const size_t last = (base + Q * (size_t)k + 15) & ~(size_t)15;  // do not read past the array's last chunk
+    for (size_t c = threadIdx.x; c < nchunks; c += 256) {
+        const uintptr_t addr = a0 + 16 * c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (addr + 16 <= last) v = *reinterpret_cast<const uint4 *>(addr);
+        s_bytes[c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= nq) return;
+    const uint8_t *s = reinterpret_cast<const uint8_t *>(s_bytes) + skew + (size_t)threadIdx.x * k;
+    const size_t q = q0 + threadIdx.x;
+    bool ok = k > 0;
+    for (uint32_t w = 0; w < wpq; ++w) {
+        uint64_t word = 0;
+        const uint32_t b0 = w * 32u;
+        const uint32_t m = (k - b0) < 32u ? (k - b0) : 32u;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint8_t ch = s[b0 + i];
+            const uint32_t code = ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+            ok = ok && (ch == 'A' || code != 0u);
+            word |= (uint64_t)code << (2u * i);
+        }
+        packed[q * wpq + w] = word;
+    }
+    valid[q] = ok ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Batched backward search.
 // ------------------------------------------------------------------------------------------
@@ -390,9 +430,14 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
                        void *d_valid, hipStream_t stream) {
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(256, Q, 8192)), dim3(256), 0, stream,
-                       (const uint8_t *)d_kmers, Q, k, stride, wpq, (uint64_t *)d_packed,
-                       (uint8_t *)d_valid);
+    const size_t lds = 256 * (size_t)k + 32;
+    if (stride == k && k > 0 && lds <= 48 * 1024 && (Q + 255) / 256 < (1ull << 31))
+        hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), lds, stream,
+                           (const uint8_t *)d_kmers, Q, k, wpq, (uint64_t *)d_packed, (uint8_t *)d_valid);
+    else
+        hipLaunchKernelGGL(pack_kernel, dim3(grid_for(256, Q, 8192)), dim3(256), 0, stream,
+                           (const uint8_t *)d_kmers, Q, k, stride, wpq, (uint64_t *)d_packed,
+                           (uint8_t *)d_valid);
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
 //     Occ(b, upper); each lane does its own directory lookup;
 //   * blocks are still fetched the way the memory system likes them (tools/gather_bench.hip): in
 //     four rounds, DPP-quad q of the wave reads the 128-B block wanted by lane 16r+q as
-//     4 x 32 B, and parks it in LDS (144-B slots: conflict-free for 16-B reads at one offset);
+//     4 x 32 B, and parks it in LDS (128-B slots, 16-byte chunks XOR-swizzled by the lane);
 //   * every lane then ranks ITS block out of LDS: the header names the quarter (24 runs) holding
 //     the position, the quarters before it are summed 4 bytes at a time (v_dot4_u32_u8 against a
 //     0/1 match mask), and only the one quarter is scanned run by run (SDWA, 5 VALU per run).
@@ -16,13 +16,18 @@
 // Requires the exact (s = 8) directory; other indexes use the octet kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bwt_device.h"
 #include "kernels.h"
 
 namespace rsb {
 
-constexpr int SLOT_U4 = 9;  // 144-byte LDS slot per lane = 9 uint4
+// LDS stage: lane T's block lives at T * 128 B, its 16-byte chunk c stored at position
+// c ^ swz(T), swz(T) = (T ^ (T >> 3)) & 7 -- 16-byte reads of one chunk across a wave are then
+// bank-conflict free (8-byte ones 2-way), with no padding: 8 KB per wave, 32 KB per 4-wave
+// workgroup, so exactly 5 workgroups (20 waves) fit a CU's 160 KB.
+constexpr int SLOT_U4 = 8;
 constexpr int WG_WAVES = 4; // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
 
 // The stage is written as uint4 and parsed as dwords / 8- / 16-byte pieces: the read types may
@@ -58,9 +63,12 @@ __device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want
         if (tb[r] != ~0u) {
             // pinned: hipcc must not split or sink these loads (two dependent round trips otherwise)
             asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(a[r].z), "+v"(a[r].w), "+v"(c[r].x), "+v"(c[r].y), "+v"(c[r].z), "+v"(c[r].w));
-            uint4 *dst = stage + (16u * r + quad) * SLOT_U4 + 2u * t;
-            dst[0] = a[r];
-            dst[1] = c[r];
+            // target lane T = 16r + quad; swz(T) = (quad ^ (2r + (quad >> 3))) & 7
+            const uint32_t T = 16u * r + quad;
+            const uint32_t sw = (T ^ (T >> 3)) & 7u;
+            uint4 *dst = stage + T * SLOT_U4;
+            dst[(2u * t) ^ sw] = a[r];
+            dst[(2u * t + 1u) ^ sw] = c[r];
         }
     }
     // LDS operations of one wave execute in order: later reads of `stage` see these writes.
@@ -118,12 +126,11 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
-    __shared__ uint64_t s_C[8], s_total[8];
-    if (threadIdx.x < 5) {
-        s_C[threadIdx.x] = ix.C[threadIdx.x];
-        s_total[threadIdx.x] = ix.total[threadIdx.x];
-    }
-    __syncthreads();
+    // C[1..4] in scalar registers, picked with selects.  (Left as ix.C[b], hipcc turns the lookup
+    // into a dependent global load from the kernel-argument segment in every pass; an LDS table
+    // would cost the 128 bytes that keep a fifth workgroup off the CU.)
+    uint64_t c1 = ix.C[1], c2 = ix.C[2], c3 = ix.C[3], c4 = ix.C[4];
+    asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4));
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -166,7 +173,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         if (stepping) {
             if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-            pb = s_C[b];
+            pb = b == 1u ? c1 : b == 2u ? c2 : b == 3u ? c3 : c4;
             // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
             // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
             // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
@@ -186,27 +193,30 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
 
         // ---- fetch every lane's block (idle lanes ask for block 0: all four rounds stay uniform)
         coop_fetch(lane_base, blk, quad, t, stage);
-        const lds_u32 *mine = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
+        // dword d of this lane's block: chunk d >> 2 at (d >> 2) ^ swz(lane)
+        const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
+        const uint32_t swz = (lane ^ (lane >> 3)) & 7u;
+#define MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
         uint32_t off = 0, hops = 0;
         if (SLOTS) {
             // the slot may continue in overflow blocks: follow `next` while the position is beyond
             // this block (wave-uniform loop; only the lanes that need it fetch again)
             off = pin;
-            bool need = stepping && off >= ((mine[17] >> 8) & 0xFFFu);
+            bool need = stepping && off >= ((*MINE(17) >> 8) & 0xFFFu);
             // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
             // corrupt chain, so that every wave drains
             for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
                 uint32_t want = ~0u;
                 if (need) {
-                    const uint32_t m1 = mine[9] >> 8;
-                    want = (mine[1] >> 8) | ((m1 & 0xFFu) << 24);  // next
+                    const uint32_t m1 = *MINE(9) >> 8;
+                    want = (*MINE(1) >> 8) | ((m1 & 0xFFu) << 24);  // next
                     if (want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
                     else { blk = want; ++hops; }
                 }
                 coop_fetch(lane_base, want, quad, t, stage);
                 if (need) {
-                    off = pin - ((mine[9] >> 16) & 0xFFFu);  // ostart of the block just fetched
-                    need = off >= ((mine[17] >> 8) & 0xFFFu);
+                    off = pin - ((*MINE(9) >> 16) & 0xFFFu);  // ostart of the block just fetched
+                    need = off >= ((*MINE(17) >> 8) & 0xFFFu);
                 }
             }
         }
@@ -214,9 +224,9 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         uint64_t occ = 0;
         if (stepping) {
             // header: meta of words 0, 2, 3 and the count word of symbol b (block_format.h)
-            const uint32_t m2 = mine[17] >> 8, m3 = mine[25] >> 8;
-            const uint2 cw = *reinterpret_cast<const lds_u2 *>(mine + 8u * (b - 1u));
-            if (!SLOTS) off = ((uint32_t)p - (mine[1] >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
+            const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+            const uint2 cw = *reinterpret_cast<const lds_u2 *>(MINE(8u * (b - 1u)));
+            if (!SLOTS) off = ((uint32_t)p - (*MINE(1) >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
             const uint32_t o = off + 1u;
             const uint32_t s1 = m2 >> 12, s2 = m3 & 0xFFFu, s3 = m3 >> 12;
             const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
@@ -226,8 +236,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             uint32_t before = 0;
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt) {
-                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(mine + 8 * qt + 2);
-                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(mine + 8 * qt + 4);
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8 * qt + 2));
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8 * qt + 4));
                 uint32_t m = dword_matched(x0.x, bb, 0u);
                 m = dword_matched(x0.y, bb, m);
                 m = dword_matched(x1.x, bb, m);
@@ -239,8 +249,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             // the quarter holding it: run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
             lane_block lb;
             {
-                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(mine + 8u * cq + 2u);
-                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(mine + 8u * cq + 4u);
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8u * cq + 2u));
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8u * cq + 4u));
                 lb.r[0] = x0.x; lb.r[1] = x0.y; lb.r[2] = x1.x; lb.r[3] = x1.y; lb.r[4] = x1.z; lb.r[5] = x1.w;
                 lb.hdr_lo = 0; lb.hdr_hi = 0;
             }
@@ -342,10 +352,17 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
                               hipEvent_t ev0, hipEvent_t ev1) {
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    // 32 queries per wave; 36.9 KB of LDS per 4-wave workgroup admits 4 workgroups (16 waves) per CU
+    // 32 queries per wave, 4 waves per workgroup
     const size_t per_wg = 32u * WG_WAVES;
     size_t g = (Q + per_wg - 1) / per_wg;
-    const size_t cap = (size_t)num_cus * (WG_WAVES == 1 ? 17 : 16 / WG_WAVES);
+    // Workgroups per CU: LDS admits 5, but 4 (16 waves) measured fastest on the 20 GB shard
+    // (2: 6.78 ms, 3: 5.52, 4: 5.24, 5: 5.81); RSBWT_WAVE_WGS_PER_CU overrides.
+    static const int wgs_per_cu = [] {
+        const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 4;
+    }();
+    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;
     const int grid = (int)g;
     const uint64_t *pk = (const uint64_t *)d_packed;
