@@ -159,6 +159,11 @@ def main():
         x, y, z = C.c_uint64(), C.c_uint64(), C.c_uint64()
         ok(L.rsbwt_last_search_work(g.handle, C.byref(x), C.byref(y), C.byref(z)))
         lf, oc, bl = lf + x.value, oc + y.value, bl + z.value
+        ph = (C.c_uint64 * 6)()
+        npass = C.c_uint64()
+        ok(L.rsbwt_last_search_phases(g.handle, ph, C.byref(npass)))
+        phases = {"passes": npass.value, "cycles_per_pass": [round(v / max(npass.value, 1)) for v in ph],
+                  "names": ["setup", "issue", "wait+park", "hops", "rank", "update"]}
         ok(L.rsbwt_set_counting(g.handle, 0))
 
     for _ in range(a.warmup):
@@ -221,7 +226,7 @@ def main():
                        and os.environ.get("RSBWT_SEARCH_KERNEL", "w")[0] != "o" else "search_kernel"),
             "kernel_ms": avg_kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "block_reads_per_launch": bl / S,
-            "occ_lookups_per_launch": oc / S,
+            "occ_lookups_per_launch": oc / S, "phase_stamps": phases,
         },
     }
 

@@ -148,6 +148,10 @@ int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups
                            uint64_t *block_reads);
 /* ... and the number of k-mer-table lookups of that launch. */
 int rsbwt_last_search_ktab_lookups(rsbwt_t *h, uint64_t *lookups);
+/* ... and, for the wave kernel, shader cycles (s_memtime, summed over waves) spent in the six
+ * phases of a pass -- set-up, load issue, wait + LDS park, overflow hops, rank, update -- plus the
+ * number of passes.  Shares only: the stamps fence the pipeline. */
+int rsbwt_last_search_phases(rsbwt_t *h, uint64_t *cycles6, uint64_t *passes);
 
 /* Synthetic data (bench / tests) ----------------------------------------------- */
 /* Fill d_runs (HBM) with num_runs pseudo-random RLUnit bytes: the direct run-stream

@@ -75,6 +75,7 @@ SIGNATURES = {
     "rsbwt_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_counting": (C.c_int, [_vp, C.c_int]),
     "rsbwt_last_search_work": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
+    "rsbwt_last_search_phases": (C.c_int, [_vp, _u64p, _u64p]),
     "rsbwt_last_search_ktab_lookups": (C.c_int, [_vp, _u64p]),
     "rsbwt_synth_runs_dev": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "rsbwt_synth_runs_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),

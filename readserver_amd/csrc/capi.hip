@@ -126,7 +126,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         h->num_cus = prop.multiProcessorCount;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&h->d_work, 4 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&h->d_work, 16 * sizeof(unsigned long long))) != hipSuccess) {
         rsbwt_close(h);
         return fail_hip(e, "creating stream/events");
     }
@@ -395,7 +395,7 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
         std::lock_guard<std::recursive_mutex> lock(h->mu);
         if (h->counting) {
             work = h->d_work;
-            HIP_OK(hipMemsetAsync(work, 0, 4 * sizeof(unsigned long long), stream));
+            HIP_OK(hipMemsetAsync(work, 0, 16 * sizeof(unsigned long long), stream));
         }
         const int slot = (int)(h->launches % rsbwt::RING);
         hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream, h->ev_start[slot], h->ev_stop[slot]);
@@ -518,6 +518,20 @@ int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups
     if (lf_steps) *lf_steps = w[0];
     if (occ_lookups) *occ_lookups = w[1];
     if (block_reads) *block_reads = w[2];
+    return RSBWT_OK;
+}
+
+int rsbwt_last_search_phases(rsbwt_t *h, uint64_t *cycles, uint64_t *passes) {
+    if (!h || !cycles || !passes) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
+    unsigned long long w[16];
+    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) cycles[i] = w[4 + i];
+    *passes = w[10];
     return RSBWT_OK;
 }
 

@@ -45,34 +45,49 @@ __device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint3
 
 // Cooperative fetch of up to 64 blocks into the wave's LDS stage: round r, DPP-quad `quad` reads the
 // 128-B block `want` of lane 16r + quad as 4 x 32 B (want == ~0u: that lane needs nothing).
-__device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want, uint32_t quad,
-                                           uint32_t t, uint4 *stage) {
+struct coop_regs {
     uint4 a[4], c[4];
     uint32_t tb[4];
+};
+
+// issue the loads ...
+__device__ __forceinline__ void coop_issue(const uint4 *lane_base, uint32_t want, uint32_t quad,
+                                           coop_regs &g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
-        if (tb[r] != ~0u) {
-            const uint4 *bp = lane_base + (uint64_t)tb[r] * 8u;
-            a[r] = bp[0];
-            c[r] = bp[1];
+        g.tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
+        if (g.tb[r] != ~0u) {
+            const uint4 *bp = lane_base + (uint64_t)g.tb[r] * 8u;
+            g.a[r] = bp[0];
+            g.c[r] = bp[1];
         }
     }
+}
+
+// ... and, once they have landed, park the blocks in LDS
+__device__ __forceinline__ void coop_park(uint32_t quad, uint32_t t, uint4 *stage, coop_regs &g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (tb[r] != ~0u) {
+        if (g.tb[r] != ~0u) {
             // pinned: hipcc must not split or sink these loads (two dependent round trips otherwise)
-            asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(a[r].z), "+v"(a[r].w), "+v"(c[r].x), "+v"(c[r].y), "+v"(c[r].z), "+v"(c[r].w));
-            // target lane T = 16r + quad; swz(T) = (quad ^ (2r + (quad >> 3))) & 7
+            asm volatile("" : "+v"(g.a[r].x), "+v"(g.a[r].y), "+v"(g.a[r].z), "+v"(g.a[r].w), "+v"(g.c[r].x), "+v"(g.c[r].y), "+v"(g.c[r].z), "+v"(g.c[r].w));
+            // target lane T = 16r + quad, chunks swizzled by swz(T)
             const uint32_t T = 16u * r + quad;
             const uint32_t sw = (T ^ (T >> 3)) & 7u;
             uint4 *dst = stage + T * SLOT_U4;
-            dst[(2u * t) ^ sw] = a[r];
-            dst[(2u * t + 1u) ^ sw] = c[r];
+            dst[(2u * t) ^ sw] = g.a[r];
+            dst[(2u * t + 1u) ^ sw] = g.c[r];
         }
     }
     // LDS operations of one wave execute in order: later reads of `stage` see these writes.
     asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want, uint32_t quad,
+                                           uint32_t t, uint4 *stage) {
+    coop_regs g;
+    coop_issue(lane_base, want, quad, g);
+    coop_park(quad, t, stage, g);
 }
 
 // Start state of every query, computed ahead of the search so that a query entering the wave
@@ -147,6 +162,18 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     int j = 0;
     uint64_t word = 0, lo = 0, hi = 0;
     unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
+    // counting mode also stamps where a pass spends its cycles (shares only: the stamps fence)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, stamp = 0, passes = 0;
+#define STAMP(i)                                                        \
+    if (COUNT_WORK) {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        ph[i] += now_ - stamp;                                          \
+        stamp = now_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+    if (COUNT_WORK) stamp = __builtin_amdgcn_s_memtime();
 
     // symbol a table-started query continues with, and the packed word holding it
     const int j_table = KTAB ? (int)(k - ix.ktab_depth) - 1 : (int)k - 2;
@@ -158,6 +185,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         // A query entering the wave only issues its two start-up loads in this pass -- they fly
         // together with the block fetches of the other lanes -- and steps from the next pass on.
         const bool starting = alive && fresh;
+        // (Issuing these two behind the block loads, from every lane, lets hipcc wait for the blocks
+        // with a counted vmcnt -- measured 4 % slower: more registers, two more loads per pass.)
         ulonglong2 rec = {0, 0};
         uint64_t first_word = 0;
         if (starting) {
@@ -190,9 +219,14 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             }
         }
         const uint32_t first_blk = blk;
+        STAMP(0)  // pass set-up: symbol, position, slot
 
         // ---- fetch every lane's block (idle lanes ask for block 0: all four rounds stay uniform)
-        coop_fetch(lane_base, blk, quad, t, stage);
+        coop_regs g;
+        coop_issue(lane_base, blk, quad, g);
+        STAMP(1)  // issue of the block loads
+        coop_park(quad, t, stage, g);
+        STAMP(2)  // wait for the blocks + LDS writes
         // dword d of this lane's block: chunk d >> 2 at (d >> 2) ^ swz(lane)
         const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
         const uint32_t swz = (lane ^ (lane >> 3)) & 7u;
@@ -221,6 +255,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             }
         }
 
+        STAMP(3)  // overflow / hop loop
         uint64_t occ = 0;
         if (stepping) {
             // header: meta of words 0, 2, 3 and the count word of symbol b (block_format.h)
@@ -259,6 +294,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             occ = skip ? 0ull : cnt + before + inq;
         }
 
+        STAMP(4)  // rank out of LDS
         // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
         const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ, (uint32_t)occ, false, false);
         const auto sw_hi = __builtin_amdgcn_permlane32_swap((uint32_t)(occ >> 32), (uint32_t)(occ >> 32), false, false);
@@ -313,8 +349,14 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             q += nslots;
             fresh = true;
         }
+        STAMP(5)  // exchange, update, start-up decode, result stores
+        if (COUNT_WORK) ++passes;
     }
     if (COUNT_WORK) {
+        if (lane == 0u) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&work[4 + i], ph[i]);
+            atomicAdd(&work[10], passes);
+        }
         if (side == 0u && (w_steps || w_ktab)) {
             atomicAdd(&work[0], w_steps);
             atomicAdd(&work[1], w_occ);

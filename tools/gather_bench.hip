@@ -125,6 +125,51 @@ dep_kernel(const uint4 *__restrict__ buf, uint64_t nlines, const uint2 *__restri
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The wave-cooperative pattern of search_wave_kernel: every lane wants its own random line; in
+// four rounds quad q fetches the line of lane 16r+q (ids by ds_bpermute), parks it in LDS, then
+// each lane reads its line back and derives the next address from it (a dependent chain per lane).
+template <int SETS>
+__global__ void __launch_bounds__(256)
+coop_kernel(const uint4 *__restrict__ buf, uint64_t nlines, int iters, uint32_t *__restrict__ sink) {
+    __shared__ uint4 stage[4][SETS][64 * 8];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, quad = lane >> 2, t = lane & 3;
+    uint64_t state[SETS];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) state[s] = mix64(((uint64_t)blockIdx.x * 256 + threadIdx.x) * SETS + s);
+    for (int it = 0; it < iters; ++it) {
+        uint4 a[SETS][4], c[SETS][4];
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) {
+            const uint32_t want = (uint32_t)(state[s] % nlines);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16 * r + quad) << 2), (int)want);
+                const uint4 *bp = buf + (uint64_t)tb * 8 + t * 2;
+                a[s][r] = bp[0];
+                c[s][r] = bp[1];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t T = 16 * r + quad, sw = (T ^ (T >> 3)) & 7;
+                uint4 *dst = &stage[wave][s][T * 8];
+                dst[(2 * t) ^ sw] = a[s][r];
+                dst[(2 * t + 1) ^ sw] = c[s][r];
+            }
+            asm volatile("" ::: "memory");
+            const uint32_t sw = (lane ^ (lane >> 3)) & 7;
+            const uint4 v = stage[wave][s][lane * 8 + (3 ^ sw)];
+            const uint4 w = stage[wave][s][lane * 8 + (6 ^ sw)];
+            state[s] = mix64(state[s] + v.x + w.w);
+            acc ^= v.y;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 __global__ void fill_kernel(uint4 *buf, uint64_t n16) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nt = (uint64_t)gridDim.x * blockDim.x;
@@ -201,5 +246,13 @@ int main(int argc, char **argv) {
         printf("%d lane(s) per line      %12.3f %12.2f %12.1f\n", LN, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
     }
     RUNLANE(1) RUNLANE(2) RUNLANE(4) RUNLANE(8)
+#define RUNCOOP(SETS, WGS)                                                                          \
+    {                                                                                               \
+        const int g = prop.multiProcessorCount * WGS;                                               \
+        double ms = time_ms([&] { coop_kernel<SETS><<<g, 256>>>(buf, nlines, iters, sink); }, 3);    \
+        double acc = (double)g * 256 * SETS * iters;                                                \
+        printf("coop x%d sets, %d WG/CU   %12.3f %12.2f %12.1f\n", SETS, WGS, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
+    }
+    RUNCOOP(1, 2) RUNCOOP(1, 3) RUNCOOP(1, 4) RUNCOOP(1, 5) RUNCOOP(2, 1) RUNCOOP(2, 2) RUNCOOP(2, 3)
     return 0;
 }
