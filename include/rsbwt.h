@@ -123,6 +123,14 @@ int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, si
 int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                 uint64_t *counts);
 
+/* Batched read extraction: replaces  extractPrefix(pBWT, row) + extractPostfix(pBWT, row)
+ * (src/bwt/query.cpp:43-85; joined as query() does, :94-96) for n SA rows.  Row i's read is written
+ * to out + i*stride (no NUL), its length to len[i] and the length of its prefix part to
+ * prefix_len[i] (either may be NULL).  A read that does not fit `stride` bytes, or a row >= BWLen,
+ * gets len = UINT32_MAX (the reference would loop forever / read out of bounds). */
+int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride,
+                  uint32_t *len, uint32_t *prefix_len);
+
 /* Device-resident forms: all pointers are HBM addresses on the handle's device, `stream` is a
  * hipStream_t (NULL = the null stream).  Nothing is synchronised. ------------------------ */
 /* ASCII k-mers -> 2-bit packed words (A,C,G,T = 0..3, symbol i at bits 2*(i%32) of word i/32,

@@ -11,6 +11,7 @@ from .bwt import (  # noqa: F401
     GpuBWT,
     ShardSet,
     count_kmers,
+    extract_reads,
     extractPostfix,
     extractPrefix,
     find_intervals,

@@ -226,12 +226,27 @@ def extractPostfix(pBWT, index, limit=1 << 16):
     return "".join(out)
 
 
+def extract_reads(pBWT, rows, stride=512):
+    """Batched extractPrefix(row) + extractPostfix(row) (query.cpp:43-85) on the GPU: returns
+    (list of read strings, prefix lengths)."""
+    r = np.ascontiguousarray(rows, dtype=np.uint64)
+    out = np.zeros((r.size, stride), np.uint8)
+    ln = np.empty(r.size, np.uint32)
+    pl = np.empty(r.size, np.uint32)
+    check(lib().rsbwt_extract(pBWT.handle, _ptr(r), r.size, _ptr(out), stride, _ptr(ln), _ptr(pl)))
+    if (ln == 0xFFFFFFFF).any():
+        raise RsbwtError(-1, "a read does not fit the stride / a row is out of range")
+    return [out[i, :ln[i]].tobytes().decode() for i in range(r.size)], pl
+
+
 def query(pBWT, w):
     """query.cpp:87-100: every read containing w."""
     if any(c not in "ACGT" for c in w):
         return []
     itv = findInterval(pBWT, w)
-    return [extractPrefix(pBWT, i) + extractPostfix(pBWT, i) for i in range(itv.lower, itv.upper + 1)]
+    if itv.lower > itv.upper:
+        return []
+    return extract_reads(pBWT, np.arange(itv.lower, itv.upper + 1, dtype=np.uint64))[0]
 
 
 def query_exactmatch(pBWT, w):
@@ -241,8 +256,7 @@ def query_exactmatch(pBWT, w):
     itv = findInterval(pBWT, w)
     if itv.lower > itv.upper:
         return False
-    return any(w == extractPrefix(pBWT, i) + extractPostfix(pBWT, i)
-               for i in range(itv.lower, itv.upper + 1))
+    return w in extract_reads(pBWT, np.arange(itv.lower, itv.upper + 1, dtype=np.uint64))[0]
 
 
 # ---- shard sets -----------------------------------------------------------------

@@ -68,6 +68,7 @@ struct rsbwt {
     std::recursive_mutex mu;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    uint32_t *d_sel = nullptr;  // sampled select table, built on the first extraction
 
     int stage(size_t bytes) {
         if (bytes <= stage_bytes) return RSBWT_OK;
@@ -297,6 +298,7 @@ void rsbwt_close(rsbwt_t *h) {
     if (h->view.dir) (void)hipFree((void *)h->view.dir);
     if (h->view.ktab) (void)hipFree((void *)h->view.ktab);
     if (h->slots.slots) (void)hipFree((void *)h->slots.slots);
+    if (h->d_sel) (void)hipFree(h->d_sel);
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     for (int i = 0; i < rsbwt::RING; ++i) {
@@ -467,6 +469,43 @@ int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, si
 
 int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
     return search_host(h, kmers, Q, k, stride, counts, nullptr, true);
+}
+
+// ---- read extraction --------------------------------------------------------------------------
+
+int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride, uint32_t *len,
+                  uint32_t *prefix_len) {
+    if (!h || (!rows && n) || (!out && n)) return fail(RSBWT_EINVAL, "null argument");
+    if (n == 0) return RSBWT_OK;
+    if (stride == 0) return fail(RSBWT_EINVAL, "stride must be positive");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->d_sel) {
+        const uint64_t words = 4 * select_sample_stride(h->view);
+        HIP_OK(hipMalloc(&h->d_sel, words * sizeof(uint32_t)));
+        HIP_OK(hipMemsetAsync(h->d_sel, 0, words * sizeof(uint32_t), h->stream));
+        hipError_t e = launch_select_samples(h->view, h->d_sel, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "select sample kernel launch");
+        h->hbm_bytes += words * sizeof(uint32_t);
+    }
+    const size_t SLICE = 1u << 20;
+    for (size_t i0 = 0; i0 < n; i0 += SLICE) {
+        const size_t m = std::min(SLICE, n - i0);
+        const size_t a_rows = m * 8, a_out = (m * (size_t)stride + 15) & ~(size_t)15, a_len = m * 4;
+        if ((rc = h->stage(a_rows + a_out + 2 * a_len)) != RSBWT_OK) return rc;
+        uint8_t *base = (uint8_t *)h->d_stage;
+        uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
+        HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = launch_extract(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
+        HIP_OK(hipMemcpyAsync(out + i0 * (size_t)stride, d_out, m * (size_t)stride, hipMemcpyDeviceToHost, h->stream));
+        if (len) HIP_OK(hipMemcpyAsync(len + i0, d_len, a_len, hipMemcpyDeviceToHost, h->stream));
+        if (prefix_len) HIP_OK(hipMemcpyAsync(prefix_len + i0, d_pl, a_len, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    return RSBWT_OK;
 }
 
 // ---- measurement ------------------------------------------------------------------------------

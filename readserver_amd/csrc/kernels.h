@@ -35,6 +35,11 @@ hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n
                              hipStream_t stream);
 hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
                                void *d_out, hipStream_t stream);
+// read extraction: sampled select table (4 x stride u32) and the two walk kernels
+uint64_t select_sample_stride(const rsbwt_view &ix);
+hipError_t launch_select_samples(const rsbwt_view &ix, uint32_t *d_sel, hipStream_t stream);
+hipError_t launch_extract(const rsbwt_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
+                          void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream);
 hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream);
 hipError_t launch_sample_present(const rsbwt_view &ix, size_t Q, uint32_t k, size_t stride,
                                  uint64_t seed, void *d_kmers, hipStream_t stream);

@@ -417,6 +417,108 @@ __global__ void sample_present_kernel(const rsbwt_view ix, size_t Q, uint32_t k,
 }
 
 // ------------------------------------------------------------------------------------------
+// Read extraction (query.cpp:43-85): the read whose suffix is SA row `row`.
+// ------------------------------------------------------------------------------------------
+// Sampled select: sel[c-1][m] = block holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
+constexpr uint32_t SEL_SHIFT = 12;
+
+__global__ void __launch_bounds__(256)
+select_sample_kernel(const rsbwt_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ix.nblocks) return;
+    for (uint32_t c = 1; c <= 4; ++c) {
+        const uint64_t cb = block_count_before(ix, j, c);
+        const uint64_t ce = (j + 1 < ix.nblocks) ? block_count_before(ix, j + 1, c) : ix.total[c];
+        if (ce == cb) continue;
+        // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
+        for (uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT; (m << SEL_SHIFT) < ce; ++m)
+            sel[(c - 1) * stride_m + m] = (uint32_t)j;
+    }
+}
+
+// getOccAt with the sample table bounding the header search (BPTree::select's role)
+__device__ uint64_t thread_occ_at_sampled(const rsbwt_view &ix, const uint32_t *__restrict__ sel,
+                                          uint64_t stride_m, uint32_t b, uint64_t bc) {
+    const uint64_t m = (bc - 1) >> SEL_SHIFT;
+    uint64_t lo = sel[(b - 1) * stride_m + m];
+    uint64_t hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? sel[(b - 1) * stride_m + m + 1] : ix.nblocks - 1;
+    while (hi > lo) {  // largest j in [lo, hi] with count_before(j) < bc
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if (block_count_before(ix, mid, b) >= bc) hi = mid - 1;
+        else lo = mid;
+    }
+    const uint64_t j = lo;
+    const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
+    const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
+    uint64_t offset = bc - block_count_before(ix, j, b);
+    uint64_t index = P0;
+    const uint8_t *bytes = (const uint8_t *)w;
+    for (uint32_t i = 0; i < RSBWT_BLOCK_RUNS; ++i) {  // rlebwt.cpp:245-263
+        const uint8_t u = bytes[32u * (i / RSBWT_LANE_RUNS) + 8u + (i % RSBWT_LANE_RUNS)];
+        const uint32_t len = u & 31u;
+        if ((uint32_t)(u >> 5) != b) { index += len; continue; }
+        if (offset <= len) { index += offset - 1; break; }
+        offset -= len;
+        index += len;
+    }
+    return index;
+}
+
+// extractPrefix (query.cpp:43-63): LF walk left until '$'.  One quad per row; the characters are
+// produced right to left, so they are written downwards from the end of the row's buffer.
+__global__ void __launch_bounds__(256)
+extract_prefix_kernel(const rsbwt_view ix, const uint64_t *__restrict__ rows, size_t n,
+                      uint8_t *__restrict__ out, uint32_t stride, uint32_t *__restrict__ plen) {
+    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
+    const uint32_t t = threadIdx.x & 3u;
+    const uint4 *lane_base = ix.blocks + 2u * t;
+    for (size_t i = quad; i < n; i += nquads) {
+        uint64_t idx = rows[i];
+        uint8_t *buf = out + i * (size_t)stride;
+        uint32_t len = 0;
+        bool fits = idx < ix.n;
+        while (fits) {
+            lane_block lb;
+            block_meta bm;
+            uint32_t off;
+            quad_fetch<false>(ix, lane_base, idx, t, lb, bm, off);
+            const uint32_t c = quad_char(lb, bm, t, off);
+            if (c == 0u) break;
+            if (len == stride) { fits = false; break; }  // the reference would spin (query.cpp:48)
+            idx = ix.C[c] + quad_rank(lb, bm, t, c, off) - 1ull;  // C[b] + Occ(b, idx-1)
+            if (t == 0u) buf[stride - 1u - len] = (uint8_t)("$ACGT"[c]);
+            ++len;
+        }
+        if (t == 0u) plen[i] = fits ? len : 0xFFFFFFFFu;
+    }
+}
+
+// extractPostfix (query.cpp:65-85): F / select walk right until '$', appended after the prefix.
+__global__ void __launch_bounds__(256)
+extract_postfix_kernel(const rsbwt_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
+                       const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out,
+                       uint32_t stride, const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *buf = out + i * (size_t)stride;
+    const uint32_t pl = plen[i];
+    if (pl == 0xFFFFFFFFu || rows[i] >= ix.n) { tlen[i] = 0xFFFFFFFFu; return; }
+    for (uint32_t k = 0; k < pl; ++k) buf[k] = buf[stride - pl + k];  // prefix into place (src >= dst)
+    uint32_t len = pl;
+    uint64_t idx = rows[i];
+    for (;;) {
+        uint32_t f = 0;  // getF, rlebwt.cpp:307-314
+        while (f < 4u && ix.C[f + 1] <= idx) ++f;
+        if (f == 0u) break;
+        if (len == stride) { len = 0xFFFFFFFFu; break; }
+        idx = thread_occ_at_sampled(ix, sel, stride_m, f, idx - ix.C[f] + 1ull);
+        buf[len++] = (uint8_t)("$ACGT"[f]);
+    }
+    tlen[i] = len;
+}
+
+// ------------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------------
 static inline int grid_for(size_t items_per_block, size_t items, int max_blocks) {
@@ -551,6 +653,29 @@ hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const v
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(occ_at_batch_kernel, dim3(grid_for(256, n, 8192)), dim3(256), 0, stream, ix,
                        (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    return hipGetLastError();
+}
+
+uint64_t select_sample_stride(const rsbwt_view &ix) {
+    uint64_t mx = 0;
+    for (int c = 1; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
+    return (mx >> SEL_SHIFT) + 2;
+}
+
+hipError_t launch_select_samples(const rsbwt_view &ix, uint32_t *d_sel, hipStream_t stream) {
+    hipLaunchKernelGGL(select_sample_kernel, dim3((unsigned)((ix.nblocks + 255) / 256)), dim3(256), 0, stream, ix,
+                       d_sel, select_sample_stride(ix));
+    return hipGetLastError();
+}
+
+hipError_t launch_extract(const rsbwt_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
+                          void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(extract_prefix_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+                       (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen);
+    hipLaunchKernelGGL(extract_postfix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ix, d_sel,
+                       select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
+                       (const uint32_t *)d_plen, (uint32_t *)d_len);
     return hipGetLastError();
 }
 
