@@ -123,6 +123,15 @@ int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, si
 int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                 uint64_t *counts);
 
+/* 1-mismatch search (BASELINE configs[3]; not in the reference, defined by composition): for each
+ * k-mer, the exact findInterval of the k-mer itself and of each of its 3k single-substitution
+ * variants.  Outputs are [Q][3k+1] in canonical order: column 0 = the k-mer, column 1 + 3i + d =
+ * position i replaced by the d-th base of ACGT without the original one.  Empty variants have
+ * lower > upper, exactly as findInterval leaves them; a k-mer holding a symbol outside ACGT is
+ * invalid as a whole (every column lower = 1, upper = 0). */
+int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                             uint64_t *lower, uint64_t *upper);
+
 /* Batched read extraction: replaces  extractPrefix(pBWT, row) + extractPostfix(pBWT, row)
  * (src/bwt/query.cpp:43-85; joined as query() does, :94-96) for n SA rows.  Row i's read is written
  * to out + i*stride (no NUL), its length to len[i] and the length of its prefix part to

@@ -15,6 +15,8 @@ from .bwt import (  # noqa: F401
     extractPostfix,
     extractPrefix,
     find_intervals,
+    find_intervals_1mm,
+    hits_1mm,
     findInterval,
     query,
     query_exactmatch,

@@ -189,6 +189,31 @@ def count_kmers(pBWT, kmers):
     return out
 
 
+def find_intervals_1mm(pBWT, kmers):
+    """1-mismatch search by composition: (lower, upper) of shape (Q, 3k+1); column 0 is the k-mer
+    itself, column 1 + 3i + d position i with the d-th base of ACGT minus the original."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    lower = np.empty((Q, 3 * k + 1), np.uint64)
+    upper = np.empty((Q, 3 * k + 1), np.uint64)
+    check(lib().rsbwt_find_intervals_1mm(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(lower), _ptr(upper)))
+    return lower, upper
+
+
+def hits_1mm(kmer, lower_row, upper_row):
+    """The sorted list of (pos, base, lower, upper) of the non-empty variants of one k-mer
+    (pos = -1 for the exact hit), from one row of find_intervals_1mm."""
+    out = []
+    if upper_row[0] >= lower_row[0]:
+        out.append((-1, "", int(lower_row[0]), int(upper_row[0])))
+    for v in range(1, len(lower_row)):
+        if upper_row[v] >= lower_row[v]:
+            pos, d = (v - 1) // 3, (v - 1) % 3
+            alt = [c for c in "ACGT" if c != kmer[pos]][d]
+            out.append((pos, alt, int(lower_row[v]), int(upper_row[v])))
+    return out
+
+
 def findInterval(pBWT, w):
     """BWTInterval findInterval(const BWT*, const std::string& w) (query.cpp:24-41)."""
     lo, up = find_intervals(pBWT, [w])

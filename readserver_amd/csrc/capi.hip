@@ -471,6 +471,41 @@ int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stri
     return search_host(h, kmers, Q, k, stride, counts, nullptr, true);
 }
 
+// ---- 1-mismatch search ------------------------------------------------------------------------
+
+int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                             uint64_t *lower, uint64_t *upper) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers || !lower || !upper) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0 || stride < k) return fail(RSBWT_EINVAL, "bad k/stride");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const uint32_t wpq = words_per_kmer(k);
+    const size_t V = 3 * (size_t)k + 1;
+    const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+        const size_t m = std::min(SLICE, Q - q0), mv = m * V;
+        const size_t ascii_bytes = (m - 1) * stride + k;
+        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+        const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
+        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8)) != RSBWT_OK) return rc;
+        uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+        uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
+        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+        rc = search_dev(h, d_vpk, d_vok, mv, k, d_lo, d_up, false, h->stream);
+        if (rc) return rc;
+        HIP_OK(hipMemcpyAsync(lower + q0 * V, d_lo, mv * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(upper + q0 * V, d_up, mv * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    return RSBWT_OK;
+}
+
 // ---- read extraction --------------------------------------------------------------------------
 
 int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride, uint32_t *len,

@@ -35,6 +35,8 @@ hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n
                              hipStream_t stream);
 hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
                                void *d_out, hipStream_t stream);
+hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
+                           void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (4 x stride u32) and the two walk kernels
 uint64_t select_sample_stride(const rsbwt_view &ix);
 hipError_t launch_select_samples(const rsbwt_view &ix, uint32_t *d_sel, hipStream_t stream);

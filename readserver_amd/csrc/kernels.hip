@@ -417,6 +417,31 @@ __global__ void sample_present_kernel(const rsbwt_view ix, size_t Q, uint32_t k,
 }
 
 // ------------------------------------------------------------------------------------------
+// 1-mismatch search by composition: every k-mer expands to itself plus its 3k
+// single-substitution variants, in canonical order (variant 0 = the k-mer; 1 + 3i + d = position
+// i carries the d-th base of ACGT \ {original}); each variant is then an exact findInterval.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+variants_kernel(const uint64_t *__restrict__ packed, const uint8_t *__restrict__ valid, size_t Q,
+                uint32_t k, uint32_t wpq, uint64_t *__restrict__ vpacked, uint8_t *__restrict__ vvalid) {
+    const uint32_t V = 3u * k + 1u;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * V) return;
+    const size_t q = i / V;
+    const uint32_t v = (uint32_t)(i % V);
+    vvalid[i] = valid[q];
+    for (uint32_t w = 0; w < wpq; ++w) vpacked[i * wpq + w] = packed[q * wpq + w];
+    if (v == 0u) return;
+    const uint32_t pos = (v - 1u) / 3u, d = (v - 1u) % 3u;
+    const uint32_t w = pos >> 5, sh = 2u * (pos & 31u);
+    uint64_t word = packed[q * wpq + w];
+    const uint32_t orig = (uint32_t)(word >> sh) & 3u;
+    const uint32_t repl = d < orig ? d : d + 1u;
+    word = (word & ~(3ull << sh)) | ((uint64_t)repl << sh);
+    vpacked[i * wpq + w] = word;
+}
+
+// ------------------------------------------------------------------------------------------
 // Read extraction (query.cpp:43-85): the read whose suffix is SA row `row`.
 // ------------------------------------------------------------------------------------------
 // Sampled select: sel[c-1][m] = block holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
@@ -653,6 +678,17 @@ hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const v
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(occ_at_batch_kernel, dim3(grid_for(256, n, 8192)), dim3(256), 0, stream, ix,
                        (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
+                           void *d_vvalid, hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    const size_t total = Q * (3 * (size_t)k + 1);
+    hipLaunchKernelGGL(variants_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, Q, k, wpq, (uint64_t *)d_vpacked,
+                       (uint8_t *)d_vvalid);
     return hipGetLastError();
 }
 

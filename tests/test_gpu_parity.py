@@ -80,6 +80,44 @@ def test_gpu_golden_extract(rsb, gix, golden):
         assert s.encode() == e[:n].tobytes() and pl == gpl
 
 
+@pytest.mark.parametrize("k", [1, 5, 31, 33])
+def test_gpu_one_mismatch_equals_composition_of_exact_searches(rsb, oracle, tmp_path, k):
+    """configs[3] is not in the reference: the result is defined as the oracle's exact findInterval
+    of every single-substitution variant."""
+    bwt, rd = str(tmp_path / "s.bwt"), str(tmp_path / "s.reads")
+    rsb.synth_popbwt(bwt, rd, seed=9, genome_len=30000, haplotypes=6, snp_rate=0.01, read_len=60, coverage=3.0)
+    reads = open(rd).read().split()
+    oix = oracle.load(bwt)
+    rng = np.random.default_rng(k)
+    kmers = []
+    for _ in range(300):
+        r = reads[rng.integers(len(reads))]
+        s = rng.integers(0, len(r) - k + 1)
+        w = list(r[s:s + k])
+        if rng.random() < 0.5:  # plant one mismatch
+            p = rng.integers(k)
+            w[p] = "ACGT"[("ACGT".index(w[p]) + 1 + rng.integers(3)) % 4]
+        kmers.append("".join(w))
+    kmers.append("N" * k)
+    with rsb.GpuBWT(bwt) as g:
+        lo, up = rsb.find_intervals_1mm(g, kmers)
+        assert lo.shape == (len(kmers), 3 * k + 1)
+        # a k-mer with a symbol outside ACGT is invalid as a whole: every column is (1, 0)
+        assert (lo[-1] == 1).all() and (up[-1] == 0).all()
+        for qi, w in enumerate(kmers[:-1]):
+            assert (int(lo[qi, 0]), int(up[qi, 0])) == oix.find_interval(w)
+            v = 1
+            for pos in range(k):
+                for alt in [c for c in "ACGT" if c != w[pos]]:
+                    var = w[:pos] + alt + w[pos + 1:]
+                    assert (int(lo[qi, v]), int(up[qi, v])) == oix.find_interval(var), (w, pos, alt)
+                    v += 1
+        hits = rsb.hits_1mm(kmers[0], lo[0], up[0])
+        assert hits == sorted(hits) and all(h[3] >= h[2] for h in hits)
+        planted = sum(1 for qi in range(len(kmers) - 1) if len(rsb.hits_1mm(kmers[qi], lo[qi], up[qi])) > 0)
+        assert planted >= 290 or k < 5
+
+
 def test_gpu_extract_vs_oracle_and_limits(rsb, oracle):
     import ctypes as C
     L = rsb.lib()
