@@ -200,6 +200,22 @@ int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32
 int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
                     uint64_t *counts);
 
+/* Service slice: the CountReads / ExactMatch-Count path of the query service --------
+ * rsbwt_service_counts replaces, for a batch of serialised `Request` messages
+ * (src/service/readserver.proto:3-14; message i = requests[req_off[i] .. req_off[i+1])), what the
+ * recv loop does per message (src/service/service.cpp:1549-1554,1567-1570 -> count_reads
+ * :279-315): two serialised `Reply` messages per request, forward strand then reverse complement,
+ * each carrying the original query and an int32 count summed over the set's shards (the front-end
+ * only adds partition counts: src/service/server.cpp:184-197).  Reply j of request i is
+ * replies[rep_off[2i+j] .. rep_off[2i+j+1]); requests of any other type get two empty replies and
+ * stay with the caller.  *needed receives the bytes required; RSBWT_ERANGE if cap is too small. */
+int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, const uint64_t *req_off, size_t n,
+                         uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed);
+/* The codec on its own (host only). */
+int rsbwt_proto_decode_request(const uint8_t *msg, size_t len, int *t, int *rt, const char **q, size_t *qlen);
+size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen,
+                                      int revcomp, int32_t c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,10 @@ SIGNATURES = {
     "rsbwt_sample_present_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint64, _vp, _vp]),
     "rsbwt_synth_popbwt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_uint32, C.c_double, C.c_int, C.c_int]),
+    "rsbwt_service_counts": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),
+    "rsbwt_proto_decode_request": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
+    "rsbwt_proto_encode_count_reply": (C.c_size_t, [_vp, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int32]),
     "rsbwt_set_open": (C.c_int, [C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
     "rsbwt_set_from_handles": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.POINTER(_vp)]),
     "rsbwt_set_close": (None, [_vp]),
