@@ -137,7 +137,8 @@ search_init_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
 template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS>
 __global__ void __launch_bounds__(64 * WG_WAVES)
 search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__restrict__ packed,
-                   const ulonglong2 *__restrict__ init, size_t Q, uint32_t k, uint32_t wpq,
+                   const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
+                   size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
@@ -154,11 +155,18 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     const uint32_t quad = lane >> 2;
     uint4 *stage = s_stage[wave];
     const uint4 *lane_base = (SLOTS ? sv.slots : ix.blocks) + 2u * t;
-    const size_t nslots = (size_t)gridDim.x * (32u * WG_WAVES);
     const uint32_t nblk_total = SLOTS ? (uint32_t)(sv.p.nslots + sv.noverflow) : 0u;
 
-    size_t q = ((size_t)blockIdx.x * WG_WAVES + wave) * 32u + (lane & 31u);
-    bool fresh = true;
+    // Queries are handed out dynamically: a wave draws chunks of QCHUNK consecutive queries from
+    // one global counter (one atomic per chunk) and gives the next one to whichever lane pair
+    // has finished (ballot + popcount, no further atomics).  A static q += stride schedule makes
+    // every wave as slow as its unluckiest pair: 36 % idle lane-passes on the bench batch.
+    constexpr uint32_t QCHUNK = 1024;
+    uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
+    bool drained = false;                  // the global counter ran past Q
+    size_t q = 0;
+    bool has_q = false;
+    bool fresh = false;
     int j = 0;
     uint64_t word = 0, lo = 0, hi = 0;
     unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
@@ -179,8 +187,34 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     const int j_table = KTAB ? (int)(k - ix.ktab_depth) - 1 : (int)k - 2;
     const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
 
-    while (__builtin_amdgcn_ballot_w64(q < Q) != 0ull) {
-        const bool alive = q < Q;
+    for (;;) {
+        // ---- hand the next queries to the lane pairs that have none
+        if (pool_next >= pool_end && !drained) {
+            unsigned long long c = 0;
+            if (lane == 0u) c = atomicAdd(next_query, (unsigned long long)QCHUNK);
+            c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)c);
+            pool_next = c;
+            pool_end = c + QCHUNK < Q ? c + QCHUNK : Q;
+            if (c >= Q) { drained = true; pool_next = pool_end = 0; }
+        }
+        {
+            const uint32_t want_mask = (uint32_t)__builtin_amdgcn_ballot_w64(!has_q);  // low half = pairs
+            const uint32_t before = __builtin_popcount(want_mask & ((1u << (lane & 31u)) - 1u));
+            const uint64_t mine = pool_next + before;
+            if (!has_q && mine < pool_end) {
+                q = (size_t)mine;
+                has_q = true;
+                fresh = true;
+            }
+            const uint64_t taken = pool_next + __builtin_popcount(want_mask);
+            pool_next = taken < pool_end ? taken : pool_end;
+        }
+        if (__builtin_amdgcn_ballot_w64(has_q) == 0ull) {
+            if (drained) break;
+            continue;  // pool exhausted mid-pass: refill at the top
+        }
+        const bool alive = has_q;
         bool done = false;
         // A query entering the wave only issues its two start-up loads in this pass -- they fly
         // together with the block fetches of the other lanes -- and steps from the next pass on.
@@ -346,8 +380,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                     out_upper[q] = hi;
                 }
             }
-            q += nslots;
-            fresh = true;
+            has_q = false;
+            fresh = false;
         }
         STAMP(5)  // exchange, update, start-up decode, result stores
         if (COUNT_WORK) ++passes;
@@ -370,13 +404,14 @@ template <bool CW, bool CO, bool KT>
 static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
                       const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
                       uint64_t *lo, uint64_t *up, unsigned long long *work) {
+    unsigned long long *ctr = (unsigned long long *)(init + Q);  // zeroed counter behind the records
     if (sv)
         hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix, *sv,
-                           pk, init, Q, k, wpq, lo, up, work);
+                           pk, init, ctr, Q, k, wpq, lo, up, work);
     else {
         slot_view none = {};
         hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix,
-                           none, pk, init, Q, k, wpq, lo, up, work);
+                           none, pk, init, ctr, Q, k, wpq, lo, up, work);
     }
 }
 
@@ -397,12 +432,12 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
     // 32 queries per wave, 4 waves per workgroup
     const size_t per_wg = 32u * WG_WAVES;
     size_t g = (Q + per_wg - 1) / per_wg;
-    // Workgroups per CU: LDS admits 5, but 4 (16 waves) measured fastest on the 20 GB shard
-    // (2: 6.78 ms, 3: 5.52, 4: 5.24, 5: 5.81); RSBWT_WAVE_WGS_PER_CU overrides.
+    // Workgroups per CU: LDS admits 5 (20 waves).  Before queries were handed out dynamically 4 was faster
+    // (5.24 vs 5.81 ms); now 3: 4.69, 4: 4.57, 5: 4.51 ms.  RSBWT_WAVE_WGS_PER_CU overrides.
     static const int wgs_per_cu = [] {
         const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 4;
+        return v > 0 ? v : 5;
     }();
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;
@@ -413,7 +448,9 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
     const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
     // start records of this batch: stream-ordered scratch, so concurrent calls do not share state
     ulonglong2 *init = nullptr;
-    hipError_t e = hipMallocAsync((void **)&init, Q * sizeof(ulonglong2), stream);
+    hipError_t e = hipMallocAsync((void **)&init, (Q + 1) * sizeof(ulonglong2), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(init + Q, 0, sizeof(ulonglong2), stream);  // the query counter
     if (e != hipSuccess) return e;
     const int ig = (int)((Q + 255) / 256);
     if (ktab) hipLaunchKernelGGL(search_init_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
