@@ -134,7 +134,10 @@ search_init_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
     init[q] = rec;
 }
 
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS>
+// LONGK: k > 32, i.e. a query spans several packed words.  A template parameter because with the
+// reload on the path -- however it is guarded at run time -- hipcc waits for vmcnt(0) at the top of
+// every pass, which also waits for the start-up loads just issued by entering lanes.
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool SLOTS, bool LONGK>
 __global__ void __launch_bounds__(64 * WG_WAVES)
 search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__restrict__ packed,
                    const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
@@ -234,7 +237,9 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         uint64_t p = 0, pb = 0;
         bool skip = false;
         if (stepping) {
-            if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+            if (LONGK) {
+                if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+            }
             b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
             pb = b == 1u ? c1 : b == 2u ? c2 : b == 3u ? c3 : c4;
             // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
@@ -368,7 +373,9 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 if (COUNT_WORK && !fallback) w_ktab += 1;
                 // a tabulated suffix that is already empty ends the search (query.cpp:35-37)
                 done = (j < 0) || (!fallback && lo > hi);
-                if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                if (LONGK) {
+                    if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                }
             }
         }
         if (alive && done) {
@@ -405,14 +412,18 @@ static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const r
                       const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
                       uint64_t *lo, uint64_t *up, unsigned long long *work) {
     unsigned long long *ctr = (unsigned long long *)(init + Q);  // zeroed counter behind the records
-    if (sv)
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix, *sv,
-                           pk, init, ctr, Q, k, wpq, lo, up, work);
-    else {
-        slot_view none = {};
-        hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, ix,
-                           none, pk, init, ctr, Q, k, wpq, lo, up, work);
+    slot_view none = {};
+#define RSB_LAUNCH_W(SL, LK)                                                                              \
+    hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, SL, LK>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, \
+                       ix, (SL ? *sv : none), pk, init, ctr, Q, k, wpq, lo, up, work)
+    if (sv) {
+        if (wpq > 1) RSB_LAUNCH_W(true, true);
+        else RSB_LAUNCH_W(true, false);
+    } else {
+        if (wpq > 1) RSB_LAUNCH_W(false, true);
+        else RSB_LAUNCH_W(false, false);
     }
+#undef RSB_LAUNCH_W
 }
 
 template <bool CW, bool CO>

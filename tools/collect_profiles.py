@@ -26,7 +26,7 @@ counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "search_wave_kernel<false, false, true" in r["Kernel_Name"]:
+        if "search_wave_kernel<false, false, true, true, false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         counters[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
