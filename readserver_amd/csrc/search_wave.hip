@@ -275,50 +275,86 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             // the slot may continue in overflow blocks: follow `next` while the position is beyond
             // this block (wave-uniform loop; only the lanes that need it fetch again)
             off = pin;
-            bool need = stepping && off >= ((*MINE(17) >> 8) & 0xFFFu);
+            bool need = stepping && off >= ((*MINE(1) >> 8) & 0xFFFu);  // beyond this block's span
             // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
             // corrupt chain, so that every wave drains
             for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
                 uint32_t want = ~0u;
                 if (need) {
-                    const uint32_t m1 = *MINE(9) >> 8;
-                    want = (*MINE(1) >> 8) | ((m1 & 0xFFu) << 24);  // next
-                    if (want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
+                    const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+                    want = (m2 & 0x7FFFFFu) | (m3 << 23);  // next = x bits 0..31 (chain blocks)
+                    if ((m2 >> 23) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
                     else { blk = want; ++hops; }
                 }
                 coop_fetch(lane_base, want, quad, t, stage);
                 if (need) {
-                    off = pin - ((*MINE(9) >> 16) & 0xFFFu);  // ostart of the block just fetched
-                    need = off >= ((*MINE(17) >> 8) & 0xFFFu);
+                    off = pin - ((*MINE(25) >> 17) & 0xFFFu);  // ostart = x bits 32..43 of the new block
+                    need = off >= ((*MINE(1) >> 8) & 0xFFFu);
                 }
             }
         }
-
         STAMP(3)  // overflow / hop loop
         uint64_t occ = 0;
         if (stepping) {
-            // header: meta of words 0, 2, 3 and the count word of symbol b (block_format.h)
-            const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+            // header: the count word of symbol b and the meta fields (block_format.h / slots.hip)
             const uint2 cw = *reinterpret_cast<const lds_u2 *>(MINE(8u * (b - 1u)));
-            if (!SLOTS) off = ((uint32_t)p - (*MINE(1) >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
+            uint32_t s1, s2, s3;
+            uint32_t before = 0;
+            bool full_sum = true;  // add up every quarter before the one holding the position
+            uint32_t one_q = 0;    // else: the single quarter still to add (if any)
+            bool add_one = false;
+            if (SLOTS) {
+                const uint32_t m0 = *MINE(1) >> 8, m1 = *MINE(9) >> 8, m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+                s1 = m0 >> 12; s2 = m1 & 0xFFFu; s3 = m1 >> 12;
+                if ((m2 >> 23) == 0u) {  // not a chain block: x holds the half-way counts
+                    full_sum = false;
+                    const uint64_t x = (uint64_t)(m2 & 0x7FFFFFu) | ((uint64_t)m3 << 23);
+                    before = (uint32_t)(x >> (11u * (b - 1u))) & 0x7FFu;  // b's in quarters 0+1
+                }
+            } else {
+                const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+                s1 = m2 >> 12; s2 = m3 & 0xFFFu; s3 = m3 >> 12;
+                off = ((uint32_t)p - (*MINE(1) >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
+            }
             const uint32_t o = off + 1u;
-            const uint32_t s1 = m2 >> 12, s2 = m3 & 0xFFFu, s3 = m3 >> 12;
             const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
             const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
             const uint32_t bb = b * 0x01010101u;
-            // quarters before the one holding the position: matched lengths, 4 runs per dot4
-            uint32_t before = 0;
+            if (!full_sum) {
+                // quarters 0+1 come from the header; what is left is at most one quarter
+                before = cq >= 2u ? before : 0u;
+                add_one = (cq & 1u) != 0u;  // cq = 1: quarter 0, cq = 3: quarter 2
+                one_q = cq - 1u;
+            }
+            if (__builtin_amdgcn_ballot_w64(full_sum) != 0ull) {
+                // classic blocks and chain blocks: matched lengths of every earlier quarter
+                uint32_t sum = 0;
 #pragma unroll
-            for (int qt = 0; qt < 3; ++qt) {
-                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8 * qt + 2));
-                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8 * qt + 4));
+                for (int qt = 0; qt < 3; ++qt) {
+                    const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8 * qt + 2));
+                    const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8 * qt + 4));
+                    uint32_t m = dword_matched(x0.x, bb, 0u);
+                    m = dword_matched(x0.y, bb, m);
+                    m = dword_matched(x1.x, bb, m);
+                    m = dword_matched(x1.y, bb, m);
+                    m = dword_matched(x1.z, bb, m);
+                    m = dword_matched(x1.w, bb, m);
+                    sum += (cq > (uint32_t)qt) ? m : 0u;
+                }
+                if (full_sum) before = sum;
+            }
+            if (SLOTS) {
+                // matched lengths of the one remaining quarter, 4 runs per dot4
+                const uint32_t qsel = add_one ? one_q : 0u;
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8u * qsel + 2u));
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8u * qsel + 4u));
                 uint32_t m = dword_matched(x0.x, bb, 0u);
                 m = dword_matched(x0.y, bb, m);
                 m = dword_matched(x1.x, bb, m);
                 m = dword_matched(x1.y, bb, m);
                 m = dword_matched(x1.z, bb, m);
                 m = dword_matched(x1.w, bb, m);
-                before += (cq > (uint32_t)qt) ? m : 0u;
+                before += add_one ? m : 0u;
             }
             // the quarter holding it: run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
             lane_block lb;

@@ -10,10 +10,16 @@
 // blocks stored behind the slots (`next`), each holding the following <= 96 pieces.
 //
 // Slot / overflow block = 4 x (8-byte header word + 24 run bytes), as a classic block, with meta
-//   t=0  next bits 0..23            next = index (into the same array) of the block that continues
-//   t=1  next bits 24..31 | ostart << 8    this window, 0 = none; ostart = symbols of the window
-//   t=2  span | start_1 << 12              that precede this block (0 for the slot itself)
-//   t=3  start_2 | start_3 << 12
+//   t=0  span | start_1 << 12           span = symbols held by this block; start_t = symbols held
+//   t=1  start_2 | start_3 << 12        by quarters 0..t-1
+//   t=2  x bits 0..22 | chain << 23     x is 44 bits wide:
+//   t=3  x bits 23..43                    chain = 0: the symbols A,C,G,T held by quarters 0+1, 11 bits
+//                                                    each (the rank of a position in the second half
+//                                                    starts from them instead of re-adding 48 runs)
+//                                         chain = 1: next (32 bits) | ostart << 32.  The window is
+//                                                    split over several blocks: next = index (into the
+//                                                    same array) of the block that continues it, 0 = none;
+//                                                    ostart = symbols of the window before this block
 // Memory is ~ n/S * 128 B (about the size of the classic index), so slots are built only on
 // request / when HBM allows, NEXT TO the classic index, which the other kernels keep using.
 #include <hip/hip_runtime.h>
@@ -126,8 +132,24 @@ __device__ void flush_slot_block(uint4 *dst, const uint8_t *buf, uint32_t used, 
         start[q] = span;
         for (int d = 0; d < 6; ++d) span = __builtin_amdgcn_sad_u8(wds[6 * q + d] & 0x1F1F1F1Fu, 0u, span);
     }
-    const uint32_t meta[4] = {next & 0xFFFFFFu, (next >> 24) | (ostart << 8), span | (start[1] << 12),
-                              start[2] | (start[3] << 12)};
+    uint64_t x;
+    const bool chain = next != 0u || ostart != 0u;
+    if (chain) {
+        x = (uint64_t)next | ((uint64_t)ostart << 32);
+    } else {
+        x = 0;
+        for (uint32_t c = 1; c <= 4; ++c) {
+            uint32_t h = 0;
+            for (int d = 0; d < 12; ++d) {
+                const uint32_t w = wds[d];
+                for (int k = 0; k < 4; ++k)
+                    if (((w >> (8 * k + 5)) & 7u) == c) h += (w >> (8 * k)) & 31u;
+            }
+            x |= (uint64_t)h << (11u * (c - 1u));
+        }
+    }
+    const uint32_t meta[4] = {span | (start[1] << 12), start[2] | (start[3] << 12),
+                              (uint32_t)(x & 0x7FFFFFu) | (chain ? 1u << 23 : 0u), (uint32_t)(x >> 23)};
     for (int q = 0; q < 4; ++q) {
         const uint64_t word = (cnt0[q] & RSBWT_COUNT_MASK) | ((uint64_t)meta[q] << 40);
         dst[2 * q] = make_uint4((uint32_t)word, (uint32_t)(word >> 32), wds[6 * q], wds[6 * q + 1]);
