@@ -50,9 +50,23 @@ struct coop_regs {
     uint32_t tb[4];
 };
 
-// issue the loads ...
+// issue the loads ...  (ALL: every lane wants a block, so the four id exchanges go out back to
+// back and are waited for once, instead of one LDS round trip per round)
+template <bool ALL>
 __device__ __forceinline__ void coop_issue(const uint4 *lane_base, uint32_t want, uint32_t quad,
                                            coop_regs &g) {
+    if (ALL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            g.tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint4 *bp = lane_base + (uint64_t)g.tb[r] * 8u;
+            g.a[r] = bp[0];
+            g.c[r] = bp[1];
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         g.tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
@@ -86,7 +100,7 @@ __device__ __forceinline__ void coop_park(uint32_t quad, uint32_t t, uint4 *stag
 __device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want, uint32_t quad,
                                            uint32_t t, uint4 *stage) {
     coop_regs g;
-    coop_issue(lane_base, want, quad, g);
+    coop_issue<false>(lane_base, want, quad, g);
     coop_park(quad, t, stage, g);
 }
 
@@ -262,7 +276,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
 
         // ---- fetch every lane's block (idle lanes ask for block 0: all four rounds stay uniform)
         coop_regs g;
-        coop_issue(lane_base, blk, quad, g);
+        coop_issue<true>(lane_base, blk, quad, g);
         STAMP(1)  // issue of the block loads
         coop_park(quad, t, stage, g);
         STAMP(2)  // wait for the blocks + LDS writes
@@ -270,32 +284,10 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
         const uint32_t swz = (lane ^ (lane >> 3)) & 7u;
 #define MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
-        uint32_t off = 0, hops = 0;
-        if (SLOTS) {
-            // the slot may continue in overflow blocks: follow `next` while the position is beyond
-            // this block (wave-uniform loop; only the lanes that need it fetch again)
-            off = pin;
-            bool need = stepping && off >= ((*MINE(1) >> 8) & 0xFFFu);  // beyond this block's span
-            // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
-            // corrupt chain, so that every wave drains
-            for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
-                uint32_t want = ~0u;
-                if (need) {
-                    const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
-                    want = (m2 & 0x7FFFFFu) | (m3 << 23);  // next = x bits 0..31 (chain blocks)
-                    if ((m2 >> 23) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
-                    else { blk = want; ++hops; }
-                }
-                coop_fetch(lane_base, want, quad, t, stage);
-                if (need) {
-                    off = pin - ((*MINE(25) >> 17) & 0xFFFu);  // ostart = x bits 32..43 of the new block
-                    need = off >= ((*MINE(1) >> 8) & 0xFFFu);
-                }
-            }
-        }
-        STAMP(3)  // overflow / hop loop
-        uint64_t occ = 0;
-        if (stepping) {
+        uint32_t hops = 0;
+        // Occ(b, p) out of this lane's staged block, `off` = p's offset in it (slots) / derived
+        // from the block's P0 (classic).  RLEBWT::getOcc, src/bwt/rlebwt.cpp:268-301.
+        auto rank_staged = [&](uint32_t off) -> uint64_t {
             // header: the count word of symbol b and the meta fields (block_format.h / slots.hip)
             const uint2 cw = *reinterpret_cast<const lds_u2 *>(MINE(8u * (b - 1u)));
             uint32_t s1, s2, s3;
@@ -366,10 +358,41 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             }
             const uint32_t inq = lane_scan(lb, b, o - start);
             const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
-            occ = skip ? 0ull : cnt + before + inq;
+            return cnt + before + inq;
+        };
+        uint64_t occ = 0;
+        uint32_t off = pin;
+        bool need = false;
+        if (stepping) {
+            // ranked straight away; the rare lane whose window continues in an overflow block is
+            // found out below and ranked again (keeps the LDS round trip of the span test off the
+            // common path)
+            if (SLOTS) need = off >= ((*MINE(1) >> 8) & 0xFFFu);
+            occ = rank_staged(off);
         }
-
-        STAMP(4)  // rank out of LDS
+        STAMP(3)  // rank out of LDS
+        if (SLOTS) {
+            // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
+            // corrupt chain, so that every wave drains
+            for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
+                uint32_t want = ~0u;
+                const bool was = need;
+                if (need) {
+                    const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+                    want = (m2 & 0x7FFFFFu) | (m3 << 23);  // next = x bits 0..31 (chain blocks)
+                    if ((m2 >> 23) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
+                    else { blk = want; ++hops; }
+                }
+                coop_fetch(lane_base, want, quad, t, stage);
+                if (need) {
+                    off = pin - ((*MINE(25) >> 17) & 0xFFFu);  // ostart = x bits 32..43 of the new block
+                    need = off >= ((*MINE(1) >> 8) & 0xFFFu);
+                }
+                if (was && !need) occ = rank_staged(off);
+            }
+        }
+        if (skip) occ = 0;
+        STAMP(4)  // overflow chains
         // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
         const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ, (uint32_t)occ, false, false);
         const auto sw_hi = __builtin_amdgcn_permlane32_swap((uint32_t)(occ >> 32), (uint32_t)(occ >> 32), false, false);
