@@ -163,7 +163,7 @@ def main():
         npass = C.c_uint64()
         ok(L.rsbwt_last_search_phases(g.handle, ph, C.byref(npass)))
         phases = {"passes": npass.value, "cycles_per_pass": [round(v / max(npass.value, 1)) for v in ph],
-                  "names": ["setup", "issue", "wait+park", "hops", "rank", "update"]}
+                  "names": ["setup", "issue", "wait+park", "rank", "overflow", "update"]}
         ok(L.rsbwt_set_counting(g.handle, 0))
 
     for _ in range(a.warmup):

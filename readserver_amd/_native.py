@@ -5,7 +5,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "librsbwt.so")
+_LIB = os.environ.get("RSBWT_LIB") or os.path.join(_HERE, "lib", "librsbwt.so")
 _lock = threading.Lock()
 _lib = None
 

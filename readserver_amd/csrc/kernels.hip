@@ -632,7 +632,7 @@ hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *
 hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, uint64_t *d_entries,
                         int num_cus, hipStream_t stream) {
     const uint64_t total = 1ull << (2u * T);
-    const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 22);
+    const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 24);
     uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr;
     uint8_t *d_ok = nullptr;
     hipError_t e;

@@ -43,66 +43,35 @@ __device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint3
     return __builtin_amdgcn_udot4(x & 0x1F1F1F1Fu, m01, acc, false);
 }
 
-// Cooperative fetch of up to 64 blocks into the wave's LDS stage: round r, DPP-quad `quad` reads the
-// 128-B block `want` of lane 16r + quad as 4 x 32 B (want == ~0u: that lane needs nothing).
-struct coop_regs {
-    uint4 a[4], c[4];
-    uint32_t tb[4];
-};
+// Fetch of up to 64 blocks into the wave's LDS stage, direct to LDS (global_load_lds_dwordx4,
+// gfx950): no register round trip, no ds_write pass.  One instruction writes 1 KB of LDS in lane
+// order, so the work is split the way that makes this the stage layout itself: instruction k
+// (0..7) serves lanes T = 8o + k, the eight lanes of octet o each bringing 16 B of the block
+// lane T wants (a full 128-B line per octet: the request shape tools/gather_bench.hip measures
+// fastest).  Lane T's block then sits at k * 1 KB + o * 128 B, chunk c at position c ^ k -- the
+// swizzle is applied on the SOURCE side (lane l of the octet loads chunk (l & 7) ^ k) -- so a wave
+// reading one chunk of every row is bank-conflict free.  8 KB per wave, 32 KB per 4-wave
+// workgroup: exactly 5 workgroups (20 waves) fit a CU's 160 KB.
+// want == ~0u: that lane needs nothing (its octet's lanes are masked off for that instruction and
+// the row keeps what it held).
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
 
-// issue the loads ...  (ALL: every lane wants a block, so the four id exchanges go out back to
-// back and are waited for once, instead of one LDS round trip per round)
-template <bool ALL>
-__device__ __forceinline__ void coop_issue(const uint4 *lane_base, uint32_t want, uint32_t quad,
-                                           coop_regs &g) {
-    if (ALL) {
+__device__ __forceinline__ void glds_fetch(const char *blocks, uint32_t want, uint32_t lane, uint32_t stage_lds) {
+    uint32_t tb[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            g.tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
+    for (int k = 0; k < 8; ++k)
+        tb[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~7u) + k) << 2), (int)want);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint4 *bp = lane_base + (uint64_t)g.tb[r] * 8u;
-            g.a[r] = bp[0];
-            g.c[r] = bp[1];
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        g.tb[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + quad) << 2), (int)want);
-        if (g.tb[r] != ~0u) {
-            const uint4 *bp = lane_base + (uint64_t)g.tb[r] * 8u;
-            g.a[r] = bp[0];
-            g.c[r] = bp[1];
+    for (int k = 0; k < 8; ++k) {
+        if (tb[k] != ~0u) {
+            const char *src = blocks + (uint64_t)tb[k] * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
+            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, 0);
         }
     }
 }
-
-// ... and, once they have landed, park the blocks in LDS
-__device__ __forceinline__ void coop_park(uint32_t quad, uint32_t t, uint4 *stage, coop_regs &g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (g.tb[r] != ~0u) {
-            // pinned: hipcc must not split or sink these loads (two dependent round trips otherwise)
-            asm volatile("" : "+v"(g.a[r].x), "+v"(g.a[r].y), "+v"(g.a[r].z), "+v"(g.a[r].w), "+v"(g.c[r].x), "+v"(g.c[r].y), "+v"(g.c[r].z), "+v"(g.c[r].w));
-            // target lane T = 16r + quad, chunks swizzled by swz(T)
-            const uint32_t T = 16u * r + quad;
-            const uint32_t sw = (T ^ (T >> 3)) & 7u;
-            uint4 *dst = stage + T * SLOT_U4;
-            dst[(2u * t) ^ sw] = g.a[r];
-            dst[(2u * t + 1u) ^ sw] = g.c[r];
-        }
-    }
-    // LDS operations of one wave execute in order: later reads of `stage` see these writes.
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ void coop_fetch(const uint4 *lane_base, uint32_t want, uint32_t quad,
-                                           uint32_t t, uint4 *stage) {
-    coop_regs g;
-    coop_issue<false>(lane_base, want, quad, g);
-    coop_park(quad, t, stage, g);
-}
+// the blocks are in LDS once every outstanding load has returned
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Start state of every query, computed ahead of the search so that a query entering the wave
 // costs one independent 16-byte load instead of a chain (validity byte + packed word -> k-mer
@@ -168,10 +137,10 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t side = lane >> 5;  // 0: lower-1 side, 1: upper side
-    const uint32_t t = lane & 3u;     // which 32 B of a block this lane fetches
-    const uint32_t quad = lane >> 2;
     uint4 *stage = s_stage[wave];
-    const uint4 *lane_base = (SLOTS ? sv.slots : ix.blocks) + 2u * t;
+    const char *blocks_bytes = reinterpret_cast<const char *>(SLOTS ? sv.slots : ix.blocks);
+    // LDS byte address of this wave's stage, in a scalar register (it goes to M0)
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
     const uint32_t nblk_total = SLOTS ? (uint32_t)(sv.p.nslots + sv.noverflow) : 0u;
 
     // Queries are handed out dynamically: a wave draws chunks of QCHUNK consecutive queries from
@@ -181,9 +150,12 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     constexpr uint32_t QCHUNK = 1024;
     uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
     bool drained = false;                  // the global counter ran past Q
-    size_t q = 0;
+    size_t q = 0;          // the query this lane pair is stepping
     bool has_q = false;
-    bool fresh = false;
+    size_t nq = 0;         // the one it runs next, start record already prefetched
+    bool has_n = false;
+    ulonglong2 nrec = {0, 0};
+    uint64_t nword = 0;
     int j = 0;
     uint64_t word = 0, lo = 0, hi = 0;
     unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
@@ -205,7 +177,33 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
 
     for (;;) {
-        // ---- hand the next queries to the lane pairs that have none
+        // ---- a pair whose query ended in the last pass takes up the one it had prefetched: it
+        // steps in this very pass (a start record fetched on demand instead would cost every query
+        // one idle pass, ~10 % of all lane-passes on the bench batch)
+        bool done = false;
+        if (!has_q && has_n) {
+            has_q = true;
+            has_n = false;
+            q = nq;
+            if (nrec.x & INIT_INVALID) {
+                lo = 1;
+                hi = 0;
+                done = true;
+            } else {
+                const bool fallback = !KTAB || (nrec.x & INIT_FALLBACK) != 0ull;
+                lo = nrec.x & RSBWT_COUNT_MASK;
+                hi = nrec.y;
+                j = fallback ? (int)k - 2 : j_table;
+                word = nword;
+                if (COUNT_WORK && !fallback) w_ktab += 1;
+                // a tabulated suffix that is already empty ends the search (query.cpp:35-37)
+                done = (j < 0) || (!fallback && lo > hi);
+                if (LONGK) {
+                    if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                }
+            }
+        }
+        // ---- hand the next queries to the lane pairs that have none in reserve
         if (pool_next >= pool_end && !drained) {
             unsigned long long c = 0;
             if (lane == 0u) c = atomicAdd(next_query, (unsigned long long)QCHUNK);
@@ -215,36 +213,33 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             pool_end = c + QCHUNK < Q ? c + QCHUNK : Q;
             if (c >= Q) { drained = true; pool_next = pool_end = 0; }
         }
+        bool got_n = false;
         {
-            const uint32_t want_mask = (uint32_t)__builtin_amdgcn_ballot_w64(!has_q);  // low half = pairs
+            const uint32_t want_mask = (uint32_t)__builtin_amdgcn_ballot_w64(!has_n);  // low half = pairs
             const uint32_t before = __builtin_popcount(want_mask & ((1u << (lane & 31u)) - 1u));
             const uint64_t mine = pool_next + before;
-            if (!has_q && mine < pool_end) {
-                q = (size_t)mine;
-                has_q = true;
-                fresh = true;
+            if (!has_n && mine < pool_end) {
+                nq = (size_t)mine;
+                got_n = true;
             }
             const uint64_t taken = pool_next + __builtin_popcount(want_mask);
             pool_next = taken < pool_end ? taken : pool_end;
         }
-        if (__builtin_amdgcn_ballot_w64(has_q) == 0ull) {
+        if (__builtin_amdgcn_ballot_w64(has_q || got_n) == 0ull) {
             if (drained) break;
             continue;  // pool exhausted mid-pass: refill at the top
         }
-        const bool alive = has_q;
-        bool done = false;
-        // A query entering the wave only issues its two start-up loads in this pass -- they fly
-        // together with the block fetches of the other lanes -- and steps from the next pass on.
-        const bool starting = alive && fresh;
-        // (Issuing these two behind the block loads, from every lane, lets hipcc wait for the blocks
-        // with a counted vmcnt -- measured 4 % slower: more registers, two more loads per pass.)
+        // The two start-up loads of a query taken into reserve fly together with this pass's block
+        // fetches.  (Issuing them behind the block loads, from every lane, lets hipcc wait for the
+        // blocks with a counted vmcnt -- measured 4 % slower: more registers, two more loads.)
         ulonglong2 rec = {0, 0};
         uint64_t first_word = 0;
-        if (starting) {
-            rec = init[q];
-            first_word = packed[q * wpq + w_table];
+        if (got_n) {
+            rec = init[nq];
+            first_word = packed[nq * wpq + w_table];
         }
-        const bool stepping = alive && !fresh;
+        const bool alive = has_q;
+        const bool stepping = alive && !done;
 
         // ---- this lane's lookup: symbol, position, directory entry -> block id
         uint32_t b = 1, blk = 0, pin = 0;
@@ -274,15 +269,26 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         const uint32_t first_blk = blk;
         STAMP(0)  // pass set-up: symbol, position, slot
 
-        // ---- fetch every lane's block (idle lanes ask for block 0: all four rounds stay uniform)
-        coop_regs g;
-        coop_issue<true>(lane_base, blk, quad, g);
+        // ---- fetch: one request per distinct block.  Lanes with nothing to look up ask for
+        // nothing, and the upper side of a query whose two positions fall in the same block (more
+        // than 4 in 10 lookups on the bench batch) reads the lower side's row instead of fetching
+        // the block again: the L1's outstanding-request slots are what this kernel runs out of.
+        uint32_t want = (stepping && !skip) ? blk : ~0u;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(want, want, false, false);  // full exec
+            const uint32_t other_want = side ? sw[0] : sw[1];
+            if (side != 0u && want == other_want) want = ~0u;
+        }
+        const bool shared_row = stepping && !skip && want == ~0u;
+        glds_fetch(blocks_bytes, want, lane, stage_lds);
         STAMP(1)  // issue of the block loads
-        coop_park(quad, t, stage, g);
-        STAMP(2)  // wait for the blocks + LDS writes
-        // dword d of this lane's block: chunk d >> 2 at (d >> 2) ^ swz(lane)
-        const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + lane * SLOT_U4);
-        const uint32_t swz = (lane ^ (lane >> 3)) & 7u;
+        glds_wait();
+        STAMP(2)  // wait for the blocks
+        // dword d of this lane's block: chunk d >> 2 at (d >> 2) ^ swz(lane) of the row
+        // (lane & 7) * 1 KB + (lane >> 3) * 128 B; lanes l and l + 32 share k and the swizzle
+        const uint32_t swz = lane & 7u;
+        const lds_u32 *own_row = reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
+        const lds_u32 *mine0 = shared_row ? own_row - 4 * 32 : own_row;  // row of lane - 32
 #define MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
         uint32_t hops = 0;
         // Occ(b, p) out of this lane's staged block, `off` = p's offset in it (slots) / derived
@@ -311,7 +317,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             const uint32_t o = off + 1u;
             const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
             const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
-            const uint32_t bb = b * 0x01010101u;
+            const uint32_t bb = __umul24(b, 0x010101u) | (b << 24);  // b in every byte (full-rate ops)
             if (!full_sum) {
                 // quarters 0+1 come from the header; what is left is at most one quarter
                 before = cq >= 2u ? before : 0u;
@@ -363,7 +369,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         uint64_t occ = 0;
         uint32_t off = pin;
         bool need = false;
-        if (stepping) {
+        if (stepping && !skip) {
             // ranked straight away; the rare lane whose window continues in an overflow block is
             // found out below and ranked again (keeps the LDS round trip of the span test off the
             // common path)
@@ -383,7 +389,9 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                     if ((m2 >> 23) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
                     else { blk = want; ++hops; }
                 }
-                coop_fetch(lane_base, want, quad, t, stage);
+                glds_fetch(blocks_bytes, want, lane, stage_lds);
+                glds_wait();
+                if (want != ~0u) mine0 = own_row;  // an overflow block always lands in the lane's own row
                 if (need) {
                     off = pin - ((*MINE(25) >> 17) & 0xFFFu);  // ostart = x bits 32..43 of the new block
                     need = off >= ((*MINE(1) >> 8) & 0xFFFu);
@@ -391,7 +399,6 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 if (was && !need) occ = rank_staged(off);
             }
         }
-        if (skip) occ = 0;
         STAMP(4)  // overflow chains
         // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
         const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ, (uint32_t)occ, false, false);
@@ -417,25 +424,10 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             --j;
             done = (lo > hi) || (j < 0);  // query.cpp:35-37
         }
-        if (starting) {
-            fresh = false;
-            if (rec.x & INIT_INVALID) {
-                lo = 1;
-                hi = 0;
-                done = true;
-            } else {
-                const bool fallback = !KTAB || (rec.x & INIT_FALLBACK) != 0ull;
-                lo = rec.x & RSBWT_COUNT_MASK;
-                hi = rec.y;
-                j = fallback ? (int)k - 2 : j_table;
-                word = first_word;
-                if (COUNT_WORK && !fallback) w_ktab += 1;
-                // a tabulated suffix that is already empty ends the search (query.cpp:35-37)
-                done = (j < 0) || (!fallback && lo > hi);
-                if (LONGK) {
-                    if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
-                }
-            }
+        if (got_n) {
+            nrec = rec;
+            nword = first_word;
+            has_n = true;
         }
         if (alive && done) {
             if (side == 0u) {
@@ -447,7 +439,6 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 }
             }
             has_q = false;
-            fresh = false;
         }
         STAMP(5)  // exchange, update, start-up decode, result stores
         if (COUNT_WORK) ++passes;
