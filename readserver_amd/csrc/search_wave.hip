@@ -71,7 +71,13 @@ __device__ __forceinline__ void glds_fetch(const char *blocks, uint32_t want, ui
     }
 }
 // the blocks are in LDS once every outstanding load has returned
-__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// (the builtin, not inline asm: hipcc's wait-count bookkeeping then knows nothing is outstanding and
+// does not add its own vmcnt(0) at the head of the next pass, in front of that pass's loads, where
+// it would sit out the result stores of the queries that just ended)
+__device__ __forceinline__ void glds_wait() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
 
 // Start state of every query, computed ahead of the search so that a query entering the wave
 // costs one independent 16-byte load instead of a chain (validity byte + packed word -> k-mer
@@ -128,11 +134,18 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
-    // C[1..4] in scalar registers, picked with selects.  (Left as ix.C[b], hipcc turns the lookup
-    // into a dependent global load from the kernel-argument segment in every pass; an LDS table
-    // would cost the 128 bytes that keep a fifth workgroup off the CU.)
-    uint64_t c1 = ix.C[1], c2 = ix.C[2], c3 = ix.C[3], c4 = ix.C[4];
-    asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4));
+    // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
+    // ds_bpermute reads (the LDS crossbar idles while the VALU is the busier pipe; selects out
+    // of scalar registers cost 15 VALU instructions a pass.  Left as ix.C[b], hipcc turns the
+    // lookup into a dependent global load from the kernel-argument segment in every pass; an LDS
+    // table would cost the 128 bytes that keep a fifth workgroup off the CU.)
+    uint32_t ctab_lo, ctab_hi;
+    {
+        const uint32_t l3 = threadIdx.x & 3u;
+        const uint64_t cv = l3 == 0u ? ix.C[1] : l3 == 1u ? ix.C[2] : l3 == 2u ? ix.C[3] : ix.C[4];
+        ctab_lo = (uint32_t)cv;
+        ctab_hi = (uint32_t)(cv >> 32);
+    }
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -250,7 +263,6 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             }
             b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-            pb = b == 1u ? c1 : b == 2u ? c2 : b == 3u ? c3 : c4;
             // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
             // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
             // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
@@ -266,6 +278,9 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 blk = dir_decode<true>(ix, e, p);
             }
         }
+        // C[b], with every lane active: a ds_bpermute returns 0 from a masked-off source lane
+        pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_hi) << 32) |
+             (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_lo);
         const uint32_t first_blk = blk;
         STAMP(0)  // pass set-up: symbol, position, slot
 
