@@ -186,6 +186,19 @@ int rsbwt_synth_popbwt(const char *bwt_path, const char *reads_path, uint64_t se
                        uint64_t genome_len, uint32_t haplotypes, double snp_rate,
                        uint32_t read_len, double coverage, int shard, int num_shards);
 
+/* The reference's FM-index file "<bwt>.bpi2"  -------------------------------------
+ * Replaces src/util/index_rlebwt.cpp:19-22 (RLEBWT(path) + serialiseFMIndex(path + ".bpi2"),
+ * src/bwt/rlebwt.cpp:150-161) for deployments that keep the CPU reference next to this engine:
+ * the file written is byte-identical to the reference's for the same .bwt.  Host only; the
+ * engine itself never reads a .bpi2 (its device index is derived from the run bytes). */
+int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path);
+/* Validates a prebuilt .bpi2 (what deserialiseFMIndex would load, rlebwt.cpp:163-200) against the
+ * resident index: level shapes, C[], vSum, and the absolute counts at the start of up to
+ * max_samples evenly spaced 64-run buckets (0 = all) against Occ on the GPU.  *mismatches == 0
+ * means the file describes this BWT; rsbwt_last_error() names the first difference. */
+int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
+                     uint64_t *mismatches);
+
 /* Shard sets: the shards of one process, searched with one call ------------------ */
 int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
                    uint32_t flags, rsbwt_set_t **out);

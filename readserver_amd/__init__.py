@@ -21,4 +21,6 @@ from .bwt import (  # noqa: F401
     query,
     query_exactmatch,
     synth_popbwt,
+    write_bpi2,
+    check_bpi2,
 )

@@ -5,7 +5,10 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 src="$here/csrc"
 mkdir -p "$here/lib"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-exec "$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wall -Wno-unused-function \
+"$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wall -Wno-unused-function \
   -I"$here/../include" \
-  "$src/kernels.hip" "$src/search_wave.hip" "$src/slots.hip" "$src/index.hip" "$src/capi.hip" "$src/bwt_file.cpp" "$src/synth.cpp" "$src/service_slice.cpp" \
+  "$src/kernels.hip" "$src/search_wave.hip" "$src/slots.hip" "$src/index.hip" "$src/capi.hip" "$src/bwt_file.cpp" "$src/bpi2.cpp" "$src/synth.cpp" "$src/service_slice.cpp" \
   -o "$here/lib/librsbwt.so" "$@"
+# index_rlebwt: the twin of the reference's src/util/index_rlebwt.cpp (writes "<bwt>.bpi2"); host code only
+"${CXX:-g++}" -O2 -std=c++17 -Wall -I"$here/../include" "$src/index_rlebwt_main.cpp" "$src/bpi2.cpp" "$src/bwt_file.cpp" \
+  -o "$here/lib/index_rlebwt"

@@ -322,6 +322,22 @@ class ShardSet:
         return out
 
 
+def write_bpi2(bwt_path, bpi2_path=None):
+    """src/util/index_rlebwt.cpp:19-22: writes the reference's FM-index file for a .bwt (default
+    "<bwt>.bpi2"), byte-identical to RLEBWT::serialiseFMIndex.  Host only."""
+    out = str(bpi2_path) if bpi2_path else str(bwt_path) + ".bpi2"
+    check(lib().rsbwt_bpi2_write(str(bwt_path).encode(), out.encode()))
+    return out
+
+
+def check_bpi2(pBWT, bpi2_path, max_samples=1 << 20):
+    """Validates a prebuilt .bpi2 against the resident index on the GPU: (buckets checked,
+    mismatches, first difference or '')."""
+    n, bad = C.c_uint64(), C.c_uint64()
+    check(lib().rsbwt_bpi2_check(pBWT.handle, str(bpi2_path).encode(), max_samples, C.byref(n), C.byref(bad)))
+    return n.value, bad.value, (lib().rsbwt_last_error().decode() if bad.value else "")
+
+
 def synth_popbwt(bwt_path, reads_path=None, *, seed, genome_len, haplotypes, snp_rate, read_len,
                  coverage, shard=-1, num_shards=1):
     """Deterministic synthetic population BWT written as an SGA .bwt (host only; csrc/synth.cpp)."""

@@ -12,6 +12,7 @@
 
 #include "../../include/rsbwt.h"
 #include "block_format.h"
+#include "bpi2.h"
 #include "bwt_file.h"
 #include "kernels.h"
 
@@ -377,6 +378,115 @@ int rsbwt_occ_at_batch(rsbwt_t *h, const char *b, const uint64_t *bc, size_t n, 
 int rsbwt_occ(rsbwt_t *h, char b, uint64_t index, uint64_t *occ) { return mirror_batch(h, 0, &b, &index, 1, occ); }
 int rsbwt_char(rsbwt_t *h, uint64_t index, char *c) { return mirror_batch(h, 1, nullptr, &index, 1, c); }
 int rsbwt_occ_at(rsbwt_t *h, char b, uint64_t bc, uint64_t *index) { return mirror_batch(h, 2, &b, &bc, 1, index); }
+
+// ---- .bpi2, the reference's FM-index file -----------------------------------------
+
+int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path) {
+    if (!bwt_path || !bpi2_path) return fail(RSBWT_EINVAL, "null argument");
+    bpi2_index ix;
+    std::string err;
+    int rc = bpi2_from_bwt(bwt_path, &ix, &err);
+    if (rc == RSBWT_OK) rc = bpi2_save(ix, bpi2_path, &err);
+    if (rc != RSBWT_OK) return fail(rc, "%s", err.c_str());
+    return RSBWT_OK;
+}
+
+int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
+                     uint64_t *mismatches) {
+    if (!h || !bpi2_path || !checked || !mismatches) return fail(RSBWT_EINVAL, "null argument");
+    *checked = *mismatches = 0;
+    bpi2_index f;
+    std::string err;
+    int rc = bpi2_load(bpi2_path, &f, &err);
+    if (rc != RSBWT_OK) return fail(rc, "%s", err.c_str());
+    uint64_t bad = 0;
+    std::string first;
+    auto note = [&](const std::string &m) {
+        if (bad++ == 0) first = m;
+    };
+    // shape: the levels RLEBWT::initialiseFMIndex plans for this many runs (rlebwt.cpp:46-78)
+    const bpi2_builder plan(h->num_runs);
+    if (f.levels.size() != plan.ix.levels.size()) {
+        fail(RSBWT_OK, "%s: %zu counter levels, %zu expected for %llu runs", bpi2_path, f.levels.size(),
+             plan.ix.levels.size(), (unsigned long long)h->num_runs);
+        *mismatches = 1;
+        return RSBWT_OK;
+    }
+    for (size_t k = 0; k < f.levels.size(); ++k) {
+        const bpi2_level &a = f.levels[k], &b = plan.ix.levels[k];
+        const uint64_t len = h->num_runs ? (h->num_runs - 1) / b.bucket + 1 : 0;
+        if (a.width != b.width || a.block != b.block || a.bucket != b.bucket || a.length != len)
+            note("level " + std::to_string(k) + ": width/block/bucket/length differ from the plan for this run count");
+    }
+    // C[]
+    static const char SYM[5] = {'$', 'A', 'C', 'G', 'T'};
+    for (int c = 0; c < 5; ++c)
+        if (f.pc[c] != h->view.C[c]) note(std::string("C[") + SYM[c] + "] differs");
+    if (bad) {
+        fail(RSBWT_OK, "%s: %s", bpi2_path, first.c_str());
+        *mismatches = bad;
+        return RSBWT_OK;
+    }
+    // counters: absolute counts at the start of sampled 64-run buckets = sum over the levels of
+    // the entries covering the bucket; they must equal Occ(c, position - 1) of the resident index
+    const bpi2_level &bot = f.levels.back();
+    const uint64_t nb = bot.length;
+    uint64_t S = max_samples ? std::min<uint64_t>(max_samples, nb) : nb;
+    std::vector<uint64_t> pos, want;
+    std::vector<char> sym;
+    std::vector<uint64_t> idx;
+    for (uint64_t s = 0; s < S; ++s) {
+        const uint64_t p = (S == nb) ? s : (s + 1 == S ? nb - 1 : (uint64_t)((unsigned __int128)s * nb / S));
+        uint64_t abs[5] = {0, 0, 0, 0, 0};
+        for (size_t k = 0; k < f.levels.size(); ++k) {
+            const bpi2_level &l = f.levels[k];
+            const uint64_t e = p * bot.bucket / l.bucket;
+            const uint64_t mask = l.width == 8 ? ~0ull : (1ull << (8 * l.width)) - 1ull;
+            uint64_t sum = 0;
+            for (int c = 0; c < 5; ++c) {
+                abs[c] += l.counts[e * 5 + c];
+                sum += l.counts[e * 5 + c];
+            }
+            if ((sum & mask) != l.sums[e]) note("level " + std::to_string(k) + " entry " + std::to_string(e) + ": sum field differs from its counts");
+        }
+        const uint64_t at = abs[0] + abs[1] + abs[2] + abs[3] + abs[4];
+        for (int c = 0; c < 5; ++c) {
+            if (at == 0) {
+                if (abs[c] != 0) note("bucket 0 does not start at zero");
+                continue;
+            }
+            sym.push_back(SYM[c]);
+            idx.push_back(at - 1);
+            want.push_back(abs[c]);
+            pos.push_back(p);
+        }
+    }
+    std::vector<uint64_t> got(idx.size());
+    if (!idx.empty()) {
+        rc = rsbwt_occ_batch(h, sym.data(), idx.data(), idx.size(), got.data());
+        if (rc != RSBWT_OK) return rc;
+        for (size_t i = 0; i < idx.size(); ++i)
+            if (got[i] != want[i] || idx[i] >= h->view.n)
+                note("bucket " + std::to_string(pos[i]) + ": count of '" + sym[i] + "' is " + std::to_string(want[i]) +
+                     ", the index has " + std::to_string(got[i]));
+    }
+    // vSum[t]: the bucket of the run that reaches symbol t * 65,536 (rlebwt.cpp:103-106)
+    auto before = [&](uint64_t p) {
+        uint64_t at = 0;
+        for (const bpi2_level &l : f.levels) at += l.sums[p * bot.bucket / l.bucket];
+        return at;
+    };
+    for (size_t t = 0; t < f.vsum.size(); ++t) {
+        const uint64_t b = f.vsum[t], mark = (uint64_t)t << 16;
+        if (b >= nb) { note("vSum entry beyond the last bucket"); continue; }
+        if (t == 0) { if (b != 0) note("vSum[0] is not 0"); continue; }
+        if (!(before(b) < mark) || (b + 1 < nb && before(b + 1) < mark)) note("vSum[" + std::to_string(t) + "] names the wrong bucket");
+    }
+    *checked = S;
+    *mismatches = bad;
+    if (bad) fail(RSBWT_OK, "%s: %s", bpi2_path, first.c_str());
+    return RSBWT_OK;
+}
 
 // ---- batched search ---------------------------------------------------------------------------
 

@@ -5,15 +5,16 @@
 // spends ~20 VALU instructions per lookup, most of them per-quad overhead replicated 16 times per
 // wave, and is VALU-issue bound.  Here
 //   * a wavefront carries 32 queries: lane i resolves Occ(b, lower-1) of query i, lane i+32
-//     Occ(b, upper); each lane does its own directory lookup;
-//   * blocks are still fetched the way the memory system likes them (tools/gather_bench.hip): in
-//     four rounds, DPP-quad q of the wave reads the 128-B block wanted by lane 16r+q as
-//     4 x 32 B, and parks it in LDS (128-B slots, 16-byte chunks XOR-swizzled by the lane);
+//     Occ(b, upper); each lane does its own slot arithmetic / directory lookup;
+//   * blocks are still fetched the way the memory system likes them (tools/gather_bench.hip): a
+//     full 128-B line per group of adjacent lanes, by LDS-DMA straight into the wave's LDS stage
+//     (glds_fetch below), each distinct block of a query once;
 //   * every lane then ranks ITS block out of LDS: the header names the quarter (24 runs) holding
-//     the position, the quarters before it are summed 4 bytes at a time (v_dot4_u32_u8 against a
-//     0/1 match mask), and only the one quarter is scanned run by run (SDWA, 5 VALU per run).
+//     the position, at most one other quarter is summed 4 bytes at a time (v_dot4_u32_u8 against
+//     a 0/1 match mask; a slot's header carries the half-way counts), and only the one quarter is
+//     scanned run by run (SDWA, 5 VALU per run).
 // Overhead is shared by 64 lookups instead of 16 and the scan is 24 bytes instead of 96 per lookup.
-// Requires the exact (s = 8) directory; other indexes use the octet kernel.
+// Requires slots or the exact (s = 8) directory; other indexes use the octet kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -23,10 +24,9 @@
 
 namespace rsb {
 
-// LDS stage: lane T's block lives at T * 128 B, its 16-byte chunk c stored at position
-// c ^ swz(T), swz(T) = (T ^ (T >> 3)) & 7 -- 16-byte reads of one chunk across a wave are then
-// bank-conflict free (8-byte ones 2-way), with no padding: 8 KB per wave, 32 KB per 4-wave
-// workgroup, so exactly 5 workgroups (20 waves) fit a CU's 160 KB.
+// LDS stage: 128 B per lane, 8 KB per wave, 32 KB per 4-wave workgroup, so exactly 5 workgroups
+// (20 waves) fit a CU's 160 KB.  Where a lane's row sits and how its 16-byte chunks are swizzled
+// follows from the fetch (glds_fetch).
 constexpr int SLOT_U4 = 8;
 constexpr int WG_WAVES = 4; // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
 
