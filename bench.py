@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one batch: Q ASCII 31-mers already in HBM are packed
 to 2 bits and searched (findInterval, src/bwt/query.cpp:24-41) in every shard this rank holds;
 with N > 1 ranks the per-shard (lower, upper) arrays are then gathered on rank 0 over RCCL
-(every query goes to every shard, results are only concatenated).
+(every query goes to every shard, results are only concatenated); the gather of batch i
+runs behind the search of batch i + 1 (two resident result buffers).
 
 N = 1 default workload = BASELINE.json configs[1]: one ~20 GB shard (2e10 run bytes from the
 direct run-stream synthesiser), 1e7 31-mers, half drawn from the index (all 30 LF steps), half
@@ -128,22 +129,25 @@ def main():
     wpq = (k + 31) // 32
     d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
     d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
-    d_lower = torch.empty((S, Q), dtype=torch.int64, device=dev)
-    d_upper = torch.empty((S, Q), dtype=torch.int64, device=dev)
     from readserver_amd import sharded
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty((2, S, Q), dtype=torch.int64, device=dev) for _ in range(world)]
+    # (lower, upper) of batch i land in one of two resident [2, S, Q] buffers; with N > 1 the gather
+    # of batch i to rank 0 (RCCL) runs behind the search of batch i + 1
+    gat = sharded.IntervalGatherer(S, Q, dev, depth=2)
+    d_lower, d_upper = gat.pair(0)[0], gat.pair(0)[1]
+    step_no = [0]
 
     def step():
+        i = step_no[0]
+        step_no[0] += 1
+        pair = gat.acquire(i)
         ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
         for s, g in enumerate(shards):
             ok(L.rsbwt_find_intervals_dev(g.handle, ptr(d_packed), ptr(d_valid), Q, k,
-                                          ptr(d_lower[s]), ptr(d_upper[s]), sp))
-        if world > 1:
-            sharded.gather_intervals(d_lower, d_upper, dst=0, out=gathered)
+                                          ptr(pair[0][s]), ptr(pair[1][s]), sp))
+        gat.submit(i)
 
     def barrier():
+        gat.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

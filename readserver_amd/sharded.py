@@ -52,3 +52,55 @@ def broadcast_queries(kmers, src=0, group=None):
     if dist.get_world_size(group) > 1:
         dist.broadcast(kmers, src=src, group=group)
     return kmers
+
+
+class IntervalGatherer:
+    """Gather of per-shard intervals to rank `dst`, pipelined behind the next batch's search.
+
+    The searches of batch i write (lower, upper) straight into `pair(i)` = one of `depth` resident
+    [2, S_local, Q] buffers; `submit(i)` starts the gather of that buffer without blocking (RCCL
+    runs it on its own stream once the producing kernels are done), so batch i + 1 is searched
+    while batch i travels.  A buffer is reused only after its gather has completed (`submit`
+    waits for the one issued `depth` batches earlier); `drain()` completes everything outstanding.
+    On rank `dst`, `result(i)` is the list of `world` tensors [2, S_local, Q] of batch i.
+    """
+
+    def __init__(self, s_local, q, device, depth=2, dst=0, group=None, dtype=torch.int64):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dst, self.group, self.depth = dst, group, depth
+        self._pairs = [torch.empty((2, s_local, q), dtype=dtype, device=device) for _ in range(depth)]
+        self._out = None
+        if self.world > 1 and self.rank == dst:
+            self._out = [[torch.empty((2, s_local, q), dtype=dtype, device=device) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self._work = [None] * depth
+
+    def pair(self, i):
+        return self._pairs[i % self.depth]
+
+    def acquire(self, i):
+        """Call before writing batch i into pair(i): waits until that buffer's previous gather is done."""
+        w = self._work[i % self.depth]
+        if w is not None:
+            w.wait()
+            self._work[i % self.depth] = None
+        return self._pairs[i % self.depth]
+
+    def submit(self, i):
+        if self.world == 1:
+            return
+        j = i % self.depth
+        self._work[j] = dist.gather(self._pairs[j], self._out[j] if self.rank == self.dst else None,
+                                    dst=self.dst, group=self.group, async_op=True)
+
+    def drain(self):
+        for j, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[j] = None
+
+    def result(self, i):
+        if self.world == 1:
+            return [self._pairs[i % self.depth]]
+        return self._out[i % self.depth] if self.rank == self.dst else None

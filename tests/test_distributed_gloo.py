@@ -88,3 +88,61 @@ def test_world2_gather_and_reduce(rsb, tmp_path):
         p.join(120)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get() == "ok"
+
+
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from readserver_amd import sharded
+        S, Q, steps = 2, 1000, 7
+        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2)
+        seen = {}
+        for i in range(steps):
+            buf = g.acquire(i)  # waits for batch i - 2's gather before the buffer is rewritten
+            buf[0] = 1000 * i + 10 * rank + torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
+            buf[1] = buf[0] + 7
+            g.submit(i)
+            if rank == 0 and i >= 1:
+                # batch i - 1 is complete once its handle has been waited for; acquire(i + 1) does
+                # that for its buffer, so read it only after an explicit wait here
+                g._work[(i - 1) % 2].wait()
+                seen[i - 1] = [t.clone() for t in g.result(i - 1)]
+        g.drain()
+        if rank == 0:
+            seen[steps - 1] = [t.clone() for t in g.result(steps - 1)]
+            base = torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
+            for i in range(steps):
+                for r in range(world):
+                    assert torch.equal(seen[i][r][0], 1000 * i + 10 * r + base), (i, r)
+                    assert torch.equal(seen[i][r][1], 1000 * i + 10 * r + base + 7), (i, r)
+            q.put("ok")
+        else:
+            assert g.result(0) is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_pipelined_interval_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + 3) % 2000
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"
+
+
+def test_single_process_gatherer_is_a_no_op():
+    from readserver_amd import sharded
+    g = sharded.IntervalGatherer(1, 10, torch.device("cpu"))
+    b = g.acquire(0)
+    b.fill_(3)
+    g.submit(0)
+    g.drain()
+    assert g.result(0)[0] is g.pair(0) and int(g.pair(0).sum()) == 60
