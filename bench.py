@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
     ap.add_argument("--slots", choices=["auto", "on", "off"], default=None,
                     help="single-request search layout (default: auto at 1 shard per GPU, else off)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="HIP streams the batches alternate on.  2: packing, start records and the head of "
+                         "batch i + 1 overlap the tail of batch i (+12 %% searches/s), but two search kernels "
+                         "then share the GPU and their event-timed durations no longer price one launch, so "
+                         "the roofline line is quoted at 1")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -127,11 +132,17 @@ def main():
         del mine, idx
 
     wpq = (k + 31) // 32
-    d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
-    d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     from readserver_amd import sharded
-    # (lower, upper) of batch i land in one of two resident [2, S, Q] buffers; with N > 1 the gather
-    # of batch i to rank 0 (RCCL) runs behind the search of batch i + 1
+    # Batches can alternate between two HIP streams (--streams 2), each with its own packed-query
+    # and result buffers: packing and start records of batch i + 1 then run beside the search of
+    # batch i.  With N > 1 the gather of batch i to rank 0 (RCCL) travels behind the search of
+    # batch i + 1 either way.
+    nst = a.streams
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nst)] if nst > 1 else [stream]
+    for st in streams:
+        st.wait_stream(stream)
+    d_packed = [torch.empty((Q, wpq), dtype=torch.int64, device=dev) for _ in range(nst)]
+    d_valid = [torch.empty(Q, dtype=torch.uint8, device=dev) for _ in range(nst)]
     gat = sharded.IntervalGatherer(S, Q, dev, depth=2)
     d_lower, d_upper = gat.pair(0)[0], gat.pair(0)[1]
     step_no = [0]
@@ -139,12 +150,15 @@ def main():
     def step():
         i = step_no[0]
         step_no[0] += 1
-        pair = gat.acquire(i)
-        ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
-        for s, g in enumerate(shards):
-            ok(L.rsbwt_find_intervals_dev(g.handle, ptr(d_packed), ptr(d_valid), Q, k,
-                                          ptr(pair[0][s]), ptr(pair[1][s]), sp))
-        gat.submit(i)
+        j = i % nst
+        with torch.cuda.stream(streams[j]):
+            spj = C.c_void_p(streams[j].cuda_stream)
+            pair = gat.acquire(i)
+            ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed[j]), ptr(d_valid[j]), local, spj))
+            for s, g in enumerate(shards):
+                ok(L.rsbwt_find_intervals_dev(g.handle, ptr(d_packed[j]), ptr(d_valid[j]), Q, k,
+                                              ptr(pair[0][s]), ptr(pair[1][s]), spj))
+            gat.submit(i)
 
     def barrier():
         gat.drain()
