@@ -132,6 +132,20 @@ int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stri
 int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                              uint64_t *lower, uint64_t *upper);
 
+/* The same search with the output SURVEY 8 f3 defines: only the variants that occur, as a list
+ * sorted by (query, pos, base).  The dense [Q][3k+1] matrices above are mostly empty intervals
+ * (1.5 KB per 31-mer over PCIe); the list is compacted on the device.  `hits` receives at most
+ * `cap` records, *nhits the number found; RSBWT_ERANGE (nothing written) when cap is too small. */
+typedef struct rsbwt_hit_1mm {
+    uint64_t lower, upper; /* lower <= upper */
+    uint32_t query;        /* index of the k-mer in the batch */
+    int16_t pos;           /* -1: the k-mer itself, else the substituted position (0 = leftmost) */
+    char base;             /* the base put there ('\0' for the k-mer itself) */
+    char reserved;
+} rsbwt_hit_1mm;
+int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                   rsbwt_hit_1mm *hits, size_t cap, size_t *nhits);
+
 /* Batched read extraction: replaces  extractPrefix(pBWT, row) + extractPostfix(pBWT, row)
  * (src/bwt/query.cpp:43-85; joined as query() does, :94-96) for n SA rows.  Row i's read is written
  * to out + i*stride (no NUL), its length to len[i] and the length of its prefix part to

@@ -17,6 +17,7 @@ from .bwt import (  # noqa: F401
     find_intervals,
     find_intervals_1mm,
     hits_1mm,
+    hits_1mm_batch,
     findInterval,
     query,
     query_exactmatch,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
     "rsbwt_find_intervals_1mm": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
+    "rsbwt_hits_1mm": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_extract": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp]),
     "rsbwt_pack_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "rsbwt_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),

@@ -200,6 +200,27 @@ def find_intervals_1mm(pBWT, kmers):
     return lower, upper
 
 
+HIT_1MM = np.dtype([("lower", "<u8"), ("upper", "<u8"), ("query", "<u4"), ("pos", "<i2"), ("base", "S1"),
+                    ("reserved", "u1")])  # = rsbwt_hit_1mm
+
+
+def hits_1mm_batch(pBWT, kmers, cap=None):
+    """1-mismatch search with SURVEY 8 f3's output: a structured array (HIT_1MM) of the variants
+    that occur, sorted by (query, pos, base); pos = -1 / base = b'' for the k-mer itself."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    cap = int(cap) if cap is not None else max(1024, 4 * Q)
+    while True:
+        out = np.zeros(cap, HIT_1MM)
+        n = C.c_size_t()
+        rc = lib().rsbwt_hits_1mm(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(out), cap, C.byref(n))
+        if rc == -7 and n.value > cap:  # RSBWT_ERANGE: the list is longer than the buffer
+            cap = n.value
+            continue
+        check(rc)
+        return out[:n.value]
+
+
 def hits_1mm(kmer, lower_row, upper_row):
     """The sorted list of (pos, base, lower, upper) of the non-empty variants of one k-mer
     (pos = -1 for the exact hit), from one row of find_intervals_1mm."""

@@ -622,6 +622,68 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
     return RSBWT_OK;
 }
 
+int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
+                   size_t cap, size_t *nhits) {
+    if (!h || !nhits) return fail(RSBWT_EINVAL, "null argument");
+    *nhits = 0;
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers || (!hits && cap)) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0 || stride < k) return fail(RSBWT_EINVAL, "bad k/stride");
+    if (k > 32767u) return fail(RSBWT_ERANGE, "k %u: positions are reported as int16", k);
+    if (Q > 0xFFFFFFFFull) return fail(RSBWT_ERANGE, "at most 2^32 - 1 k-mers per call");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const uint32_t wpq = words_per_kmer(k);
+    const size_t V = 3 * (size_t)k + 1;
+    const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    std::vector<uint32_t> counts;
+    std::vector<uint64_t> offsets;
+    size_t total = 0;
+    bool overflow = false;
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+        const size_t m = std::min(SLICE, Q - q0), mv = m * V;
+        const size_t ascii_bytes = (m - 1) * stride + k;
+        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+        const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
+        const size_t a_cnt = (m * 4 + 15) & ~(size_t)15, a_off = m * 8, a_hits = mv * sizeof(rsbwt_hit_1mm);
+        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits)) != RSBWT_OK) return rc;
+        uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+        uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
+        uint8_t *d_cnt = d_up + mv * 8, *d_off = d_cnt + a_cnt, *d_hits = d_off + a_off;
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
+        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+        rc = search_dev(h, d_vpk, d_vok, mv, k, d_lo, d_up, false, h->stream);
+        if (rc) return rc;
+        e = launch_hits1mm_count(d_lo, d_up, m, (uint32_t)V, d_cnt, h->stream);
+        if (e != hipSuccess) return fail_hip(e, "hit count kernel launch");
+        counts.resize(m);
+        offsets.resize(m);
+        HIP_OK(hipMemcpyAsync(counts.data(), d_cnt, m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        uint64_t run = 0;
+        for (size_t i = 0; i < m; ++i) {
+            offsets[i] = run;
+            run += counts[i];
+        }
+        if (!overflow && total + run <= cap && run) {
+            HIP_OK(hipMemcpyAsync(d_off, offsets.data(), m * 8, hipMemcpyHostToDevice, h->stream));
+            e = launch_hits1mm_write(d_lo, d_up, d_pk, m, (uint32_t)V, k, d_off, (uint32_t)q0, d_hits, h->stream);
+            if (e != hipSuccess) return fail_hip(e, "hit write kernel launch");
+            HIP_OK(hipMemcpyAsync(hits + total, d_hits, run * sizeof(rsbwt_hit_1mm), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+        } else if (total + run > cap) {
+            overflow = true;  // keep counting so that the caller learns the size it needs
+        }
+        total += run;
+    }
+    *nhits = total;
+    if (overflow) return fail(RSBWT_ERANGE, "%zu hits, room for %zu", total, cap);
+    return RSBWT_OK;
+}
+
 // ---- read extraction --------------------------------------------------------------------------
 
 int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride, uint32_t *len,

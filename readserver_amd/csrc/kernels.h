@@ -35,6 +35,10 @@ hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n
                              hipStream_t stream);
 hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
                                void *d_out, hipStream_t stream);
+hipError_t launch_hits1mm_count(const void *d_lower, const void *d_upper, size_t m, uint32_t V, void *d_counts,
+                                hipStream_t stream);
+hipError_t launch_hits1mm_write(const void *d_lower, const void *d_upper, const void *d_packed, size_t m, uint32_t V,
+                                uint32_t k, const void *d_offsets, uint32_t query0, void *d_hits, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (4 x stride u32) and the two walk kernels

@@ -116,6 +116,14 @@ def test_gpu_one_mismatch_equals_composition_of_exact_searches(rsb, oracle, tmp_
         assert hits == sorted(hits) and all(h[3] >= h[2] for h in hits)
         planted = sum(1 for qi in range(len(kmers) - 1) if len(rsb.hits_1mm(kmers[qi], lo[qi], up[qi])) > 0)
         assert planted >= 290 or k < 5
+        # the compacted list (SURVEY 8 f3's output) = the non-empty cells of the matrices, in order
+        hl = rsb.hits_1mm_batch(g, kmers, cap=16)  # too small a buffer: grown from the count returned
+        want = []
+        for qi, w in enumerate(kmers):
+            want += [(qi,) + h for h in rsb.hits_1mm(w, lo[qi], up[qi])]
+        got = [(int(r["query"]), int(r["pos"]), r["base"].decode(), int(r["lower"]), int(r["upper"])) for r in hl]
+        assert got == want
+        assert len(rsb.hits_1mm_batch(g, ["N" * k])) == 0
 
 
 def test_gpu_extract_vs_oracle_and_limits(rsb, oracle):

@@ -57,6 +57,9 @@ Q1 = 50000
 dt = timed(lambda: rsb.find_intervals_1mm(g, km[:Q1]))
 out["one_mismatch_kmers_per_s"] = Q1 / dt
 out["one_mismatch_variant_searches_per_s"] = Q1 * (3 * k + 1) / dt
+dt = timed(lambda: rsb.hits_1mm_batch(g, km[:Q1], cap=40 * Q1))
+out["one_mismatch_hit_list_kmers_per_s"] = Q1 / dt
+out["one_mismatch_hits"] = int(len(rsb.hits_1mm_batch(g, km[:Q1], cap=40 * Q1)))
 rows = rng.integers(0, g.getBWLen(), 100000).astype(np.uint64)
 dt = timed(lambda: rsb.extract_reads(g, rows, stride=256))
 out["extract_reads_per_s"] = rows.size / dt
