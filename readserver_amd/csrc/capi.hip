@@ -502,7 +502,8 @@ int rsbwt_pack_kmers_dev(const void *d_kmers, size_t Q, uint32_t k, size_t strid
 }
 
 static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
-                      void *d_lower, void *d_upper, bool counts_only, hipStream_t stream) {
+                      void *d_lower, void *d_upper, bool counts_only, hipStream_t stream,
+                      const wave_search_extra *extra = nullptr) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
     if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
     int rc = use_device(h->device);
@@ -516,7 +517,7 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
             HIP_OK(hipMemsetAsync(work, 0, 16 * sizeof(unsigned long long), stream));
         }
         const int slot = (int)(h->launches % rsbwt::RING);
-        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream, h->ev_start[slot], h->ev_stop[slot]);
+        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream, h->ev_start[slot], h->ev_stop[slot], extra);
         if (e != hipSuccess) return fail_hip(e, "search kernel launch");
         h->launches++;
     }
@@ -589,6 +590,36 @@ int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stri
 
 // ---- 1-mismatch search ------------------------------------------------------------------------
 
+// The [m][3k+1] variant intervals of m packed k-mers (variants_kernel's order) into d_lo/d_up.
+// With the wave kernel and a k-mer table that does not cover the whole k-mer, the k-mers
+// themselves are searched first with a trace, and every variant whose substituted position lies
+// left of the table's reach resumes from its k-mer's interval at that position instead of being
+// searched from scratch (it shares that whole suffix).  `scratch` holds the trace and the k-mers'
+// own results: variants_scratch_bytes().
+static size_t variants_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
+    if (!search_uses_wave_kernel(h->view, &h->slots)) return 0;
+    const uint32_t tn = wave_trace_entries(h->view, k);
+    return tn ? m * (size_t)tn * 16 + 2 * m * 8 : 0;
+}
+
+static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_t m, uint32_t k, const void *d_vpk,
+                           const void *d_vok, void *d_lo, void *d_up, uint8_t *scratch, hipStream_t stream) {
+    const size_t V = 3 * (size_t)k + 1;
+    const uint32_t tn = search_uses_wave_kernel(h->view, &h->slots) ? wave_trace_entries(h->view, k) : 0u;
+    if (tn == 0) return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream);
+    uint8_t *d_trace = scratch, *d_olo = d_trace + m * (size_t)tn * 16, *d_oup = d_olo + m * 8;
+    wave_search_extra traced;
+    traced.d_trace_out = d_trace;
+    traced.trace_n = tn;
+    int rc = search_dev(h, d_pk, d_ok, m, k, d_olo, d_oup, false, stream, &traced);
+    if (rc) return rc;
+    wave_search_extra resumed;
+    resumed.d_trace_in = d_trace;
+    resumed.trace_n = tn;
+    resumed.variants = (uint32_t)V;
+    return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream, &resumed);
+}
+
 int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                              uint64_t *lower, uint64_t *upper) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
@@ -606,14 +637,16 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
         const size_t ascii_bytes = (m - 1) * stride + k;
         const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
         const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
-        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8)) != RSBWT_OK) return rc;
+        const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
+        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_scr)) != RSBWT_OK) return rc;
         uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
         uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
+        uint8_t *d_scr = d_up + mv * 8;
         HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
         hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
         if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
         if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-        rc = search_dev(h, d_vpk, d_vok, mv, k, d_lo, d_up, false, h->stream);
+        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, h->stream);
         if (rc) return rc;
         HIP_OK(hipMemcpyAsync(lower + q0 * V, d_lo, mv * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_OK(hipMemcpyAsync(upper + q0 * V, d_up, mv * 8, hipMemcpyDeviceToHost, h->stream));
@@ -647,15 +680,16 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
         const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
         const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
         const size_t a_cnt = (m * 4 + 15) & ~(size_t)15, a_off = m * 8, a_hits = mv * sizeof(rsbwt_hit_1mm);
-        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits)) != RSBWT_OK) return rc;
+        const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
+        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits + a_scr)) != RSBWT_OK) return rc;
         uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
         uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
-        uint8_t *d_cnt = d_up + mv * 8, *d_off = d_cnt + a_cnt, *d_hits = d_off + a_off;
+        uint8_t *d_cnt = d_up + mv * 8, *d_off = d_cnt + a_cnt, *d_hits = d_off + a_off, *d_scr = d_hits + a_hits;
         HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
         hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
         if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
         if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-        rc = search_dev(h, d_vpk, d_vok, mv, k, d_lo, d_up, false, h->stream);
+        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, h->stream);
         if (rc) return rc;
         e = launch_hits1mm_count(d_lo, d_up, m, (uint32_t)V, d_cnt, h->stream);
         if (e != hipSuccess) return fail_hip(e, "hit count kernel launch");

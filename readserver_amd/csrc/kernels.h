@@ -17,12 +17,26 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
 hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
                          size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream,
-                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-// search_wave.hip: the wave-cooperative form of the same search (needs dir_shift == 8)
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                         const struct wave_search_extra *extra = nullptr);  // extra: wave kernel only
+// search_wave.hip: the wave-cooperative form of the same search (needs slots or dir_shift == 8)
+struct wave_search_extra {
+    // 1-mismatch search.  A traced search records, per k-mer, the interval it holds
+    // when about to take each of its first trace_n symbols ([Q][trace_n] x {lower, upper}); the
+    // search of the k-mers' variants (`variants` per k-mer, variants_kernel's order) then starts
+    // every variant whose substituted position is < trace_n from that interval.
+    void *d_trace_out = nullptr;
+    const void *d_trace_in = nullptr;
+    uint32_t trace_n = 0, variants = 0;
+};
 hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
                               const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
                               bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                              const wave_search_extra *extra = nullptr);
+uint32_t wave_trace_entries(const rsbwt_view &ix, uint32_t k);
+// does launch_search run the wave kernel on this index?
+bool search_uses_wave_kernel(const rsbwt_view &ix, const slot_view *sv);
 // slots.hip
 bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp);
 hipError_t build_slots(const rsbwt_view &ix, uint64_t num_runs, uint32_t want_S, hipStream_t stream,

@@ -653,15 +653,21 @@ static bool prefer_wave_kernel() {
     return v != 0;
 }
 
+bool search_uses_wave_kernel(const rsbwt_view &ix, const slot_view *sv) {
+    const bool have_slots = sv && sv->slots;
+    return (have_slots || ix.dir_shift == 8) && prefer_wave_kernel();
+}
+
 hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
                          size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0,
-                         hipEvent_t ev1) {
+                         hipEvent_t ev1, const wave_search_extra *extra) {
     if (Q == 0) return hipSuccess;
     const bool have_slots = sv && sv->slots;
     if ((have_slots || ix.dir_shift == 8) && prefer_wave_kernel())
         return launch_search_wave(ix, have_slots ? sv : nullptr, d_packed, d_valid, Q, k, d_lower, d_upper,
-                                  counts_only, d_work, num_cus, stream, ev0, ev1);
+                                  counts_only, d_work, num_cus, stream, ev0, ev1, extra);
+    if (extra) return hipErrorInvalidValue;  // traced / resumed searches exist in the wave kernel only
     if (ev0) (void)hipEventRecord(ev0, stream);
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.

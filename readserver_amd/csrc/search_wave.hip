@@ -84,6 +84,32 @@ __device__ __forceinline__ void glds_wait() {
 // table entry) in front of every pass.  Record = { lower | flags, upper }.
 constexpr uint64_t INIT_INVALID = 1ull << 63;   // symbol outside ACGT: result (1, 0)
 constexpr uint64_t INIT_FALLBACK = 1ull << 62;  // not from the k-mer table: continue at symbol k-2
+constexpr uint64_t INIT_EXPLICIT = 1ull << 61;  // continue at the symbol named in bits 40..55 (1-mismatch variants)
+
+template <bool KTAB>
+__device__ __forceinline__ ulonglong2 start_record(const rsbwt_view &ix, const uint64_t *pq, uint32_t k) {
+    ulonglong2 rec;
+    const uint64_t last = pq[(k - 1u) >> 5];
+    if (KTAB) {
+        const uint32_t T = ix.ktab_depth;
+        const uint32_t off = 2u * (k - T);
+        const uint32_t w0 = off >> 6, sh = off & 63u;
+        uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
+        if (sh + 2u * T > 64u) bits |= last << (64u - sh);
+        const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
+        const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
+        if (width != RSBWT_KTAB_WIDE) {
+            rec.x = e & RSBWT_COUNT_MASK;
+            rec.y = rec.x + width - 1ull;
+            return rec;
+        }
+    }
+    // initInterval, query.cpp:18-21
+    const uint32_t b = (uint32_t)((last >> (2u * ((k - 1u) & 31u))) & 3u) + 1u;
+    rec.x = ix.C[b] | INIT_FALLBACK;
+    rec.y = ix.C[b] + ix.total[b] - 1ull;
+    return rec;
+}
 
 template <bool KTAB>
 __global__ void __launch_bounds__(256)
@@ -92,35 +118,45 @@ search_init_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
                    ulonglong2 *__restrict__ init) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
-    const uint64_t *pq = packed + q * wpq;
     ulonglong2 rec;
     if (valid[q] == 0) {
         rec.x = INIT_INVALID;
         rec.y = 0;
     } else {
-        const uint64_t last = pq[(k - 1u) >> 5];
-        bool from_table = false;
-        if (KTAB) {
-            const uint32_t T = ix.ktab_depth;
-            const uint32_t off = 2u * (k - T);
-            const uint32_t w0 = off >> 6, sh = off & 63u;
-            uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
-            if (sh + 2u * T > 64u) bits |= last << (64u - sh);
-            const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
-            const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
-            if (width != RSBWT_KTAB_WIDE) {
-                from_table = true;
-                rec.x = e & RSBWT_COUNT_MASK;
-                rec.y = rec.x + width - 1ull;
-            }
-        }
-        if (!from_table) {  // initInterval, query.cpp:18-21
-            const uint32_t b = (uint32_t)((last >> (2u * ((k - 1u) & 31u))) & 3u) + 1u;
-            rec.x = ix.C[b] | INIT_FALLBACK;
-            rec.y = ix.C[b] + ix.total[b] - 1ull;
-        }
+        rec = start_record<KTAB>(ix, packed + q * wpq, k);
     }
     init[q] = rec;
+}
+
+// Start records of the 3k+1 variants of m k-mers (1-mismatch search, variants_kernel's order).  A
+// variant whose substituted position is left of the k-mer table's reach shares its whole suffix
+// with the k-mer itself: it starts from the interval the k-mer's own (traced) search had when it
+// was about to take that position -- trace[q][pos] -- and takes the substituted symbol first.
+template <bool KTAB>
+__global__ void __launch_bounds__(256)
+search_init_1mm_kernel(const rsbwt_view ix, const uint64_t *__restrict__ vpacked,
+                       const uint8_t *__restrict__ vvalid, size_t mv, uint32_t k, uint32_t wpq, uint32_t V,
+                       const ulonglong2 *__restrict__ trace, uint32_t trace_n,
+                       ulonglong2 *__restrict__ init) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mv) return;
+    ulonglong2 rec;
+    if (vvalid[i] == 0) {
+        rec.x = INIT_INVALID;
+        rec.y = 0;
+    } else {
+        const size_t q = i / V;
+        const uint32_t v = (uint32_t)(i - q * V);
+        const uint32_t pos = v ? (v - 1u) / 3u : ~0u;
+        if (pos < trace_n) {
+            const ulonglong2 t = trace[q * trace_n + pos];
+            rec.x = (t.x & RSBWT_COUNT_MASK) | ((uint64_t)pos << RSBWT_COUNT_BITS) | INIT_EXPLICIT;
+            rec.y = t.y;
+        } else {
+            rec = start_record<KTAB>(ix, vpacked + i * wpq, k);
+        }
+    }
+    init[i] = rec;
 }
 
 // LONGK: k > 32, i.e. a query spans several packed words.  A template parameter because with the
@@ -132,7 +168,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                    const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
                    size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
-                   unsigned long long *__restrict__ work) {
+                   unsigned long long *__restrict__ work,
+                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
     // ds_bpermute reads (the LDS crossbar idles while the VALU is the busier pipe; selects out
@@ -160,7 +197,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
     // one global counter (one atomic per chunk) and gives the next one to whichever lane pair
     // has finished (ballot + popcount, no further atomics).  A static q += stride schedule makes
     // every wave as slow as its unluckiest pair: 36 % idle lane-passes on the bench batch.
-    constexpr uint32_t QCHUNK = 1024;
+    const uint32_t QCHUNK = qchunk;  // chosen by the launcher: 1024 for big batches, less so that small ones still spread over the GPU
     uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
     bool drained = false;                  // the global counter ran past Q
     size_t q = 0;          // the query this lane pair is stepping
@@ -201,7 +238,17 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             if (nrec.x & INIT_INVALID) {
                 lo = 1;
                 hi = 0;
+                j = -1;
                 done = true;
+            } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search
+                lo = nrec.x & RSBWT_COUNT_MASK;
+                hi = nrec.y;
+                j = (int)((nrec.x >> RSBWT_COUNT_BITS) & 0xFFFFull);
+                word = nword;
+                done = lo > hi;  // the shared suffix was already absent (query.cpp:35-37)
+                if (LONGK) {
+                    if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                }
             } else {
                 const bool fallback = !KTAB || (nrec.x & INIT_FALLBACK) != 0ull;
                 lo = nrec.x & RSBWT_COUNT_MASK;
@@ -259,6 +306,8 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         uint64_t p = 0, pb = 0;
         bool skip = false;
         if (stepping) {
+            // traced search (1-mismatch): the interval this query has when about to take symbol j
+            if (trace && side == 0u && (uint32_t)j < trace_n) trace[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
             if (LONGK) {
                 if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
             }
@@ -445,6 +494,11 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
             has_n = true;
         }
         if (alive && done) {
+            if (trace && side == 0u) {
+                // the positions it never reached: a search resumed there ends where this one did
+                for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
+                    trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
+            }
             if (side == 0u) {
                 if (COUNTS_ONLY) {
                     out_lower[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
@@ -475,12 +529,17 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
 template <bool CW, bool CO, bool KT>
 static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
                       const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
-                      uint64_t *lo, uint64_t *up, unsigned long long *work) {
+                      uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n) {
     unsigned long long *ctr = (unsigned long long *)(init + Q);  // zeroed counter behind the records
     slot_view none = {};
+    // queries per draw from the pool: at least ~4 draws per wave, so that a batch of a few
+    // thousand queries (a service micro-batch, the k-mers of a 1-mismatch slice) still occupies
+    // every wave launched instead of the first few
+    uint32_t qchunk = 1024;
+    while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q) qchunk >>= 1;
 #define RSB_LAUNCH_W(SL, LK)                                                                              \
     hipLaunchKernelGGL((search_wave_kernel<CW, CO, KT, SL, LK>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, \
-                       ix, (SL ? *sv : none), pk, init, ctr, Q, k, wpq, lo, up, work)
+                       ix, (SL ? *sv : none), pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk)
     if (sv) {
         if (wpq > 1) RSB_LAUNCH_W(true, true);
         else RSB_LAUNCH_W(true, false);
@@ -494,16 +553,18 @@ static void launch_w2(const slot_view *sv, int grid, hipStream_t stream, const r
 template <bool CW, bool CO>
 static void launch_w(bool ktab, const slot_view *sv, int grid, hipStream_t stream, const rsbwt_view &ix,
                      const uint64_t *pk, const ulonglong2 *init, size_t Q, uint32_t k, uint32_t wpq,
-                     uint64_t *lo, uint64_t *up, unsigned long long *work) {
-    if (ktab) launch_w2<CW, CO, true>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work);
-    else launch_w2<CW, CO, false>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work);
+                     uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n) {
+    if (ktab) launch_w2<CW, CO, true>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work, trace, trace_n);
+    else launch_w2<CW, CO, false>(sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, work, trace, trace_n);
 }
 
 hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
                               const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
                               bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream,
-                              hipEvent_t ev0, hipEvent_t ev1) {
+                              hipEvent_t ev0, hipEvent_t ev1, const wave_search_extra *extra) {
     if (Q == 0) return hipSuccess;
+    ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
+    const uint32_t trace_n = extra ? extra->trace_n : 0u;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     // 32 queries per wave, 4 waves per workgroup
     const size_t per_wg = 32u * WG_WAVES;
@@ -529,20 +590,34 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
     e = hipMemsetAsync(init + Q, 0, sizeof(ulonglong2), stream);  // the query counter
     if (e != hipSuccess) return e;
     const int ig = (int)((Q + 255) / 256);
-    if (ktab) hipLaunchKernelGGL(search_init_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
+    if (extra && extra->d_trace_in) {
+        const ulonglong2 *tin = (const ulonglong2 *)extra->d_trace_in;
+        if (ktab) hipLaunchKernelGGL(search_init_1mm_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, extra->variants, tin, trace_n, init);
+        else hipLaunchKernelGGL(search_init_1mm_kernel<false>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, extra->variants, tin, trace_n, init);
+    } else if (ktab) hipLaunchKernelGGL(search_init_kernel<true>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
     else hipLaunchKernelGGL(search_init_kernel<false>, dim3(ig), dim3(256), 0, stream, ix, pk, vd, Q, k, wpq, init);
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_work) {
-        if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
-        else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<true, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        else launch_w<true, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work, trace, trace_n);
     } else {
-        if (counts_only) launch_w<false, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
-        else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work);
+        if (counts_only) launch_w<false, true>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        else launch_w<false, false>(ktab, sv, grid, stream, ix, pk, init, Q, k, wpq, lo, up, d_work, trace, trace_n);
     }
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);
     const hipError_t e2 = hipFreeAsync(init, stream);
     return e != hipSuccess ? e : e2;
+}
+
+
+
+// Entries per k-mer of a traced search = the positions left of the k-mer table's reach (0: the
+// 1-mismatch search has nothing to share: no table, or k within it)
+uint32_t wave_trace_entries(const rsbwt_view &ix, uint32_t k) {
+    const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
+    if (!ktab || k <= ix.ktab_depth || k - ix.ktab_depth > 0xFFFFu) return 0;
+    return k - ix.ktab_depth;
 }
 
 }  // namespace rsb

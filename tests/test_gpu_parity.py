@@ -126,6 +126,42 @@ def test_gpu_one_mismatch_equals_composition_of_exact_searches(rsb, oracle, tmp_
         assert len(rsb.hits_1mm_batch(g, ["N" * k])) == 0
 
 
+@pytest.mark.parametrize("T,slots,k", [(2, True, 31), (6, False, 31), (12, True, 31), (12, False, 40), (9, True, 64),
+                                       (8, True, 9), (None, True, 20)])
+def test_gpu_one_mismatch_resumed_from_the_trace_equals_searching_every_variant(rsb, tmp_path, T, slots, k):
+    """Variants left of the k-mer table's reach resume from their k-mer's traced search; the result
+    must be what the exact search gives for every variant spelled out (itself held to the oracle
+    elsewhere), whatever the table depth (T = 2: wide entries, fallback starts), the layout, and
+    with k-mers that span several packed words."""
+    bwt, rd = str(tmp_path / "s.bwt"), str(tmp_path / "s.reads")
+    rsb.synth_popbwt(bwt, rd, seed=21, genome_len=60000, haplotypes=4, snp_rate=0.005, read_len=80, coverage=4.0)
+    reads = open(rd).read().split()
+    rng = np.random.default_rng(100 * k + (T or 0))
+    kmers = []
+    for i in range(700):
+        r = reads[rng.integers(len(reads))]
+        s0 = rng.integers(0, len(r) - k + 1)
+        w = list(r[s0:s0 + k])
+        for _ in range(i % 3):  # 0, 1 or 2 planted substitutions
+            p = rng.integers(k)
+            w[p] = "ACGT"[("ACGT".index(w[p]) + 1 + rng.integers(3)) % 4]
+        kmers.append("".join(w))
+    kmers += ["A" * k, "T" * k, "ACGT" * (k // 4) + "A" * (k % 4), "N" + "A" * (k - 1)]
+    with rsb.GpuBWT(bwt, ktab_depth=T, slots=slots, dir_shift=8) as g:
+        lo, up = rsb.find_intervals_1mm(g, kmers)
+        spelled = []
+        for w in kmers:
+            spelled.append(w)
+            for pos in range(k):
+                for alt in [c for c in "ACGT" if c != w[pos]][:3]:
+                    spelled.append(w[:pos] + alt + w[pos + 1:])
+        elo, eup = rsb.find_intervals(g, spelled)
+        elo, eup = elo.reshape(len(kmers), -1), eup.reshape(len(kmers), -1)
+        elo[-1], eup[-1] = 1, 0  # a k-mer with a foreign symbol is invalid as a whole
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+        assert (up[:-1] >= lo[:-1]).sum() > len(kmers) // 2
+
+
 def test_gpu_extract_vs_oracle_and_limits(rsb, oracle):
     import ctypes as C
     L = rsb.lib()
