@@ -61,6 +61,7 @@ struct rsbwt {
     slot_view slots = {};
     uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
     hipStream_t stream = nullptr;  // host-buffer calls run here
+    hipStream_t stream2 = nullptr; // ... and here: consecutive slices of a big host batch alternate
     static constexpr int RING = 64;  // HIP-event pairs of the most recent search launches
     hipEvent_t ev_start[RING] = {}, ev_stop[RING] = {};
     uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
@@ -313,6 +314,7 @@ void rsbwt_close(rsbwt_t *h) {
         if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
     }
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
 }
 
@@ -551,31 +553,52 @@ static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size
         return RSBWT_OK;
     }
     const uint32_t wpq = words_per_kmer(k);
-    const size_t SLICE = 4u << 20;
-    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
-        const size_t m = std::min(SLICE, Q - q0);
-        // the last k-mer needs only k bytes
-        const size_t ascii_bytes = (m - 1) * stride + k;
-        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15;
-        const size_t a_packed = m * wpq * 8;
-        const size_t a_valid = (m + 15) & ~(size_t)15;
-        std::lock_guard<std::recursive_mutex> lock(h->mu);
-        if ((rc = h->stage(a_ascii + a_packed + a_valid + 2 * m * 8)) != RSBWT_OK) return rc;
-        uint8_t *base = (uint8_t *)h->d_stage;
-        uint8_t *d_ascii = base;
-        uint8_t *d_packed = d_ascii + a_ascii;
-        uint8_t *d_valid = d_packed + a_packed;
-        uint8_t *d_lo = d_valid + a_valid;
-        uint8_t *d_up = d_lo + m * 8;
-        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
-        hipError_t e = launch_pack(d_ascii, m, k, stride, d_packed, d_valid, h->stream);
-        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
-        rc = search_dev(h, d_packed, d_valid, m, k, d_lo, d_up, counts_only, h->stream);
-        if (rc) return rc;
-        HIP_OK(hipMemcpyAsync(lower + q0, d_lo, m * 8, hipMemcpyDeviceToHost, h->stream));
-        if (!counts_only) HIP_OK(hipMemcpyAsync(upper + q0, d_up, m * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
+    // Slices of at most 2M k-mers alternate between two streams and two halves of the staging
+    // buffer: while the host sits in slice i's copy back, the GPU already searches slice i + 1
+    // (its k-mers went up before that copy was issued).
+    const size_t SLICE = 2u << 20;
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    if (!h->stream2 && Q > SLICE) {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail_hip(e, "hipStreamCreate");
     }
+    const size_t m_max = std::min(SLICE, Q);
+    const size_t a_ascii = (((m_max - 1) * stride + k) + 15) & ~(size_t)15;
+    const size_t a_packed = m_max * wpq * 8;
+    const size_t a_valid = (m_max + 15) & ~(size_t)15;
+    const size_t half = a_ascii + a_packed + a_valid + 2 * m_max * 8;
+    if ((rc = h->stage(Q > SLICE ? 2 * half : half)) != RSBWT_OK) return rc;
+    struct slice_t {
+        size_t q0 = 0, m = 0;
+        uint8_t *d_lo = nullptr, *d_up = nullptr;
+        hipStream_t st = nullptr;
+    } prev;
+    auto collect = [&](const slice_t &sl) -> int {  // results of a slice whose search is under way
+        HIP_OK(hipMemcpyAsync(lower + sl.q0, sl.d_lo, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
+        if (!counts_only) HIP_OK(hipMemcpyAsync(upper + sl.q0, sl.d_up, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
+        HIP_OK(hipStreamSynchronize(sl.st));
+        return RSBWT_OK;
+    };
+    size_t i = 0;
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE, ++i) {
+        slice_t cur;
+        cur.q0 = q0;
+        cur.m = std::min(SLICE, Q - q0);
+        cur.st = (i & 1) ? h->stream2 : h->stream;
+        uint8_t *base = (uint8_t *)h->d_stage + (i & 1) * half;
+        uint8_t *d_ascii = base, *d_packed = d_ascii + a_ascii, *d_valid = d_packed + a_packed;
+        cur.d_lo = d_valid + a_valid;
+        cur.d_up = cur.d_lo + m_max * 8;
+        const size_t ascii_bytes = (cur.m - 1) * stride + k;  // the last k-mer needs only k bytes
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, cur.st));
+        hipError_t e = launch_pack(d_ascii, cur.m, k, stride, d_packed, d_valid, cur.st);
+        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+        rc = search_dev(h, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st);
+        if (rc) return rc;
+        if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
+        prev = cur;
+    }
+    if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
     return RSBWT_OK;
 }
 

@@ -349,6 +349,43 @@ def test_gpu_device_synth_equals_host_synth(rsb):
     assert np.array_equal(d.cpu().numpy(), h)
 
 
+def test_gpu_host_interface_pipelines_big_batches_over_two_streams(rsb):
+    """rsbwt_find_intervals / rsbwt_count cut a host batch into 2M-query slices that alternate
+    between two streams and staging halves: 5.3M k-mers (three slices, the last one ragged) must
+    come back exactly as one device-resident launch over the same k-mers gives them."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    R = 3000000
+    d_runs = torch.empty(R, dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, 41, 0, None) == 0
+    torch.cuda.synchronize()
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
+    Q, k = 5300001, 20
+    d_km = torch.empty((Q, k), dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_sample_present_kmers_dev(g.handle, Q, k, k, 3, C.c_void_p(d_km.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    rnd = torch.randint(0, 4, (Q // 3, k), device="cuda:0", dtype=torch.uint8)
+    d_km[::3][:Q // 3] = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda:0")[rnd.long()]
+    d_km[12345, 7] = ord("N")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    d_pk = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_ok = torch.empty(Q, dtype=torch.uint8, device="cuda:0")
+    d_lo = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    d_up = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+    assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, None) == 0
+    assert L.rsbwt_find_intervals_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), p(d_up), None) == 0
+    torch.cuda.synchronize()
+    km = d_km.cpu().numpy()
+    lo, up = rsb.find_intervals(g, km)
+    assert np.array_equal(lo, d_lo.cpu().numpy().view(np.uint64))
+    assert np.array_equal(up, d_up.cpu().numpy().view(np.uint64))
+    assert (lo[12345], up[12345]) == (1, 0) and (up >= lo).sum() > Q // 2
+    cnt = rsb.count_kmers(g, km)
+    assert np.array_equal(cnt, np.where(up >= lo, up - lo + 1, 0).astype(np.uint64))
+    g.close()
+
+
 def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     """The *_dev forms bench.py uses: pack + search on device buffers, HIP-event timing, and the
     exact LF-step / Occ / block counters against the oracle's step counts."""

@@ -31,12 +31,25 @@ assert L.rsbwt_sample_present_kmers_dev(g.handle, Q // 2, k, k, 8, C.c_void_p(ha
 torch.cuda.synchronize()
 km[::2][:Q // 2] = half.cpu().numpy()
 km = np.ascontiguousarray(km)
-rsb.find_intervals(g, km)
-t = time.perf_counter()
-reps = 3
-for _ in range(reps):
-    lo, up = rsb.find_intervals(g, km)
-dt = (time.perf_counter() - t) / reps
-print(json.dumps({"queries": Q, "run_bytes": R, "host_interface_q_per_s": Q / dt, "ms_per_batch": dt * 1e3,
-                  "bytes_over_pcie_per_query": k + 16, "hits": int((up >= lo).sum())}))
+vp = lambda a: C.c_void_p(a.ctypes.data)
+res = {"queries": Q, "run_bytes": R, "bytes_over_pcie_per_query": k + 16}
+for name, pin in (("pageable", False), ("pinned", True)):
+    if pin:  # page-locked host buffers (what a caller that cares would pass)
+        tk = torch.from_numpy(km).pin_memory()
+        tl = torch.empty(Q, dtype=torch.int64).pin_memory()
+        tu = torch.empty(Q, dtype=torch.int64).pin_memory()
+        a, lo, up = tk.numpy(), tl.numpy().view(np.uint64), tu.numpy().view(np.uint64)
+    else:
+        a, lo, up = km, np.empty(Q, np.uint64), np.empty(Q, np.uint64)
+    f = lambda: L.rsbwt_find_intervals(g.handle, vp(a), Q, k, k, vp(lo), vp(up))
+    assert f() == 0
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        f()
+    dt = (time.perf_counter() - t) / reps
+    res[name + "_q_per_s"] = Q / dt
+    res[name + "_ms_per_batch"] = dt * 1e3
+    res["hits"] = int((up >= lo).sum())
+print(json.dumps(res))
 g.close()
