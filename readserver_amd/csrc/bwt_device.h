@@ -132,6 +132,14 @@ __device__ __forceinline__ uint32_t offset_in_block(const block_meta &bm, uint64
     return ((uint32_t)p - bm.P0_lo24) & 0xFFFFFFu;
 }
 
+// matched symbols in one dword of 4 runs: acc + sum of len over the bytes whose symbol == b
+// (bb = b in every byte), 4 runs per v_dot4_u32_u8
+__device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint32_t acc) {
+    const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;             // 0 where the symbol matches
+    const uint32_t m01 = ((0x80808080u - z) >> 7) & 0x01010101u;  // 1 where it matches
+    return __builtin_amdgcn_udot4(x & 0x1F1F1F1Fu, m01, acc, false);
+}
+
 // Sum over this lane's 24 runs of min(len, what is left of `rem` symbols), counting only runs of
 // symbol b.  RLEBWT::getOcc's bucket scan (src/bwt/rlebwt.cpp:281-298), 5 VALU per run byte:
 // SDWA operands pick the byte out of the pre-masked dwords.

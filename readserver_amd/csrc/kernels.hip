@@ -317,6 +317,42 @@ __device__ __forceinline__ uint64_t block_count_before(const rsbwt_view &ix, uin
                  (w3 & RSBWT_COUNT_MASK));
 }
 
+// Offset inside block j of its `offset`-th b (offset >= 1, at most the block's count of b):
+// RLEBWT::getOccAt's scan (src/bwt/rlebwt.cpp:245-263), a quarter (32 B = two 16-byte loads) at a
+// time -- quarters before the one holding the occurrence are only added up, 4 runs per dot4.
+__device__ uint64_t thread_select_in_block(const rsbwt_view &ix, uint64_t j, uint32_t b, uint64_t offset) {
+    const uint4 *blk = ix.blocks + 8 * j;
+    const uint32_t bb = b * 0x01010101u;
+    uint64_t index = 0;
+    for (uint32_t t = 0; t < 4u; ++t) {
+        const uint4 a = blk[2 * t], c = blk[2 * t + 1];
+        const uint32_t r[6] = {a.z, a.w, c.x, c.y, c.z, c.w};
+        uint32_t matched = 0, total = 0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            matched = dword_matched(r[d], bb, matched);
+            total = __builtin_amdgcn_udot4(r[d] & 0x1F1F1F1Fu, 0x01010101u, total, false);
+        }
+        if (offset > matched && t < 3u) {
+            offset -= matched;
+            index += total;
+            continue;
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = (r[d] >> (8 * k)) & 0xFFu, len = u & 31u;
+                if ((u >> 5) != b) { index += len; continue; }
+                if (offset <= len) return index + offset - 1;
+                offset -= len;
+                index += len;
+            }
+        }
+    }
+    return index;
+}
+
 // getOccAt(b, bc): position of the bc-th b (bc >= 1).  Floor search over the block headers
 // (BPTree::select's role, include/bwt/BPTree.h:50-67), then RLEBWT::getOccAt's scan
 // (src/bwt/rlebwt.cpp:245-263) over the block's 96 runs.  One thread per item.
@@ -330,18 +366,7 @@ __device__ uint64_t thread_occ_at(const rsbwt_view &ix, uint32_t b, uint64_t bc)
     const uint64_t j = lo;
     const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
     const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
-    uint64_t offset = bc - block_count_before(ix, j, b);
-    uint64_t index = P0;
-    const uint8_t *bytes = (const uint8_t *)w;
-    for (uint32_t i = 0; i < RSBWT_BLOCK_RUNS; ++i) {
-        const uint8_t u = bytes[32u * (i / RSBWT_LANE_RUNS) + 8u + (i % RSBWT_LANE_RUNS)];
-        const uint32_t len = u & 31u;
-        if ((uint32_t)(u >> 5) != b) { index += len; continue; }
-        if (offset <= len) { index += offset - 1; break; }
-        offset -= len;
-        index += len;
-    }
-    return index;
+    return P0 + thread_select_in_block(ix, j, b, bc - block_count_before(ix, j, b));
 }
 
 __global__ void occ_at_batch_kernel(const rsbwt_view ix, const uint8_t *__restrict__ syms,
@@ -500,7 +525,7 @@ hits1mm_write_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restr
 // Read extraction (query.cpp:43-85): the read whose suffix is SA row `row`.
 // ------------------------------------------------------------------------------------------
 // Sampled select: sel[c-1][m] = block holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
-constexpr uint32_t SEL_SHIFT = 12;
+constexpr uint32_t SEL_SHIFT = 8;  // one sample per 256 occurrences: the header search spans 1-3 blocks
 
 __global__ void __launch_bounds__(256)
 select_sample_kernel(const rsbwt_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
@@ -530,18 +555,7 @@ __device__ uint64_t thread_occ_at_sampled(const rsbwt_view &ix, const uint32_t *
     const uint64_t j = lo;
     const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
     const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
-    uint64_t offset = bc - block_count_before(ix, j, b);
-    uint64_t index = P0;
-    const uint8_t *bytes = (const uint8_t *)w;
-    for (uint32_t i = 0; i < RSBWT_BLOCK_RUNS; ++i) {  // rlebwt.cpp:245-263
-        const uint8_t u = bytes[32u * (i / RSBWT_LANE_RUNS) + 8u + (i % RSBWT_LANE_RUNS)];
-        const uint32_t len = u & 31u;
-        if ((uint32_t)(u >> 5) != b) { index += len; continue; }
-        if (offset <= len) { index += offset - 1; break; }
-        offset -= len;
-        index += len;
-    }
-    return index;
+    return P0 + thread_select_in_block(ix, j, b, bc - block_count_before(ix, j, b));
 }
 
 // extractPrefix (query.cpp:43-63): LF walk left until '$'.  One quad per row; the characters are

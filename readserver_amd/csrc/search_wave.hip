@@ -36,13 +36,6 @@ typedef uint32_t __attribute__((may_alias)) lds_u32;
 typedef uint2 __attribute__((may_alias)) lds_u2;
 typedef uint4 __attribute__((may_alias)) lds_u4;
 
-// matched symbols in one dword of 4 runs: sum of len over the bytes whose symbol == b
-__device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint32_t acc) {
-    const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;          // 0 where the symbol matches
-    const uint32_t m01 = ((0x80808080u - z) >> 7) & 0x01010101u;  // 1 where it matches
-    return __builtin_amdgcn_udot4(x & 0x1F1F1F1Fu, m01, acc, false);
-}
-
 // Fetch of up to 64 blocks into the wave's LDS stage, direct to LDS (global_load_lds_dwordx4,
 // gfx950): no register round trip, no ds_write pass.  One instruction writes 1 KB of LDS in lane
 // order, so the work is split the way that makes this the stage layout itself: instruction k
