@@ -349,6 +349,42 @@ def test_gpu_device_synth_equals_host_synth(rsb):
     assert np.array_equal(d.cpu().numpy(), h)
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100])
+def test_gpu_pack_kernels_against_numpy(rsb, k):
+    """2 bits per base, 32 bases per u64 (base i at bits 2i), validity = only ACGT (callers test
+    find_first_not_of("ACGT"), service.cpp:299): dense input (stride == k, the 4-symbols-per-step
+    kernel, every byte alignment of a k-mer's start) and strided input (the byte-wise kernel)."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    rng = np.random.default_rng(k)
+    Q = 3001
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (Q, k))].copy()
+    bad = rng.random(Q) < 0.2
+    for q in np.nonzero(bad)[0]:
+        km[q, rng.integers(k)] = rng.choice(np.frombuffer(b"N$acgtBDUZ@[`{\x00\xff", np.uint8))
+    wpq = (k + 31) // 32
+    code = np.zeros((256,), np.uint64)
+    code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+    want = np.zeros((Q, wpq), np.uint64)
+    for i in range(k):
+        want[:, i // 32] |= code[km[:, i]] << np.uint64(2 * (i % 32))
+    ok_want = np.isin(km, np.frombuffer(b"ACGT", np.uint8)).all(1)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for stride, off in ((k, 0), (k, 1), (k, 2), (k, 3), (k + 5, 0)):
+        flat = torch.zeros(off + Q * stride + 64, dtype=torch.uint8, device="cuda:0")
+        view = flat[off:off + Q * stride].view(Q, stride)
+        view[:, :k] = torch.from_numpy(km).cuda()
+        d_pk = torch.zeros((Q, wpq), dtype=torch.int64, device="cuda:0")
+        d_ok = torch.zeros(Q, dtype=torch.uint8, device="cuda:0")
+        assert L.rsbwt_pack_kmers_dev(C.c_void_p(flat.data_ptr() + off), Q, k, stride, p(d_pk), p(d_ok), 0, None) == 0
+        torch.cuda.synchronize()
+        got_ok = d_ok.cpu().numpy().astype(bool)
+        assert np.array_equal(got_ok, ok_want), (stride, off)
+        got = d_pk.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[ok_want], want[ok_want]), (stride, off)
+
+
 def test_gpu_host_interface_pipelines_big_batches_over_two_streams(rsb):
     """rsbwt_find_intervals / rsbwt_count cut a host batch into 2M-query slices that alternate
     between two streams and staging halves: 5.3M k-mers (three slices, the last one ragged) must
