@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
     ap.add_argument("--slots", choices=["auto", "on", "off"], default=None,
                     help="single-request search layout (default auto: built while index + slots fit 30 %% of HBM)")
+    ap.add_argument("--slot-span", type=int, default=0, help="symbols per slot (0 = auto)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams the batches alternate on.  2: packing, start records and the head of "
                          "batch i + 1 overlap the tail of batch i (+12 %% searches/s), but two search kernels "
@@ -99,7 +100,7 @@ def main():
         slots = a.slots or "auto"  # the library builds slots only while index + slots stay within 30 % of HBM
         g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local, dir_shift=a.dir_shift,
                        ktab_depth=None if a.ktab_depth < 0 else a.ktab_depth,
-                       slots={"auto": "auto", "on": True, "off": False}[slots])
+                       slots={"auto": "auto", "on": True, "off": False}[slots], slot_span=a.slot_span)
         if rank == 0 and s == 0 and world == 1 and a.cpu_sample > 0:
             host_runs = d_runs.cpu().numpy()
         del d_runs
