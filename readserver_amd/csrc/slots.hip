@@ -274,20 +274,16 @@ static bool reciprocal32(uint32_t m, uint32_t *magic, uint32_t *shift) {
     return false;
 }
 
-bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp) {
+// The largest usable span <= cap (S = m << a, m with an exact 32-bit reciprocal; at least the smallest)
+static bool span_at_most(uint64_t n, double cap, slot_params *sp) {
     const uint32_t a = n <= (1ull << 39) ? 7u : 8u;  // p >> a must fit 32 bits
-    const double L = num_runs ? (double)n / (double)num_runs : 1.0;
-    // ~2/3 of the 96-run payload: on the bench stream 0.03 % of the windows then need an overflow
-    // block, against 1.5 % at 3/4 -- with 64 lookups a pass, 1.5 % means an extra fetch round in
-    // most passes (measured: 4 % faster for 6 % more HBM)
-    const double target = want_S ? (double)want_S : 62.0 * L;
     uint32_t best_m = 0, best_magic = 0, best_shift = 0;
     for (uint32_t m = 2; m <= 32; ++m) {
         uint32_t mg, sh;
         if (!reciprocal32(m, &mg, &sh)) continue;
         const double S = (double)(m << a);
         if (S > 4095.0) break;  // span and ostart are 12-bit fields
-        if (S <= target * 1.04 || best_m == 0) { best_m = m; best_magic = mg; best_shift = sh; }
+        if (S <= cap || best_m == 0) { best_m = m; best_magic = mg; best_shift = sh; }
     }
     if (!best_m) return false;
     sp->S = best_m << a;
@@ -297,6 +293,14 @@ bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_param
     sp->nslots = (n + sp->S - 1) / sp->S;
     if (sp->nslots == 0) sp->nslots = 1;
     return true;
+}
+
+// The span asked for, or the starting point of build_slots' choice: windows of ~3/4 of the 96-run
+// payload (mean run length x 74).  build_slots then shrinks it while more than 1 window in 1000
+// needs an overflow block.
+bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp) {
+    const double L = num_runs ? (double)n / (double)num_runs : 1.0;
+    return span_at_most(n, (want_S ? (double)want_S : 74.0 * L) * 1.04, sp);
 }
 
 #define HIP_TRY(x)              \
@@ -314,25 +318,38 @@ hipError_t build_slots(const rsbwt_view &ix, uint64_t num_runs, uint32_t want_S,
     *range_error = 0;
     slot_params sp;
     if (!choose_slot_span(ix.n, num_runs, want_S, &sp)) { *range_error = 1; return hipSuccess; }
-    const uint64_t ns = sp.nslots;
-    const uint64_t nchunks = (ns + 1023) / 1024;
+    uint64_t ns = 0, nchunks = 0;
     uint32_t *d_novf = nullptr;
     uint64_t *d_sums = nullptr, *d_base = nullptr, *d_total = nullptr;
     uint4 *d_out = nullptr;
     uint64_t total_ovf = 0;
-    if (ns >= (1ull << 32)) { *range_error = 1; return hipSuccess; }
-    HIP_TRY(hipMalloc(&d_novf, ns * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_sums, nchunks * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&d_base, ns * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&d_total, sizeof(uint64_t)));
-    hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ix, sp.S, ns, d_novf);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_novf, ns, d_sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, d_sums, nchunks, d_total);
-    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_novf, ns, d_sums, d_base);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&total_ovf, d_total, sizeof total_ovf, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    // Count the overflow blocks of the candidate span; unless the caller fixed it, shrink it while
+    // more than 1 window in 1000 overflows.  A search pass makes 64 lookups: at 1.5 % overflowing
+    // windows most passes pay an extra dependent fetch round (measured: 4 % slower than at 0.03 %),
+    // and how full the windows may be for that depends on the spread of the run lengths, which
+    // only the data tells.  One streaming pass over the blocks per candidate.
+    for (;;) {
+        ns = sp.nslots;
+        nchunks = (ns + 1023) / 1024;
+        if (ns >= (1ull << 32)) { *range_error = 1; goto fail; }
+        HIP_TRY(hipMalloc(&d_novf, ns * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d_sums, nchunks * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_base, ns * sizeof(uint64_t)));
+        if (!d_total) HIP_TRY(hipMalloc(&d_total, sizeof(uint64_t)));
+        hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ix, sp.S, ns, d_novf);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_novf, ns, d_sums);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, d_sums, nchunks, d_total);
+        hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_novf, ns, d_sums, d_base);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&total_ovf, d_total, sizeof total_ovf, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        slot_params smaller;
+        if (want_S || total_ovf * 1000 <= ns || !span_at_most(ix.n, (double)sp.S - 1.0, &smaller) || smaller.S >= sp.S) break;
+        sp = smaller;
+        (void)hipFree(d_novf); (void)hipFree(d_sums); (void)hipFree(d_base);
+        d_novf = nullptr; d_sums = nullptr; d_base = nullptr;
+    }
     if (ns + total_ovf >= (1ull << 32)) { *range_error = 1; goto fail; }
     HIP_TRY(hipMalloc(&d_out, (ns + total_ovf) * RSBWT_BLOCK_BYTES));
     hipLaunchKernelGGL(slot_write_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ix, sp.S, ns,
