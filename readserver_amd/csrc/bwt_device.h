@@ -143,13 +143,14 @@ __device__ __forceinline__ uint32_t dword_matched(uint32_t x, uint32_t bb, uint3
 // Sum over this lane's 24 runs of min(len, what is left of `rem` symbols), counting only runs of
 // symbol b.  RLEBWT::getOcc's bucket scan (src/bwt/rlebwt.cpp:281-298), 5 VALU per run byte:
 // SDWA operands pick the byte out of the pre-masked dwords.
-__device__ __forceinline__ uint32_t lane_scan(const lane_block &lb, uint32_t b, uint32_t rem) {
+template <int ND>
+__device__ __forceinline__ uint32_t runs_scan(const uint32_t *r, uint32_t b, uint32_t rem) {
     const uint32_t b5 = b << 5;
     uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const uint32_t l = lb.r[i] & 0x1F1F1F1Fu;   // lengths
-        const uint32_t sy = lb.r[i] & 0xE0E0E0E0u;  // symbols << 5
+    for (int i = 0; i < ND; ++i) {
+        const uint32_t l = r[i] & 0x1F1F1F1Fu;   // lengths
+        const uint32_t sy = r[i] & 0xE0E0E0E0u;  // symbols << 5
         uint32_t t0, t1;
         asm("v_cmp_eq_u32_sdwa vcc, %[sy], %[b5] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
             "v_min_u32_sdwa %[t0], %[rem], %[l] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
@@ -174,6 +175,10 @@ __device__ __forceinline__ uint32_t lane_scan(const lane_block &lb, uint32_t b, 
             : "vcc");
     }
     return acc;
+}
+
+__device__ __forceinline__ uint32_t lane_scan(const lane_block &lb, uint32_t b, uint32_t rem) {
+    return runs_scan<6>(lb.r, b, rem);
 }
 
 // Occ(b, p) for the block that holds position p: # of symbol b (rank 1..4) in BWT[0..p].

@@ -9,11 +9,12 @@
 //   * blocks are still fetched the way the memory system likes them (tools/gather_bench.hip): a
 //     full 128-B line per group of adjacent lanes, by LDS-DMA straight into the wave's LDS stage
 //     (glds_fetch below), each distinct block of a query once;
-//   * every lane then ranks ITS block out of LDS: the header names the quarter (24 runs) holding
-//     the position, at most one other quarter is summed 4 bytes at a time (v_dot4_u32_u8 against
-//     a 0/1 match mask; a slot's header carries the half-way counts), and only the one quarter is
-//     scanned run by run (SDWA, 5 VALU per run).
-// Overhead is shared by 64 lookups instead of 16 and the scan is 24 bytes instead of 96 per lookup.
+//   * every lane then ranks ITS block out of LDS: the header names the quarter holding the
+//     position and (slots) what the quarters before it hold of every symbol, so only that one
+//     quarter's 16 runs are scanned run by run (SDWA, 5 VALU per run); classic blocks (24-run
+//     quarters, no such counts) add the earlier quarters up 4 bytes at a time (v_dot4_u32_u8
+//     against a 0/1 match mask).
+// Overhead is shared by 64 lookups instead of 16 and the scan is 16 bytes instead of 96 per lookup.
 // Requires slots or the exact (s = 8) directory; other indexes use the octet kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -351,67 +352,48 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         // Occ(b, p) out of this lane's staged block, `off` = p's offset in it (slots) / derived
         // from the block's P0 (classic).  RLEBWT::getOcc, src/bwt/rlebwt.cpp:268-301.
         auto rank_staged = [&](uint32_t off) -> uint64_t {
-            // header: the count word of symbol b and the meta fields (block_format.h / slots.hip)
+            // the count word of symbol b (block_format.h / slots.hip)
             const uint2 cw = *reinterpret_cast<const lds_u2 *>(MINE(8u * (b - 1u)));
-            uint32_t s1, s2, s3;
-            uint32_t before = 0;
-            bool full_sum = true;  // add up every quarter before the one holding the position
-            uint32_t one_q = 0;    // else: the single quarter still to add (if any)
-            bool add_one = false;
+            const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
             if (SLOTS) {
-                const uint32_t m0 = *MINE(1) >> 8, m1 = *MINE(9) >> 8, m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
-                s1 = m0 >> 12; s2 = m1 & 0xFFFu; s3 = m1 >> 12;
-                if ((m2 >> 23) == 0u) {  // not a chain block: x holds the half-way counts
-                    full_sum = false;
-                    const uint64_t x = (uint64_t)(m2 & 0x7FFFFFu) | ((uint64_t)m3 << 23);
-                    before = (uint32_t)(x >> (11u * (b - 1u))) & 0x7FFu;  // b's in quarters 0+1
-                }
-            } else {
-                const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
-                s1 = m2 >> 12; s2 = m3 & 0xFFFu; s3 = m3 >> 12;
-                off = ((uint32_t)p - (*MINE(1) >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
+                // slot: 4 quarters of { word0, word1, 16 runs }; word1 of quarter t = what quarters
+                // 0..t hold of A,C,G,T -- the scan of one quarter is all there is to add
+                const uint32_t m0 = *MINE(1) >> 8, m1 = *MINE(9) >> 8;
+                const uint32_t s1 = m0 >> 12, s2 = m1 & 0xFFFu, s3 = m1 >> 12;
+                const uint32_t o = off + 1u;
+                const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
+                const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+                const uint32_t pq = cq ? cq - 1u : 0u;
+                const uint2 held = *reinterpret_cast<const lds_u2 *>(MINE(8u * pq + 2u));
+                const uint64_t h64 = ((uint64_t)held.y << 32) | held.x;
+                const uint32_t before = cq ? (uint32_t)(h64 >> (11u * (b - 1u))) & 0x7FFu : 0u;
+                const uint4 x = *reinterpret_cast<const lds_u4 *>(MINE(8u * cq + 4u));
+                const uint32_t r[4] = {x.x, x.y, x.z, x.w};
+                // run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
+                return cnt + before + runs_scan<4>(r, b, o - start);
             }
+            // classic block: 4 x { header word, 24 runs }; the quarters before the one holding the
+            // position are added up 4 runs per dot4
+            const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
+            const uint32_t s1 = m2 >> 12, s2 = m3 & 0xFFFu, s3 = m3 >> 12;
+            off = ((uint32_t)p - (*MINE(1) >> 8)) & 0xFFFFFFu;  // exact directory: inside the block
             const uint32_t o = off + 1u;
             const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
             const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
             const uint32_t bb = __umul24(b, 0x010101u) | (b << 24);  // b in every byte (full-rate ops)
-            if (!full_sum) {
-                // quarters 0+1 come from the header; what is left is at most one quarter
-                before = cq >= 2u ? before : 0u;
-                add_one = (cq & 1u) != 0u;  // cq = 1: quarter 0, cq = 3: quarter 2
-                one_q = cq - 1u;
-            }
-            if (__builtin_amdgcn_ballot_w64(full_sum) != 0ull) {
-                // classic blocks and chain blocks: matched lengths of every earlier quarter
-                uint32_t sum = 0;
+            uint32_t before = 0;
 #pragma unroll
-                for (int qt = 0; qt < 3; ++qt) {
-                    const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8 * qt + 2));
-                    const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8 * qt + 4));
-                    uint32_t m = dword_matched(x0.x, bb, 0u);
-                    m = dword_matched(x0.y, bb, m);
-                    m = dword_matched(x1.x, bb, m);
-                    m = dword_matched(x1.y, bb, m);
-                    m = dword_matched(x1.z, bb, m);
-                    m = dword_matched(x1.w, bb, m);
-                    sum += (cq > (uint32_t)qt) ? m : 0u;
-                }
-                if (full_sum) before = sum;
-            }
-            if (SLOTS) {
-                // matched lengths of the one remaining quarter, 4 runs per dot4
-                const uint32_t qsel = add_one ? one_q : 0u;
-                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8u * qsel + 2u));
-                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8u * qsel + 4u));
+            for (int qt = 0; qt < 3; ++qt) {
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8 * qt + 2));
+                const uint4 x1 = *reinterpret_cast<const lds_u4 *>(MINE(8 * qt + 4));
                 uint32_t m = dword_matched(x0.x, bb, 0u);
                 m = dword_matched(x0.y, bb, m);
                 m = dword_matched(x1.x, bb, m);
                 m = dword_matched(x1.y, bb, m);
                 m = dword_matched(x1.z, bb, m);
                 m = dword_matched(x1.w, bb, m);
-                before += add_one ? m : 0u;
+                before += (cq > (uint32_t)qt) ? m : 0u;
             }
-            // the quarter holding it: run by run (RLEBWT::getOcc's scan, src/bwt/rlebwt.cpp:281-298)
             lane_block lb;
             {
                 const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(8u * cq + 2u));
@@ -419,9 +401,7 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
                 lb.r[0] = x0.x; lb.r[1] = x0.y; lb.r[2] = x1.x; lb.r[3] = x1.y; lb.r[4] = x1.z; lb.r[5] = x1.w;
                 lb.hdr_lo = 0; lb.hdr_hi = 0;
             }
-            const uint32_t inq = lane_scan(lb, b, o - start);
-            const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
-            return cnt + before + inq;
+            return cnt + before + lane_scan(lb, b, o - start);
         };
         uint64_t occ = 0;
         uint32_t off = pin;
@@ -435,22 +415,22 @@ search_wave_kernel(const rsbwt_view ix, const slot_view sv, const uint64_t *__re
         }
         STAMP(3)  // rank out of LDS
         if (SLOTS) {
-            // a window has at most S < 4096 pieces = 43 blocks: the bound only guards against a
+            // a window has at most S < 4096 pieces = 64 blocks: the bound only guards against a
             // corrupt chain, so that every wave drains
-            for (int guard = 0; guard < 48 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
+            for (int guard = 0; guard < 72 && __builtin_amdgcn_ballot_w64(need) != 0ull; ++guard) {
                 uint32_t want = ~0u;
                 const bool was = need;
                 if (need) {
-                    const uint32_t m2 = *MINE(17) >> 8, m3 = *MINE(25) >> 8;
-                    want = (m2 & 0x7FFFFFu) | (m3 << 23);  // next = x bits 0..31 (chain blocks)
-                    if ((m2 >> 23) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
+                    const uint32_t m2 = *MINE(17) >> 8;
+                    want = *MINE(26);  // next: word1 of quarter 3
+                    if (((m2 >> 12) & 1u) == 0u || want == 0u || want >= nblk_total) { want = ~0u; need = false; }  // never for p < n
                     else { blk = want; ++hops; }
                 }
                 glds_fetch(blocks_bytes, want, lane, stage_lds);
                 glds_wait();
                 if (want != ~0u) mine0 = own_row;  // an overflow block always lands in the lane's own row
                 if (need) {
-                    off = pin - ((*MINE(25) >> 17) & 0xFFFu);  // ostart = x bits 32..43 of the new block
+                    off = pin - ((*MINE(17) >> 8) & 0xFFFu);  // ostart: meta_2 of the new block
                     need = off >= ((*MINE(1) >> 8) & 0xFFFu);
                 }
                 if (was && !need) occ = rank_staged(off);

@@ -6,20 +6,24 @@
 // position is computable: slot i holds the run pieces of BWT[i*S, (i+1)*S) (runs are split at slot
 // borders) with absolute A/C/G/T counts at i*S -- address = slots + 128 * (p / S), one request.
 // S = m << a (a = 7 or 8, m with an exact 32-bit reciprocal) is chosen from the mean run length so
-// that the 96-run payload is ~3/4 full; the few windows that need more pieces chain to overflow
-// blocks stored behind the slots (`next`), each holding the following <= 96 pieces.
+// that the 64-run payload is ~3/4 full and shrunk while more than 1 window in 1000 needs more
+// pieces; those chain to overflow blocks stored behind the slots (`next`), 64 pieces each.
 //
-// Slot / overflow block = 4 x (8-byte header word + 24 run bytes), as a classic block, with meta
-//   t=0  span | start_1 << 12           span = symbols held by this block; start_t = symbols held
-//   t=1  start_2 | start_3 << 12        by quarters 0..t-1
-//   t=2  x bits 0..22 | chain << 23     x is 44 bits wide:
-//   t=3  x bits 23..43                    chain = 0: the symbols A,C,G,T held by quarters 0+1, 11 bits
-//                                                    each (the rank of a position in the second half
-//                                                    starts from them instead of re-adding 48 runs)
-//                                         chain = 1: next (32 bits) | ostart << 32.  The window is
-//                                                    split over several blocks: next = index (into the
-//                                                    same array) of the block that continues it, 0 = none;
-//                                                    ostart = symbols of the window before this block
+// Slot / overflow block (128 B) = 4 quarters of 32 B, each { word0, word1, 16 run bytes }:
+//   word0 of quarter t = count of symbol t+1 before the block (40 bits) | meta_t << 40
+//       meta_0  span | start_1 << 12     span = symbols held by this block; start_t = symbols held
+//       meta_1  start_2 | start_3 << 12  by quarters 0..t-1
+//       meta_2  ostart | chain << 12     the window is split over several blocks (chain = 1):
+//                                        ostart = symbols of the window before this block
+//   word1 of quarter t < 3 = the symbols A,C,G,T held by quarters 0..t (4 x 11 bits): the rank of
+//       a position in quarter t+1 starts from them, so it scans at most the 16 runs of one quarter
+//       and never re-adds whole quarters
+//   word1 of quarter 3 = next: index (into the same array) of the block that continues the
+//       window, 0 = none
+// Half of a block is counters: a lookup costs one 128-B request whatever the block holds, the
+// search kernel is short of VALU issue and request slots, not of HBM capacity, and the number of
+// distinct blocks a batch touches hardly depends on S (8.67e7 at S = 640, 8.79e7 at S = 384 on the
+// bench batch) -- so the block is laid out for the cheapest rank, not for density.
 // Memory is ~ n/S * 128 B (about the size of the classic index), so slots are built only on
 // request / when HBM allows, NEXT TO the classic index, which the other kernels keep using.
 #include <hip/hip_runtime.h>
@@ -98,6 +102,8 @@ struct run_walker {
     }
 };
 
+constexpr uint32_t SLOT_RUNS = 64;  // run pieces per slot / overflow block (4 quarters of 16)
+
 // pass 1: overflow blocks each window needs
 __global__ void __launch_bounds__(256)
 slot_count_kernel(const rsbwt_view ix, uint32_t S, uint64_t nslots, uint32_t *__restrict__ novf) {
@@ -113,13 +119,13 @@ slot_count_kernel(const rsbwt_view ix, uint32_t S, uint64_t nslots, uint32_t *__
         remaining -= len;
         ++pieces;
     }
-    novf[i] = pieces > RSBWT_BLOCK_RUNS ? (pieces - 1u) / RSBWT_BLOCK_RUNS : 0u;
+    novf[i] = pieces > SLOT_RUNS ? (pieces - 1u) / SLOT_RUNS : 0u;
 }
 
 __device__ void flush_slot_block(uint4 *dst, const uint8_t *buf, uint32_t used, const uint64_t cnt0[4],
                                  uint32_t next, uint32_t ostart) {
-    uint32_t wds[24];
-    for (int d = 0; d < 24; ++d) {
+    uint32_t wds[16];
+    for (int d = 0; d < 16; ++d) {
         uint32_t x = 0;
         for (int k = 0; k < 4; ++k) {
             const uint32_t idx = 4u * d + k;
@@ -128,32 +134,29 @@ __device__ void flush_slot_block(uint4 *dst, const uint8_t *buf, uint32_t used, 
         wds[d] = x;
     }
     uint32_t start[4] = {0, 0, 0, 0}, span = 0;
+    uint32_t held[4] = {0, 0, 0, 0};  // A,C,G,T held so far
+    uint64_t word1[4] = {0, 0, 0, 0};
     for (int q = 0; q < 4; ++q) {
         start[q] = span;
-        for (int d = 0; d < 6; ++d) span = __builtin_amdgcn_sad_u8(wds[6 * q + d] & 0x1F1F1F1Fu, 0u, span);
-    }
-    uint64_t x;
-    const bool chain = next != 0u || ostart != 0u;
-    if (chain) {
-        x = (uint64_t)next | ((uint64_t)ostart << 32);
-    } else {
-        x = 0;
-        for (uint32_t c = 1; c <= 4; ++c) {
-            uint32_t h = 0;
-            for (int d = 0; d < 12; ++d) {
-                const uint32_t w = wds[d];
-                for (int k = 0; k < 4; ++k)
-                    if (((w >> (8 * k + 5)) & 7u) == c) h += (w >> (8 * k)) & 31u;
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t w = wds[4 * q + d];
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t len = (w >> (8 * k)) & 31u, sym = (w >> (8 * k + 5)) & 7u;
+                span += len;
+                if (sym >= 1u && sym <= 4u) held[sym - 1u] += len;
             }
-            x |= (uint64_t)h << (11u * (c - 1u));
         }
+        if (q < 3)
+            word1[q] = (uint64_t)held[0] | ((uint64_t)held[1] << 11) | ((uint64_t)held[2] << 22) | ((uint64_t)held[3] << 33);
     }
+    word1[3] = next;
+    const bool chain = next != 0u || ostart != 0u;
     const uint32_t meta[4] = {span | (start[1] << 12), start[2] | (start[3] << 12),
-                              (uint32_t)(x & 0x7FFFFFu) | (chain ? 1u << 23 : 0u), (uint32_t)(x >> 23)};
+                              ostart | (chain ? 1u << 12 : 0u), 0u};
     for (int q = 0; q < 4; ++q) {
-        const uint64_t word = (cnt0[q] & RSBWT_COUNT_MASK) | ((uint64_t)meta[q] << 40);
-        dst[2 * q] = make_uint4((uint32_t)word, (uint32_t)(word >> 32), wds[6 * q], wds[6 * q + 1]);
-        dst[2 * q + 1] = make_uint4(wds[6 * q + 2], wds[6 * q + 3], wds[6 * q + 4], wds[6 * q + 5]);
+        const uint64_t word0 = (cnt0[q] & RSBWT_COUNT_MASK) | ((uint64_t)meta[q] << 40);
+        dst[2 * q] = make_uint4((uint32_t)word0, (uint32_t)(word0 >> 32), (uint32_t)word1[q], (uint32_t)(word1[q] >> 32));
+        dst[2 * q + 1] = make_uint4(wds[4 * q], wds[4 * q + 1], wds[4 * q + 2], wds[4 * q + 3]);
     }
 }
 
@@ -166,7 +169,7 @@ slot_write_kernel(const rsbwt_view ix, uint32_t S, uint64_t nslots, const uint64
     run_walker w;
     w.seek(ix, i * S);
     uint32_t remaining = (uint32_t)((ix.n - i * S) < S ? (ix.n - i * S) : S);
-    uint8_t buf[RSBWT_BLOCK_RUNS];
+    uint8_t buf[SLOT_RUNS];
     uint64_t cnt0[4] = {w.cnt[0], w.cnt[1], w.cnt[2], w.cnt[3]};
     uint32_t used = 0, ostart = 0, emitted = 0, chain = 0;
     const uint32_t nchain = novf[i];
@@ -174,7 +177,7 @@ slot_write_kernel(const rsbwt_view ix, uint32_t S, uint64_t nslots, const uint64
     for (;;) {
         uint32_t ps = 0;
         const uint32_t len = remaining ? w.take(ix, remaining, ps) : 0u;
-        if (len && used == RSBWT_BLOCK_RUNS) {
+        if (len && used == SLOT_RUNS) {
             // block full and the window goes on: chain to the next overflow block
             const uint64_t nxt = nslots + ovf_base[i] + chain;
             flush_slot_block(out + dst * 8, buf, used, cnt0, (uint32_t)nxt, ostart);
@@ -295,12 +298,12 @@ static bool span_at_most(uint64_t n, double cap, slot_params *sp) {
     return true;
 }
 
-// The span asked for, or the starting point of build_slots' choice: windows of ~3/4 of the 96-run
-// payload (mean run length x 74).  build_slots then shrinks it while more than 1 window in 1000
+// The span asked for, or the starting point of build_slots' choice: windows of ~3/4 of the 64-run
+// payload (mean run length x 49).  build_slots then shrinks it while more than 1 window in 1000
 // needs an overflow block.
 bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp) {
     const double L = num_runs ? (double)n / (double)num_runs : 1.0;
-    return span_at_most(n, (want_S ? (double)want_S : 74.0 * L) * 1.04, sp);
+    return span_at_most(n, (want_S ? (double)want_S : 49.0 * L) * 1.04, sp);
 }
 
 #define HIP_TRY(x)              \

@@ -504,7 +504,7 @@ def test_gpu_file_open_and_shard_set(rsb, oracle, tmp_path):
                                         ("mixed", 0), ("mixed", 768)])
 def test_gpu_slot_layout_is_bit_exact(rsb, oracle, style, span):
     """The single-request layout: runs split at slot borders, overflow chains for windows with more
-    than 96 pieces (forced by large spans over short runs), half-empty slots (small spans over long
+    than 64 pieces (forced by large spans over short runs), half-empty slots (small spans over long
     runs) -- the same intervals as the oracle and as the classic layout."""
     L = rsb.lib()
     rng = np.random.default_rng(len(style) * 1000 + span)
