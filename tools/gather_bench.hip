@@ -201,7 +201,8 @@ int main(int argc, char **argv) {
     const int iters = argc > 3 ? atoi(argv[3]) : 64;
     const int bpc = argc > 4 ? atoi(argv[4]) : 8;
     const uint64_t nlines = (uint64_t)(buf_gib * (1ull << 30)) / 128;
-    const uint64_t ndir = (uint64_t)(dir_gib * (1ull << 30)) / 8;
+    uint64_t ndir = (uint64_t)(dir_gib * (1ull << 30)) / 8;
+    if (ndir < 1024) ndir = 1024;  // never an empty second table: the dependent pattern indexes it modulo its size
     uint4 *buf;
     uint2 *dir;
     uint32_t *sink;
