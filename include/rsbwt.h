@@ -46,17 +46,19 @@ extern "C" {
 #define RSBWT_DIR_SHIFT_AUTO 0u /* low 5 bits: log2 symbols per directory window, 0 = auto */
 #define RSBWT_DIR_SHIFT_MASK 0x1Fu
 /* bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
- * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (about 6 % of the
- * index), 31 = no table, else T = 2..15. */
+ * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (the deepest table
+ * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n), 31 = no
+ * table, else T = 2..16 (T = 16: 34 GB). */
 #define RSBWT_KTAB_SHIFT 5
 #define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_DEPTH(t) ((uint32_t)(t) << RSBWT_KTAB_SHIFT)
 /* bits 10..11: the single-request search layout ("slots": fixed-span blocks addressed from the
- * position, one HBM request per Occ lookup instead of two; about as large as the index itself and
+ * position, one HBM request per Occ lookup instead of two; up to twice the size of the index and
  * kept next to it).  AUTO builds it when index + slots stay within ~30 % of the device's HBM and
  * the allocation succeeds -- right for one shard per GPU; open many shards per GPU with OFF.
- * bits 12..23: symbols per slot (0 = from the mean run length). */
+ * bits 12..23: symbols per slot (0 = chosen from the data: the largest span that leaves at most
+ * 1 window in 1000 in need of an overflow block). */
 #define RSBWT_SLOTS_SHIFT 10
 #define RSBWT_SLOTS_AUTO (0u << RSBWT_SLOTS_SHIFT)
 #define RSBWT_SLOTS_ON (1u << RSBWT_SLOTS_SHIFT)
