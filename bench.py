@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--dir-shift", type=int, default=0)
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
     ap.add_argument("--slots", choices=["auto", "on", "off"], default=None,
-                    help="single-request search layout (default auto: built while index + slots fit 30 %% of HBM)")
+                    help="single-request search layout (default auto: built while index + slots fit 45 %% of HBM)")
     ap.add_argument("--slot-span", type=int, default=0, help="symbols per slot (0 = auto)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams the batches alternate on.  2: packing, start records and the head of "
@@ -97,7 +97,7 @@ def main():
         d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
         ok(L.rsbwt_synth_runs_dev(ptr(d_runs), R, seed, local, sp))
         torch.cuda.synchronize()
-        slots = a.slots or "auto"  # the library builds slots only while index + slots stay within 30 % of HBM
+        slots = a.slots or "auto"  # the library builds slots only while index + slots stay within 45 % of HBM
         g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local, dir_shift=a.dir_shift,
                        ktab_depth=None if a.ktab_depth < 0 else a.ktab_depth,
                        slots={"auto": "auto", "on": True, "off": False}[slots], slot_span=a.slot_span)

@@ -55,7 +55,7 @@ extern "C" {
 #define RSBWT_KTAB_DEPTH(t) ((uint32_t)(t) << RSBWT_KTAB_SHIFT)
 /* bits 10..11: the single-request search layout ("slots": fixed-span blocks addressed from the
  * position, one HBM request per Occ lookup instead of two; up to twice the size of the index and
- * kept next to it).  AUTO builds it when index + slots stay within ~30 % of the device's HBM and
+ * kept next to it).  AUTO builds it when index + slots stay within ~45 % of the device's HBM and
  * the allocation succeeds -- right for one shard per GPU; open many shards per GPU with OFF.
  * bits 12..23: symbols per slot (0 = chosen from the data: the largest span that leaves at most
  * 1 window in 1000 in need of an overflow block). */

@@ -163,9 +163,12 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         slot_params sp;
         if (mode == RSBWT_SLOTS_AUTO && h->view.n > 0 && choose_slot_span(h->view.n, h->num_runs, want_S, &sp)) {
             size_t free_b = 0, total_b = 0;
-            const uint64_t est = sp.nslots * RSBWT_BLOCK_BYTES * 21 / 20;
+            // the builder may shrink the span by a step or two (slots.hip): allow for 1.4x the
+            // starting estimate.  Index + slots within 45 % of the device leaves room for the k-mer
+            // table and the batch buffers with one shard per GPU.
+            const uint64_t est = sp.nslots * RSBWT_BLOCK_BYTES * 7 / 5;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                build = (h->hbm_bytes + est) <= total_b * 3 / 10 && est <= free_b / 2;
+                build = (h->hbm_bytes + est) <= total_b * 45 / 100 && est <= free_b / 2;
         }
         if (build && h->view.n > 0) {
             uint64_t bytes = 0;
