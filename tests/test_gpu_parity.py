@@ -257,7 +257,8 @@ def test_gpu_dense_runs_force_directory_hops(rsb, oracle):
 
 
 @pytest.mark.parametrize("slots", [True, False])
-@pytest.mark.parametrize("R,with_dollar", [(50, True), (3000, False), (200000, True), (4000000, True)])
+@pytest.mark.parametrize("R,with_dollar", [(1, True), (2, False), (17, True), (50, True), (65, False), (3000, False),
+                                           (200000, True), (4000000, True)])
 def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar, slots):
     rng = np.random.default_rng(77 + R)
     runs = _random_runs(rng, R, with_dollar)
