@@ -542,12 +542,14 @@ hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const v
     // 32 queries per wave, 4 waves per workgroup
     const size_t per_wg = 32u * WG_WAVES;
     size_t g = (Q + per_wg - 1) / per_wg;
-    // Workgroups per CU: LDS admits 5 (20 waves).  Before queries were handed out dynamically 4 was faster
-    // (5.24 vs 5.81 ms); now 3: 4.69, 4: 4.57, 5: 4.51 ms.  RSBWT_WAVE_WGS_PER_CU overrides.
+    // Workgroups per CU: LDS admits 5 (20 waves), but 4 are as fast (2.39-2.41 against 2.40-2.50 ms:
+    // the request path, not the number of lookups in flight, is what saturates) and leave 32 KB of
+    // LDS and wave slots per CU to kernels that run beside the search -- RCCL's, when the previous
+    // batch's intervals are gathered at N > 1.  3 are 8 % slower.  RSBWT_WAVE_WGS_PER_CU overrides.
     static const int wgs_per_cu = [] {
         const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 5;
+        return v > 0 ? v : 4;
     }();
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;
