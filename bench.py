@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--slot-span", type=int, default=0, help="symbols per slot (0 = auto)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams the batches alternate on.  2: packing, start records and the head of "
-                         "batch i + 1 overlap the tail of batch i (+12 %% searches/s), but two search kernels "
+                         "batch i + 1 overlap the tail of batch i (+2..4 %% searches/s), but two search kernels "
                          "then share the GPU and their event-timed durations no longer price one launch, so "
                          "the roofline line is quoted at 1")
     ap.add_argument("--seed", type=int, default=1)
