@@ -195,6 +195,34 @@ static double time_ms(F launch, int reps) {
     return ms / reps;
 }
 
+// The search kernel's fetch as it is now: 64 random lines per wave and pass, a full 128-B line per
+// octet of lanes, by LDS-DMA (global_load_lds_dwordx4) into an 8 KB stage, all 64 waited for, then
+// (as a stand-in for the rank) one LDS read per lane.  WGS workgroups of 4 waves per CU.
+typedef __attribute__((address_space(3))) void *gb_lds_ptr;
+typedef const __attribute__((address_space(1))) void *gb_glb_ptr;
+__global__ void __launch_bounds__(256)
+glds_octet_kernel(const uint4 *__restrict__ buf, uint64_t nlines, int iters, uint32_t *__restrict__ sink) {
+    __shared__ uint4 stage[4][512];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(gb_lds_ptr)stage[wave]);
+    const uint64_t me = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const char *base = reinterpret_cast<const char *>(buf);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t mine = (uint32_t)(mix64(me * 1315423911ull + (uint64_t)it) % nlines);  // the line this lane wants
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t line = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~7u) + k) << 2), (int)mine);
+            const char *src = base + (uint64_t)line * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
+            __builtin_amdgcn_global_load_lds((gb_glb_ptr)src, (gb_lds_ptr)(uintptr_t)(lds0 + k * 1024u), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        acc ^= reinterpret_cast<const volatile uint32_t *>(stage[wave])[(lane & 7u) * 256u + (lane >> 3) * 32u + 1u];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
     const double buf_gib = argc > 1 ? atof(argv[1]) : 32.0;
     const double dir_gib = argc > 2 ? atof(argv[2]) : 6.0;
@@ -255,5 +283,13 @@ int main(int argc, char **argv) {
         printf("coop x%d sets, %d WG/CU   %12.3f %12.2f %12.1f\n", SETS, WGS, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
     }
     RUNCOOP(1, 2) RUNCOOP(1, 3) RUNCOOP(1, 4) RUNCOOP(1, 5) RUNCOOP(2, 1) RUNCOOP(2, 2) RUNCOOP(2, 3)
+#define RUNGLDS(WGS)                                                                                \
+    {                                                                                               \
+        const int g = prop.multiProcessorCount * WGS;                                               \
+        double ms = time_ms([&] { glds_octet_kernel<<<g, 256>>>(buf, nlines, iters, sink); }, 3);    \
+        double acc = (double)g * 256 * iters;                                                       \
+        printf("glds octet, %d WG/CU     %12.3f %12.2f %12.1f\n", WGS, ms, acc / ms / 1e6, acc * 128 / ms / 1e6); \
+    }
+    RUNGLDS(2) RUNGLDS(3) RUNGLDS(4) RUNGLDS(5)
     return 0;
 }
