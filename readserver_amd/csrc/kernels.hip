@@ -731,6 +731,20 @@ hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, u
     rsbwt_view plain = ix;
     plain.ktab = nullptr;
     plain.ktab_depth = 0;
+    // a deep table is built on top of a shallow one: with the (T/2)-mer table in place, each of
+    // the 4^T searches starts from its last T/2 symbols' entry and takes half the LF steps
+    uint64_t *d_half = nullptr;
+    if (T >= 10u) {
+        const uint32_t T0 = T / 2u;
+        if ((e = hipMalloc(&d_half, 8ull << (2u * T0))) == hipSuccess) e = build_ktable(ix, sv, T0, d_half, num_cus, stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); (void)hipFree(d_ok);
+            if (d_half) (void)hipFree(d_half);
+            return e;
+        }
+        plain.ktab = d_half;
+        plain.ktab_depth = T0;
+    }
     for (uint64_t base = 0; base < total && e == hipSuccess; base += SL) {
         const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
         const int g = (int)((m + 255) / 256);
@@ -742,6 +756,7 @@ hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, u
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); (void)hipFree(d_ok);
+    if (d_half) (void)hipFree(d_half);
     return e;
 }
 
