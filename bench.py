@@ -2,20 +2,24 @@
 """bench.py -- 31-mer exact backward search on a population BWT resident in HBM.
 
 One "step" = one pass of the hot path over one batch: Q ASCII 31-mers already in HBM are packed
-to 2 bits and searched (findInterval, src/bwt/query.cpp:24-41) in every shard this rank holds;
-with N > 1 ranks the per-shard (lower, upper) arrays are then gathered on rank 0 over RCCL
-(every query goes to every shard, results are only concatenated); the gather of batch i
-runs behind the search of batch i + 1 (two resident result buffers).
+to 2 bits (once) and searched (findInterval, src/bwt/query.cpp:24-41) in EVERY shard this rank
+holds by one fused launch ((query, shard) pairs drawn from per-shard pools); with N > 1 ranks the
+per-shard (lower, upper) arrays are then gathered on rank 0 over RCCL (every query goes
+to every shard, results are only concatenated); the gather of batch i runs behind the search of
+batch i + 1 (two resident result buffers).
 
-N = 1 default workload = BASELINE.json configs[1]: one ~20 GB shard (2e10 run bytes from the
-direct run-stream synthesiser), 1e7 31-mers, half drawn from the index (all 30 LF steps), half
-uniform random (terminate early).  `value` counts (query x shard) searches per second.
+Default workload = the per-GPU load of BASELINE.json configs[2]: 8 shards of ~20 GB (2e10 run bytes
+each, from the direct run-stream synthesiser) resident in one MI355X, 1e7 31-mers per batch, half
+of them drawn from the local shards (all 30 LF steps in the shard they come from), half uniform
+random (terminate early).  `value` counts (query x shard) searches per second = S/s; Q/s = S/s /
+shards.  `--shards-per-gpu 1` is configs[1] (one shard, deepest k-mer table).
 
     python bench.py [--gpus N --steps K --warmup W] [--runs R --queries Q --shards-per-gpu S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BLOCK_BYTES = 128      # algorithmic bytes per distinct block read by an Occ lookup
+LINE_BYTES = 128       # algorithmic bytes per distinct window line read by an Occ lookup
+SEARCH_BYTES = 40      # per (query, shard) search: 16 B start record + 8 B packed word read, 16 B result written
 
 
 def parse():
@@ -38,22 +43,39 @@ def parse():
     ap.add_argument("--runs", type=float, default=2e10, help="run bytes per shard")
     ap.add_argument("--queries", type=float, default=1e7, help="31-mers per batch")
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--shards-per-gpu", type=int, default=1)
+    ap.add_argument("--shards-per-gpu", type=int, default=8)
     ap.add_argument("--present-frac", type=float, default=0.5)
+    ap.add_argument("--same-shards", action="store_true",
+                    help="every shard of a rank holds the same stream, so a present k-mer is present in all of them "
+                         "(the work profile of a real population: each shard sees configs[1]'s mix)")
+    ap.add_argument("--stream", choices=["mixed", "long"], default="mixed",
+                    help="run-length mix of the synthetic stream: mixed = mean ~10.4 symbols per unit; "
+                         "long = mostly 31-symbol units of long runs (mean ~25), as in a deep population BWT")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="queries timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
-    ap.add_argument("--dir-shift", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
-    ap.add_argument("--slots", choices=["auto", "on", "off"], default=None,
-                    help="single-request search layout (default auto: built while index + slots fit 45 %% of HBM)")
-    ap.add_argument("--slot-span", type=int, default=0, help="symbols per slot (0 = auto)")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="HIP streams the batches alternate on.  2: packing, start records and the head of "
-                         "batch i + 1 overlap the tail of batch i (+2..4 %% searches/s), but two search kernels "
-                         "then share the GPU and their event-timed durations no longer price one launch, so "
-                         "the roofline line is quoted at 1")
+    ap.add_argument("--window-span", type=int, default=0, help="symbols per window line (0 = from the data)")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
+
+
+def kernel_source_sha():
+    """Identifies the search kernel + layout a PMC traffic figure was measured on."""
+    h = hashlib.sha256()
+    for f in ("search_lines.hip", "line_format.h", "rank_device.h"):
+        h.update(open(os.path.join(ROOT, "readserver_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def usable_cpus():
+    n = len(os.sched_getaffinity(0))
+    try:  # cgroup v2 quota
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
 
 
 def main():
@@ -92,20 +114,23 @@ def main():
     # ---- resident index: S shards per rank, each R run bytes synthesised in HBM ---------------
     t_build0 = time.time()
     shards, host_runs = [], None
+    style = (1 << 63) if a.stream == "long" else 0
     for s in range(S):
-        seed = a.seed * 1000003 + (rank * S + s)
+        seed = style | (a.seed * 1000003 + (rank * S + (0 if a.same_shards else s)))
         d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
         ok(L.rsbwt_synth_runs_dev(ptr(d_runs), R, seed, local, sp))
         torch.cuda.synchronize()
-        slots = a.slots or "auto"  # the library builds slots only while index + slots stay within 45 % of HBM
-        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local, dir_shift=a.dir_shift,
-                       ktab_depth=None if a.ktab_depth < 0 else a.ktab_depth,
-                       slots={"auto": "auto", "on": True, "off": False}[slots], slot_span=a.slot_span)
-        if rank == 0 and s == 0 and world == 1 and a.cpu_sample > 0:
+        # tables are sized afterwards, for all shards of the GPU together (explicit depth: now)
+        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local,
+                       ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span)
+        if rank == 0 and s == 0 and a.cpu_sample > 0:
             host_runs = d_runs.cpu().numpy()
         del d_runs
+        torch.cuda.empty_cache()
         shards.append(g)
-    torch.cuda.empty_cache()
+    sset = rsb.ShardSet(shards)
+    if a.ktab_depth == 0:
+        ok(L.rsbwt_set_attach_ktabs(sset._s, 0))
     t_build = time.time() - t_build0
     n_sym = shards[0].getBWLen()
 
@@ -117,49 +142,42 @@ def main():
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     d_kmers = _lut_chunks(lut, codes)
     del codes
-    # present k-mers: every rank draws its share from its own first shard; shares are concatenated
+    # present k-mers: every rank draws its share evenly from its shards; shares are concatenated
     share = n_present // world
     if share:
-        mine = torch.empty((share, k), dtype=torch.uint8, device=dev)
-        ok(L.rsbwt_sample_present_kmers_dev(shards[0].handle, share, k, k, a.seed + 7 + rank, ptr(mine), sp))
+        per = [share // S + (1 if i < share % S else 0) for i in range(S)]
+        parts = []
+        for s, m in enumerate(per):
+            if m:
+                t = torch.empty((m, k), dtype=torch.uint8, device=dev)
+                ok(L.rsbwt_sample_present_kmers_dev(shards[s].handle, m, k, k, a.seed + 7 + rank * S + s, ptr(t), sp))
+                parts.append(t)
         torch.cuda.synchronize()
+        mine = torch.cat(parts, 0)
+        mine = mine[torch.randperm(mine.shape[0], device=dev, generator=gen)]  # the shards' k-mers interleaved
         if world > 1:
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            mine = torch.cat(parts, 0)
+            allp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allp, mine)
+            mine = torch.cat(allp, 0)
         # interleave present and random k-mers so every wave sees the mix
         idx = torch.arange(mine.shape[0], device=dev) * (Q // mine.shape[0])
         d_kmers[idx] = mine
-        del mine, idx
+        del mine, idx, parts
 
     wpq = (k + 31) // 32
     from readserver_amd import sharded
-    # Batches can alternate between two HIP streams (--streams 2), each with its own packed-query
-    # and result buffers: packing and start records of batch i + 1 then run beside the search of
-    # batch i.  With N > 1 the gather of batch i to rank 0 (RCCL) travels behind the search of
-    # batch i + 1 either way.
-    nst = a.streams
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nst)] if nst > 1 else [stream]
-    for st in streams:
-        st.wait_stream(stream)
-    d_packed = [torch.empty((Q, wpq), dtype=torch.int64, device=dev) for _ in range(nst)]
-    d_valid = [torch.empty(Q, dtype=torch.uint8, device=dev) for _ in range(nst)]
+    d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
+    d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     gat = sharded.IntervalGatherer(S, Q, dev, depth=2)
-    d_lower, d_upper = gat.pair(0)[0], gat.pair(0)[1]
     step_no = [0]
 
     def step():
         i = step_no[0]
         step_no[0] += 1
-        j = i % nst
-        with torch.cuda.stream(streams[j]):
-            spj = C.c_void_p(streams[j].cuda_stream)
-            pair = gat.acquire(i)
-            ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed[j]), ptr(d_valid[j]), local, spj))
-            for s, g in enumerate(shards):
-                ok(L.rsbwt_find_intervals_dev(g.handle, ptr(d_packed[j]), ptr(d_valid[j]), Q, k,
-                                              ptr(pair[0][s]), ptr(pair[1][s]), spj))
-            gat.submit(i)
+        pair = gat.acquire(i)
+        ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
+        ok(L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
+        gat.submit(i)
 
     def barrier():
         gat.drain()
@@ -169,21 +187,15 @@ def main():
         torch.cuda.synchronize()
 
     # ---- exact work of one step (counting mode, untimed) -----------------------------------------
-    for g in shards:
-        ok(L.rsbwt_set_counting(g.handle, 1))
+    ok(L.rsbwt_set_set_counting(sset._s, 1))
     step()
     torch.cuda.synchronize()
-    lf = oc = bl = 0
-    for g in shards:
-        x, y, z = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        ok(L.rsbwt_last_search_work(g.handle, C.byref(x), C.byref(y), C.byref(z)))
-        lf, oc, bl = lf + x.value, oc + y.value, bl + z.value
-        ph = (C.c_uint64 * 6)()
-        npass = C.c_uint64()
-        ok(L.rsbwt_last_search_phases(g.handle, ph, C.byref(npass)))
-        phases = {"passes": npass.value, "cycles_per_pass": [round(v / max(npass.value, 1)) for v in ph],
-                  "names": ["setup", "issue", "wait+park", "rank", "overflow", "update"]}
-        ok(L.rsbwt_set_counting(g.handle, 0))
+    w = (C.c_uint64 * 16)()
+    ok(L.rsbwt_set_last_search_counters(sset._s, w))
+    ok(L.rsbwt_set_set_counting(sset._s, 0))
+    lf, oc, ln, kt, hops, npass = w[0], w[1], w[2], w[3], w[11], w[10]
+    phases = {"passes": npass, "cycles_per_pass": [round(w[4 + i] / max(npass, 1)) for i in range(6)],
+              "names": ["setup", "issue", "wait", "rank", "exchange", "update"]}
 
     for _ in range(a.warmup):
         step()
@@ -194,13 +206,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # per-launch search-kernel time over the timed region: HIP events the library records on the
-    # launch stream around every search launch (it keeps the last 64 pairs per handle)
-    k_ms = []
-    for g in shards:
-        buf = (C.c_float * 64)()
-        cnt = C.c_size_t()
-        ok(L.rsbwt_search_history_ms(g.handle, buf, min(a.steps, 64), C.byref(cnt)))
-        k_ms += list(buf[:cnt.value])
+    # launch stream around every search launch (it keeps the last 64 pairs)
+    buf = (C.c_float * 64)()
+    cnt = C.c_size_t()
+    ok(L.rsbwt_set_search_history_ms(sset._s, buf, min(a.steps, 64), C.byref(cnt)))
+    k_ms = list(buf[:cnt.value])
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -210,8 +220,40 @@ def main():
     value = searches / dt
     ms_per_step = dt / a.steps * 1e3
     avg_kernel_ms = float(np.mean(k_ms))
-    alg_bytes = (bl / S) * BLOCK_BYTES + Q * (8 * wpq + 16)  # per launch (one shard)
+    alg_bytes = ln * LINE_BYTES + S * Q * SEARCH_BYTES  # per launch, the search kernel's own reads and writes
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+    # the whole step: + packing (k + 8 wpq + 1 B per query) and the start records (8-byte table read +
+    # 16 B written per search)
+    step_bytes = alg_bytes + Q * (k + 8 * wpq + 1) + S * Q * 24
+    hbm = sum(int(g.hbm_bytes()) for g in shards)
+
+    # ---- configs[1] on the same resident data: shard 0 alone (same kernel, one shard) -----------
+    single = None
+    if S > 1:
+        g0 = shards[0]
+        lo1 = torch.empty(Q, dtype=torch.int64, device=dev)
+        up1 = torch.empty(Q, dtype=torch.int64, device=dev)
+        ok(L.rsbwt_set_counting(g0.handle, 1))
+        ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+        torch.cuda.synchronize()
+        w1 = (C.c_uint64 * 16)()
+        ok(L.rsbwt_last_search_counters(g0.handle, w1))
+        ok(L.rsbwt_set_counting(g0.handle, 0))
+        for _ in range(2):
+            ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 10
+        for _ in range(n1):
+            ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t1) / n1
+        b1 = (C.c_float * 64)()
+        ok(L.rsbwt_search_history_ms(g0.handle, b1, n1, C.byref(cnt)))
+        km1 = float(np.mean(list(b1[:cnt.value])))
+        single = {"searches_per_s": Q / d1, "kernel_ms": km1, "mean_lf_steps_per_search": w1[0] / Q,
+                  "roofline_frac": (w1[2] * LINE_BYTES + Q * SEARCH_BYTES) / (km1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del lo1, up1
 
     out = {
         "metric": "31-mer backward-search queries/sec on popBWT",
@@ -229,30 +271,39 @@ def main():
         "config": {
             "workload": ("configs[1]: single BWT shard resident in one MI355X's HBM, batched 31-mer exact backward search"
                          if world == 1 and S == 1 else
-                         f"configs[2]-style: {world * S} shards over {world} GPUs, RCCL gather of intervals"),
-            "run_bytes_per_shard": R, "symbols_per_shard": int(n_sym), "shards_per_gpu": S,
+                         f"configs[2]: {world * S} of 64 suffix-shards over {world} GPU(s), {S} per GPU, exact match, "
+                         "one fused launch per GPU and batch" + (", RCCL gather of intervals to rank 0" if world > 1 else
+                                                                 " (one GPU: no gather)")),
+            "value_counts": "S/s = (query x shard) searches per second; Q/s = value / shards",
+            "queries_per_s_all_shards": value / (world * S),
+            "shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": R, "symbols_per_shard": int(n_sym),
+            "stream": a.stream + (", the same in every shard of a GPU" if a.same_shards else ""),
             "queries_per_batch": Q, "k": k, "present_fraction": a.present_frac,
-            "mean_lf_steps_per_search": lf / (S * Q), "dir_shift": shards[0].dir_shift(),
-            "ktab_depth": shards[0].ktab_depth(), "slot_span": shards[0].slot_span(),
-            "slot_overflow_blocks": int(shards[0].slot_overflow_blocks()),
-            "index_hbm_bytes_per_shard": int(shards[0].hbm_bytes()), "index_build_s": round(t_build, 2),
-            "value_counts": "query x shard searches (= queries at 1 shard)",
+            "mean_lf_steps_per_search": lf / (S * Q), "ktab_depth": shards[0].ktab_depth(),
+            "window_span": shards[0].window_span(), "far_lines_per_shard": int(shards[0].far_lines()),
+            "spilled_position_fraction": shards[0].spilled_symbols() / max(int(n_sym), 1),
+            "index_hbm_bytes_per_gpu": hbm, "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
+            "index_build_s": round(t_build, 2),
+            "multi_gpu": ("measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
+            "single_shard_check": single,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(R, Q),
-            "kernel": ("search_wave_kernel" if (shards[0].slot_span() or shards[0].dir_shift() == 8)
-                       and os.environ.get("RSBWT_SEARCH_KERNEL", "w")[0] != "o" else "search_kernel"),
-            "kernel_ms": avg_kernel_ms,
-            "algorithmic_bytes_per_launch": alg_bytes, "block_reads_per_launch": bl / S,
-            "occ_lookups_per_launch": oc / S, "phase_stamps": phases,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(R, Q, S, k, a.stream),
+            "kernel": "search_lines_kernel", "kernel_ms": avg_kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "line_reads_per_launch": ln,
+            "continuation_line_reads_per_launch": hops, "occ_lookups_per_launch": oc,
+            "ktab_starts_per_launch": kt, "phase_stamps": phases,
+            "frac_of_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
     }
 
-    if rank == 0 and world == 1 and host_runs is not None:
-        out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, d_lower[0], d_upper[0], Q, k)
+    if rank == 0 and host_runs is not None:
+        pair = gat.pair(step_no[0] - 1)
+        out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, pair[0][0], pair[1][0], Q, k)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    sset.close()
     for g in shards:
         g.close()
     if world > 1:
@@ -268,13 +319,16 @@ def _lut_chunks(lut, codes):
     return out
 
 
-def _pmc_traffic(R, Q):
+def _pmc_traffic(R, Q, S, k, stream):
     """HBM bytes per search launch from the committed rocprofv3 PMC pass of this same command
-    (profiles/<round>_pmc.json, corrected as MI355X_MICROARCH.md prescribes), or None."""
+    (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes) -- only if that pass
+    was measured on this very kernel and layout source; otherwise None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
-        if int(d["run_bytes_per_shard"]) == R and int(d["queries_per_batch"]) == Q:
+        if (d["kernel_source_sha"] == kernel_source_sha() and int(d["run_bytes_per_shard"]) == R
+                and int(d["queries_per_batch"]) == Q and int(d["shards_per_gpu"]) == S and int(d["k"]) == k
+                and d.get("stream", "mixed") == stream):
             return d["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -283,35 +337,41 @@ def _pmc_traffic(R, Q):
 
 def cpu_baseline(a, host_runs, d_kmers, d_lower, d_upper, Q, k):
     """The oracle (CPU restatement of the reference algorithm) timed on this host, on a bounded
-    sample of the same batch against the same shard; also re-checks the GPU answers."""
+    sample of the same batch against the same shard (shard 0); also re-checks the GPU answers."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding
+    import torch
     orc = oracle_binding.load()
     t0 = time.time()
     ix = orc.from_runs(host_runs)
     t_index = time.time() - t0
     m = min(int(a.cpu_sample), Q)
     sel = np.linspace(0, Q - 1, m).astype(np.int64)
-    import torch
     sel_t = torch.from_numpy(sel).to(d_kmers.device)
     km = d_kmers[sel_t].cpu().numpy()
     glo = d_lower[sel_t].cpu().numpy().view(np.uint64)
     gup = d_upper[sel_t].cpu().numpy().view(np.uint64)
-    threads = a.cpu_threads or min(os.cpu_count() or 1, 32)
+    # one thread first, cold: a disjoint sample, before the index has been walked at all
+    m1 = max(1, m // 16)
+    sel1 = torch.from_numpy((np.linspace(0, Q - 1, m1).astype(np.int64) + 7) % Q).to(d_kmers.device)
+    km1 = d_kmers[sel1].cpu().numpy()
+    t1 = time.perf_counter()
+    ix.find_intervals(km1, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    threads = a.cpu_threads or usable_cpus()
     t0 = time.perf_counter()
     lo, up = ix.find_intervals(km, nthreads=threads)
     dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    m1 = max(1, m // 16)
-    ix.find_intervals(km[:m1], nthreads=1)
-    dt1 = time.perf_counter() - t1
     match = bool(np.array_equal(lo, glo) and np.array_equal(up, gup))
     return {
         "value": m / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample": f"{m} of the batch's {Q} k-mers (evenly spaced) on the same shard; oracle/rlebwt_oracle.c, "
-                  f"{threads} POSIX threads sharing one index",
-        "single_thread_value": m1 / dt1, "host_cores": os.cpu_count(),
-        "index_build_s": round(t_index, 2), "gpu_matches_oracle_on_sample": match,
+        "sample": f"{m} of the batch's {Q} k-mers (evenly spaced) on shard 0 (one of the resident shards: per-shard "
+                  f"searches/s, to be set against S/s per shard); oracle/rlebwt_oracle.c, {threads} POSIX threads sharing "
+                  f"one index = every CPU this process may run on",
+        "single_thread_value": m1 / dt1,
+        "single_thread_sample": f"{m1} other k-mers, run first on the cold index",
+        "host_cpus_visible": os.cpu_count(), "index_build_s": round(t_index, 2),
+        "gpu_matches_oracle_on_sample": match,
     }
 
 

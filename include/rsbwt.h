@@ -40,32 +40,24 @@ extern "C" {
 #define RSBWT_ENOMEM (-4)  /* host or HBM allocation failed                  */
 #define RSBWT_ENODEV (-5)  /* no usable HIP device                           */
 #define RSBWT_EHIP (-6)    /* a HIP runtime call failed (see rsbwt_last_error) */
-#define RSBWT_ERANGE (-7)  /* shard exceeds format limits (2^40 symbols)     */
+#define RSBWT_ERANGE (-7)  /* shard exceeds format limits (2^40 symbols) / buffer too small */
 
 /* open flags */
-#define RSBWT_DIR_SHIFT_AUTO 0u /* low 5 bits: log2 symbols per directory window, 0 = auto */
-#define RSBWT_DIR_SHIFT_MASK 0x1Fu
-/* bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
+/* bits 0..4: reserved (0).
+ * bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
  * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (the deepest table
- * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n), 31 = no
- * table, else T = 2..16 (T = 16: 34 GB). */
+ * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n; rsbwt_set_open
+ * sizes the tables of one GPU's shards together), 31 = no table, else T = 2..16 (T = 16: 34 GB). */
 #define RSBWT_KTAB_SHIFT 5
 #define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_DEPTH(t) ((uint32_t)(t) << RSBWT_KTAB_SHIFT)
-/* bits 10..11: the single-request search layout ("slots": fixed-span blocks addressed from the
- * position, one HBM request per Occ lookup instead of two; up to twice the size of the index and
- * kept next to it).  AUTO builds it when index + slots stay within ~45 % of the device's HBM and
- * the allocation succeeds -- right for one shard per GPU; open many shards per GPU with OFF.
- * bits 12..23: symbols per slot (0 = chosen from the data: the largest span that leaves at most
- * 1 window in 1000 in need of an overflow block). */
-#define RSBWT_SLOTS_SHIFT 10
-#define RSBWT_SLOTS_AUTO (0u << RSBWT_SLOTS_SHIFT)
-#define RSBWT_SLOTS_ON (1u << RSBWT_SLOTS_SHIFT)
-#define RSBWT_SLOTS_OFF (2u << RSBWT_SLOTS_SHIFT)
-#define RSBWT_SLOTS_MASK (3u << RSBWT_SLOTS_SHIFT)
-#define RSBWT_SLOT_SPAN_SHIFT 12
-#define RSBWT_SLOT_SPAN_MASK (0xFFFu << RSBWT_SLOT_SPAN_SHIFT)
+/* bits 12..23: symbols per window of the HBM layout (one 128-byte line per window, so that an Occ
+ * lookup is a single request); 0 = chosen from the data: ~88 run pieces per window, shrunk while
+ * more than 2.5 % of the positions would lie past their window's line.  2..2944. */
+#define RSBWT_SPAN_SHIFT 12
+#define RSBWT_SPAN_MASK (0xFFFu << RSBWT_SPAN_SHIFT)
+#define RSBWT_SPAN(s) ((uint32_t)(s) << RSBWT_SPAN_SHIFT)
 
 typedef struct rsbwt rsbwt_t;         /* one BWT shard resident in one GPU's HBM */
 typedef struct rsbwt_set rsbwt_set_t; /* several shards on this process's GPU(s) */
@@ -107,12 +99,14 @@ int rsbwt_occ_at_batch(rsbwt_t *h, const char *b, const uint64_t *bc, size_t n, 
 /* Shape of the resident index */
 uint64_t rsbwt_num_runs(const rsbwt_t *h);
 uint64_t rsbwt_num_strings(const rsbwt_t *h);
-uint64_t rsbwt_num_blocks(const rsbwt_t *h);
-uint32_t rsbwt_dir_shift(const rsbwt_t *h);
-uint32_t rsbwt_ktab_depth(const rsbwt_t *h); /* 0 = no k-mer table */
-uint32_t rsbwt_slot_span(const rsbwt_t *h);  /* symbols per slot, 0 = slots not built */
-uint64_t rsbwt_slot_overflow_blocks(const rsbwt_t *h);
-uint64_t rsbwt_hbm_bytes(const rsbwt_t *h); /* blocks + directory + tables */
+uint64_t rsbwt_num_lines(const rsbwt_t *h);       /* 128-byte lines of the index in HBM */
+uint32_t rsbwt_ktab_depth(const rsbwt_t *h);      /* 0 = no k-mer table */
+uint32_t rsbwt_window_span(const rsbwt_t *h);     /* symbols per window */
+uint64_t rsbwt_far_lines(const rsbwt_t *h);       /* lines that continue windows of > 120 pieces */
+uint64_t rsbwt_spilled_symbols(const rsbwt_t *h); /* positions one request past their window's line */
+uint64_t rsbwt_hbm_bytes(const rsbwt_t *h);       /* lines + tables */
+/* Builds the k-mer table of depth T (2..16) of an open handle that has none. */
+int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 int rsbwt_device(const rsbwt_t *h);
 
 /* query.h mirrors, batched (include/bwt/query.h:18-32) ---------------------------------
@@ -133,6 +127,8 @@ int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stri
  * invalid as a whole (every column lower = 1, upper = 0). */
 int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                              uint64_t *lower, uint64_t *upper);
+
+/* (device-resident searches need 1 <= k <= 65535) */
 
 /* The same search with the output SURVEY 8 f3 defines: only the variants that occur, as a list
  * sorted by (query, pos, base).  The dense [Q][3k+1] matrices above are mostly empty intervals
@@ -156,6 +152,20 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
 int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride,
                   uint32_t *len, uint32_t *prefix_len);
 
+/* query.cpp:102-120  bool query_exactmatch(const BWT*, const string& w), batched: found[q] = 1 when
+ * k-mer q is itself one of the indexed reads (w == extractPrefix(i) + extractPostfix(i) for a row i
+ * of its interval), else 0 -- also for a string holding a symbol outside ACGT (query.cpp:103-105). */
+int rsbwt_query_exactmatch(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                           uint8_t *found);
+/* query.cpp:87-100  vector<string> query(const BWT*, const string& w), batched: every read that
+ * contains k-mer q, in SA-row order (extractPrefix(i) + extractPostfix(i) for i = lower..upper).
+ * first[Q+1] receives the offsets of each k-mer's reads in the output (first[Q] = their number, also
+ * stored in *nreads); read r is the read_len[r] bytes at reads + r*read_stride (UINT32_MAX: longer
+ * than read_stride).  RSBWT_ERANGE with *nreads set and nothing extracted when cap_reads is too
+ * small: call once with cap_reads = 0 to size the buffers. */
+int rsbwt_query(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
+                char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads);
+
 /* Device-resident forms: all pointers are HBM addresses on the handle's device, `stream` is a
  * hipStream_t (NULL = the null stream).  Nothing is synchronised. ------------------------ */
 /* ASCII k-mers -> 2-bit packed words (A,C,G,T = 0..3, symbol i at bits 2*(i%32) of word i/32,
@@ -175,10 +185,15 @@ int rsbwt_last_search_ms(rsbwt_t *h, float *ms);
 int rsbwt_search_history_ms(rsbwt_t *h, float *ms, size_t cap, size_t *count);
 /* Exact work counters of the last rsbwt_find_intervals_dev launch when the handle was put
  * in counting mode with rsbwt_set_counting(h, 1): LF steps taken, Occ lookups made, distinct
- * blocks those lookups read.  Counting mode costs atomics; leave it off when timing. */
+ * window lines those lookups read (one 128-byte request each; a lookup whose position lies past
+ * its window's line costs one more request, counted apart: word 11 of the counters below).
+ * Counting mode costs atomics; leave it off when timing. */
 int rsbwt_set_counting(rsbwt_t *h, int on);
 int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups,
-                           uint64_t *block_reads);
+                           uint64_t *line_reads);
+/* all 16 counter words: 0 LF steps, 1 Occ lookups, 2 window lines read, 3 k-mer-table starts,
+ * 4..9 phase cycles, 10 passes, 11 continuation (spill / far) lines read */
+int rsbwt_last_search_counters(rsbwt_t *h, uint64_t *words16);
 /* ... and the number of k-mer-table lookups of that launch. */
 int rsbwt_last_search_ktab_lookups(rsbwt_t *h, uint64_t *lookups);
 /* ... and, for the wave kernel, shader cycles (s_memtime, summed over waves) spent in the six
@@ -188,7 +203,10 @@ int rsbwt_last_search_phases(rsbwt_t *h, uint64_t *cycles6, uint64_t *passes);
 
 /* Synthetic data (bench / tests) ----------------------------------------------- */
 /* Fill d_runs (HBM) with num_runs pseudo-random RLUnit bytes: the direct run-stream
- * synthesiser for throughput runs.  Same bytes as rsbwt_synth_runs_host for the same seed. */
+ * synthesiser for throughput runs.  Same bytes as rsbwt_synth_runs_host for the same seed.
+ * Seeds with bit 63 set (RSBWT_SYNTH_LONG_RUNS | seed) give the long-run stream: mostly 31-symbol
+ * units of long runs, mean ~25 symbols per unit, as in a deep population BWT. */
+#define RSBWT_SYNTH_LONG_RUNS (1ull << 63)
 int rsbwt_synth_runs_dev(void *d_runs, uint64_t num_runs, uint64_t seed, int device, void *stream);
 int rsbwt_synth_runs_host(uint8_t *runs, uint64_t num_runs, uint64_t seed);
 /* Draw Q k-mers that are present in the index (LF walks from random rows, so every one of the
@@ -215,19 +233,43 @@ int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path);
 int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
                      uint64_t *mismatches);
 
-/* Shard sets: the shards of one process, searched with one call ------------------ */
+/* Shard sets: the shards one process holds on its GPU(s), searched with one call ------
+ * Every query goes to every shard (src/service/server.cpp:124,578).  The shards of one device are
+ * searched by ONE fused launch -- the batch is uploaded and packed once per device -- and devices
+ * are driven concurrently.  device_map[i] = HIP device of shard i (NULL: all on device 0); the
+ * deployment SURVEY 8e describes is shard s -> GPU s / 8. */
 int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
                    uint32_t flags, rsbwt_set_t **out);
 int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out);
 void rsbwt_set_close(rsbwt_set_t *s); /* closes the shards it opened itself */
 size_t rsbwt_set_size(const rsbwt_set_t *s);
+size_t rsbwt_set_devices(const rsbwt_set_t *s);
 rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
+/* k-mer tables for the shards that have none; depth 0 = sized per device from its free HBM */
+int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth);
 /* lower/upper: [num_shards][Q]; counts: [Q] summed over shards, the way the front-end sums
- * per-partition replies (src/service/server.cpp:184-197). */
+ * per-partition replies (src/service/server.cpp:184-197).  With several devices the per-device sums
+ * are reduced onto the first device over RCCL (ncclReduce) and cross PCIe once. */
 int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k,
                              size_t stride, uint64_t *lower, uint64_t *upper);
 int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
                     uint64_t *counts);
+/* Device-resident forms for a set on ONE device: one fused launch on `stream`, nothing synchronised.
+ * d_lower/d_upper/d_counts: [num_shards][Q]. */
+int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q,
+                                 uint32_t k, void *d_lower, void *d_upper, void *stream);
+int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                        void *d_counts, void *stream);
+/* Gathers per-device result blocks onto the set's first device over RCCL / xGMI (ncclSend/ncclRecv in
+ * one group): d_blocks[g], bytes[g], streams[g] belong to device g of the set; d_root (first device)
+ * receives the blocks back to back.  For GPU-resident consumers of all shards' intervals. */
+int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes,
+                                   void *d_root, void *const *streams);
+int rsbwt_rccl_available(void); /* 1 when librccl could be bound at run time */
+/* measurement hooks of a set's fused launches (first device): as the per-handle ones */
+int rsbwt_set_set_counting(rsbwt_set_t *s, int on);
+int rsbwt_set_search_history_ms(rsbwt_set_t *s, float *ms, size_t cap, size_t *count);
+int rsbwt_set_last_search_counters(rsbwt_set_t *s, uint64_t *words16);
 
 /* Service slice: the CountReads / ExactMatch-Count path of the query service --------
  * rsbwt_service_counts replaces, for a batch of serialised `Request` messages
@@ -244,6 +286,13 @@ int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, const uint64
 int rsbwt_proto_decode_request(const uint8_t *msg, size_t len, int *t, int *rt, const char **q, size_t *qlen);
 size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen,
                                       int revcomp, int32_t c);
+
+/* Test hook (host only, answers no query): lays `runs` out as window lines with the code the GPU
+ * builder runs and holds the layout's scalar readers to naive ranks at every position.  stats6 =
+ * {S, lines, far lines, chunk windows, far windows, spilled symbols}; *first_bad = first position
+ * that disagrees (RSBWT_EFORMAT) or UINT64_MAX. */
+int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
+                               uint64_t *stats6, uint64_t *first_bad);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@
 class GpuBWT : public BWT {
  public:
   explicit GpuBWT(const std::string& filename, int device = 0) : h_(nullptr) {
-    if (rsbwt_open(filename.c_str(), device, RSBWT_DIR_SHIFT_AUTO, &h_) != RSBWT_OK)
+    if (rsbwt_open(filename.c_str(), device, 0u, &h_) != RSBWT_OK)
       throw std::runtime_error(rsbwt_last_error());
   }
   ~GpuBWT() { rsbwt_close(h_); }  // NB: class BWT has no virtual destructor (bwt.h:6-15)

@@ -76,4 +76,25 @@ size_t ref_extract(void *h, uint64_t row, char *out, size_t cap, size_t *prefix_
     return s.size();
 }
 
+// query(pBWT, w) (src/bwt/query.cpp:87-100): the reads containing w, in the order the reference
+// returns them, '\n'-terminated into out; returns the bytes needed, *count = number of reads.
+size_t ref_query(void *h, const char *w, size_t len, char *out, size_t cap, size_t *count) {
+    const std::vector<std::string> seqs = query(static_cast<RLEBWT *>(h), std::string(w, len));
+    size_t need = 0;
+    for (const std::string &s : seqs) {
+        if (need + s.size() + 1 <= cap) {
+            memcpy(out + need, s.data(), s.size());
+            out[need + s.size()] = '\n';
+        }
+        need += s.size() + 1;
+    }
+    if (count) *count = seqs.size();
+    return need;
+}
+
+// query_exactmatch(pBWT, w) (src/bwt/query.cpp:102-120)
+int ref_query_exactmatch(void *h, const char *w, size_t len) {
+    return query_exactmatch(static_cast<RLEBWT *>(h), std::string(w, len)) ? 1 : 0;
+}
+
 }  // extern "C"

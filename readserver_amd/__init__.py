@@ -20,7 +20,9 @@ from .bwt import (  # noqa: F401
     hits_1mm_batch,
     findInterval,
     query,
+    query_batch,
     query_exactmatch,
+    query_exactmatch_batch,
     synth_popbwt,
     write_bpi2,
     check_bpi2,

@@ -59,18 +59,22 @@ SIGNATURES = {
     "rsbwt_occ_at_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "rsbwt_num_runs": (C.c_uint64, [_vp]),
     "rsbwt_num_strings": (C.c_uint64, [_vp]),
-    "rsbwt_num_blocks": (C.c_uint64, [_vp]),
-    "rsbwt_dir_shift": (C.c_uint32, [_vp]),
+    "rsbwt_num_lines": (C.c_uint64, [_vp]),
     "rsbwt_ktab_depth": (C.c_uint32, [_vp]),
-    "rsbwt_slot_span": (C.c_uint32, [_vp]),
-    "rsbwt_slot_overflow_blocks": (C.c_uint64, [_vp]),
+    "rsbwt_window_span": (C.c_uint32, [_vp]),
+    "rsbwt_far_lines": (C.c_uint64, [_vp]),
+    "rsbwt_spilled_symbols": (C.c_uint64, [_vp]),
     "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
+    "rsbwt_attach_ktab": (C.c_int, [_vp, C.c_uint32]),
     "rsbwt_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
     "rsbwt_find_intervals_1mm": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_hits_1mm": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_extract": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp]),
+    "rsbwt_query_exactmatch": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
+    "rsbwt_query": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_uint32, _vp, C.c_size_t,
+                              C.POINTER(C.c_size_t)]),
     "rsbwt_pack_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "rsbwt_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
@@ -78,6 +82,7 @@ SIGNATURES = {
     "rsbwt_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_counting": (C.c_int, [_vp, C.c_int]),
     "rsbwt_last_search_work": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
+    "rsbwt_last_search_counters": (C.c_int, [_vp, _u64p]),
     "rsbwt_last_search_phases": (C.c_int, [_vp, _u64p, _u64p]),
     "rsbwt_last_search_ktab_lookups": (C.c_int, [_vp, _u64p]),
     "rsbwt_synth_runs_dev": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _vp]),
@@ -95,6 +100,16 @@ SIGNATURES = {
     "rsbwt_set_from_handles": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.POINTER(_vp)]),
     "rsbwt_set_close": (None, [_vp]),
     "rsbwt_set_size": (C.c_size_t, [_vp]),
+    "rsbwt_set_devices": (C.c_size_t, [_vp]),
+    "rsbwt_set_attach_ktabs": (C.c_int, [_vp, C.c_uint32]),
+    "rsbwt_set_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
+    "rsbwt_set_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_set_gather_intervals_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), _vp, C.POINTER(_vp)]),
+    "rsbwt_rccl_available": (C.c_int, []),
+    "rsbwt_set_set_counting": (C.c_int, [_vp, C.c_int]),
+    "rsbwt_set_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rsbwt_set_last_search_counters": (C.c_int, [_vp, _u64p]),
+    "rsbwt_layout_selftest_host": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u64p, _u64p]),
     "rsbwt_set_shard": (_vp, [_vp, C.c_size_t]),
     "rsbwt_set_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_set_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),

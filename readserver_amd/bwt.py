@@ -46,15 +46,13 @@ class GpuBWT:
     """
 
     def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
-                 dir_shift=0, ktab_depth=0, slots="auto", slot_span=0):
-        """dir_shift: log2 symbols per directory window (0 = auto).  ktab_depth: depth of the k-mer
-        table (0 = auto, None = no table).  slots: "auto" | True | False -- the single-request
-        search layout; slot_span: symbols per slot (0 = from the mean run length)."""
+                 ktab_depth=0, window_span=0):
+        """ktab_depth: depth of the k-mer table (0 = auto, None = no table).  window_span: symbols
+        per window of the HBM layout (0 = from the data: ~88 run pieces per 128-byte line)."""
         self._h = C.c_void_p()
         L = lib()
-        flags = (int(dir_shift) & 0x1F) | ((31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5)
-        flags |= {"auto": 0, True: 1, False: 2}[slots] << 10
-        flags |= (int(slot_span) & 0xFFF) << 12
+        flags = (31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5
+        flags |= (int(window_span) & 0xFFF) << 12
         if filename is not None:
             check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
         elif runs is not None:
@@ -149,20 +147,20 @@ class GpuBWT:
     def num_strings(self):
         return lib().rsbwt_num_strings(self._h)
 
-    def num_blocks(self):
-        return lib().rsbwt_num_blocks(self._h)
-
-    def dir_shift(self):
-        return lib().rsbwt_dir_shift(self._h)
+    def num_lines(self):
+        return lib().rsbwt_num_lines(self._h)
 
     def ktab_depth(self):
         return lib().rsbwt_ktab_depth(self._h)
 
-    def slot_span(self):
-        return lib().rsbwt_slot_span(self._h)
+    def window_span(self):
+        return lib().rsbwt_window_span(self._h)
 
-    def slot_overflow_blocks(self):
-        return lib().rsbwt_slot_overflow_blocks(self._h)
+    def far_lines(self):
+        return lib().rsbwt_far_lines(self._h)
+
+    def spilled_symbols(self):
+        return lib().rsbwt_spilled_symbols(self._h)
 
     def hbm_bytes(self):
         return lib().rsbwt_hbm_bytes(self._h)
@@ -285,24 +283,51 @@ def extract_reads(pBWT, rows, stride=512):
     return [out[i, :ln[i]].tobytes().decode() for i in range(r.size)], pl
 
 
+def query_batch(pBWT, kmers, read_stride=256):
+    """Batched query (query.cpp:87-100) through rsbwt_query: a list, per k-mer, of the reads that
+    contain it, in SA-row order."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    first = np.zeros(Q + 1, np.uint64)
+    n = C.c_size_t()
+    rc = lib().rsbwt_query(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(first), None, read_stride, None, 0, C.byref(n))
+    if rc not in (0, -7):
+        check(rc)
+    total = n.value
+    reads = np.zeros((max(total, 1), read_stride), np.uint8)
+    ln = np.zeros(max(total, 1), np.uint32)
+    if total:
+        check(lib().rsbwt_query(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(first), _ptr(reads), read_stride, _ptr(ln),
+                                total, C.byref(n)))
+        if (ln[:total] == 0xFFFFFFFF).any():
+            raise RsbwtError(-1, "a read does not fit read_stride")
+    out = []
+    for q in range(Q):
+        out.append([reads[r, :ln[r]].tobytes().decode() for r in range(int(first[q]), int(first[q + 1]))])
+    return out
+
+
+def query_exactmatch_batch(pBWT, kmers):
+    """Batched query_exactmatch (query.cpp:102-120) through rsbwt_query_exactmatch: bool array."""
+    a, k = _kmer_matrix(kmers)
+    Q = a.shape[0]
+    found = np.zeros(Q, np.uint8)
+    check(lib().rsbwt_query_exactmatch(pBWT.handle, _ptr(a), Q, k, max(k, 1), _ptr(found)))
+    return found.astype(bool)
+
+
 def query(pBWT, w):
-    """query.cpp:87-100: every read containing w."""
-    if any(c not in "ACGT" for c in w):
+    """vector<string> query(const BWT*, const string& w) (query.cpp:87-100): every read containing w."""
+    if len(w) == 0:
         return []
-    itv = findInterval(pBWT, w)
-    if itv.lower > itv.upper:
-        return []
-    return extract_reads(pBWT, np.arange(itv.lower, itv.upper + 1, dtype=np.uint64))[0]
+    return query_batch(pBWT, [w])[0]
 
 
 def query_exactmatch(pBWT, w):
-    """query.cpp:102-120: is w itself one of the reads."""
-    if any(c not in "ACGT" for c in w):
+    """bool query_exactmatch(const BWT*, const string& w) (query.cpp:102-120): is w itself a read."""
+    if len(w) == 0:
         return False
-    itv = findInterval(pBWT, w)
-    if itv.lower > itv.upper:
-        return False
-    return w in extract_reads(pBWT, np.arange(itv.lower, itv.upper + 1, dtype=np.uint64))[0]
+    return bool(query_exactmatch_batch(pBWT, [w])[0])
 
 
 # ---- shard sets (SURVEY 8e) -----------------------------------------------------------------

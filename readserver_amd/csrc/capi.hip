@@ -6,19 +6,22 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/rsbwt.h"
-#include "block_format.h"
 #include "bpi2.h"
 #include "bwt_file.h"
+#include "capi_internal.h"
 #include "kernels.h"
+#include "line_format.h"
 
 using namespace rsb;
 
-namespace {
+namespace rsb {
 
 thread_local char g_err[512] = "";
 
@@ -31,14 +34,9 @@ int fail(int code, const char *fmt, ...) {
 }
 
 int fail_hip(hipError_t e, const char *what) {
+    if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "%s: out of HBM", what);
     return fail(RSBWT_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
-
-#define HIP_OK(x)                                              \
-    do {                                                       \
-        hipError_t _e = (x);                                   \
-        if (_e != hipSuccess) return fail_hip(_e, #x);         \
-    } while (0)
 
 int use_device(int device) {
     int n = 0;
@@ -50,48 +48,110 @@ int use_device(int device) {
     return RSBWT_OK;
 }
 
+// ---- per-call contexts: a stream pair + staging buffer, so that concurrent host callers of one
+// handle (the reference shares one BWT* across its pool threads, service.cpp:1513,1532-1569) run
+// side by side instead of queueing on one lock.  At most MAX_CTX per handle; further callers wait.
+call_ctx *ctx_pool::acquire() {
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+        if (!free_.empty()) {
+            call_ctx *c = free_.back();
+            free_.pop_back();
+            return c;
+        }
+        if (created < MAX_CTX) {
+            ++created;
+            lock.unlock();
+            call_ctx *c = new (std::nothrow) call_ctx();
+            if (c) {
+                if (hipStreamCreateWithFlags(&c->st[0], hipStreamNonBlocking) != hipSuccess ||
+                    hipStreamCreateWithFlags(&c->st[1], hipStreamNonBlocking) != hipSuccess) {
+                    if (c->st[0]) (void)hipStreamDestroy(c->st[0]);
+                    delete c;
+                    c = nullptr;
+                }
+            }
+            if (!c) {
+                lock.lock();
+                --created;
+                if (created == 0) return nullptr;  // not even one context: report it
+                continue;
+            }
+            return c;
+        }
+        cv.wait(lock);
+    }
+}
+
+void ctx_pool::release(call_ctx *c) {
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        free_.push_back(c);
+    }
+    cv.notify_one();
+}
+
+void ctx_pool::destroy() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (call_ctx *c : free_) {
+        (void)hipStreamSynchronize(c->st[0]);
+        (void)hipStreamSynchronize(c->st[1]);
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        (void)hipStreamDestroy(c->st[0]);
+        (void)hipStreamDestroy(c->st[1]);
+        delete c;
+    }
+    free_.clear();
+    created = 0;
+}
+
+int call_ctx::stage(size_t bytes) {
+    if (bytes <= stage_bytes) return RSBWT_OK;
+    if (d_stage) {
+        (void)hipStreamSynchronize(st[0]);
+        (void)hipStreamSynchronize(st[1]);
+        (void)hipFree(d_stage);
+    }
+    d_stage = nullptr;
+    stage_bytes = 0;
+    hipError_t e = hipMalloc(&d_stage, bytes);
+    if (e != hipSuccess) return fail(RSBWT_ENOMEM, "hipMalloc(%zu) for staging: %s", bytes, hipGetErrorString(e));
+    stage_bytes = bytes;
+    return RSBWT_OK;
+}
+
+}  // namespace rsb
+
+namespace {
+
+#define HIP_OK(x)                                              \
+    do {                                                       \
+        hipError_t _e = (x);                                   \
+        if (_e != hipSuccess) return fail_hip(_e, #x);         \
+    } while (0)
+
 inline uint32_t words_per_kmer(uint32_t k) { return k ? (k + 31u) / 32u : 1u; }
+
+struct ctx_guard {
+    ctx_pool &pool;
+    call_ctx *c;
+    explicit ctx_guard(ctx_pool &p) : pool(p), c(p.acquire()) {}
+    ~ctx_guard() { pool.release(c); }
+};
+
+// (re)publishes the handle's view for kernels that take it from device memory
+int upload_view(rsbwt_t *h) {
+    if (!h->d_view) HIP_OK(hipMalloc(&h->d_view, sizeof(shard_view)));
+    HIP_OK(hipMemcpy(h->d_view, &h->view, sizeof(shard_view), hipMemcpyHostToDevice));
+    return RSBWT_OK;
+}
 
 }  // namespace
 
-struct rsbwt {
-    int device = 0;
-    int num_cus = 256;
-    rsbwt_view view;
-    slot_view slots = {};
-    uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
-    hipStream_t stream = nullptr;  // host-buffer calls run here
-    hipStream_t stream2 = nullptr; // ... and here: consecutive slices of a big host batch alternate
-    static constexpr int RING = 64;  // HIP-event pairs of the most recent search launches
-    hipEvent_t ev_start[RING] = {}, ev_stop[RING] = {};
-    uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
-    bool counting = false;
-    unsigned long long *d_work = nullptr;  // 4 counters: LF steps, Occ lookups, block reads, k-table lookups
-    std::recursive_mutex mu;
-    void *d_stage = nullptr;
-    size_t stage_bytes = 0;
-    uint32_t *d_sel = nullptr;  // sampled select table, built on the first extraction
-
-    int stage(size_t bytes) {
-        if (bytes <= stage_bytes) return RSBWT_OK;
-        if (d_stage) (void)hipFree(d_stage);
-        d_stage = nullptr;
-        stage_bytes = 0;
-        hipError_t e = hipMalloc(&d_stage, bytes);
-        if (e != hipSuccess) return fail(RSBWT_ENOMEM, "hipMalloc(%zu) for staging: %s", bytes, hipGetErrorString(e));
-        stage_bytes = bytes;
-        return RSBWT_OK;
-    }
-};
-
-struct rsbwt_set {
-    std::vector<rsbwt_t *> shards;
-    bool owns = false;
-};
-
 extern "C" {
 
-const char *rsbwt_version(void) { return "rsbwt 0.1 (gfx950)"; }
+const char *rsbwt_version(void) { return "rsbwt 0.2 (gfx950, window lines)"; }
 
 int rsbwt_device_count(void) {
     int n = 0;
@@ -117,6 +177,33 @@ const char *rsbwt_strerror(int code) {
 
 // ---- lifetime -------------------------------------------------------------------------------
 
+// Builds the k-mer table of depth T (2..16) for an open handle that has none.
+int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (h->view.ktab || h->view.n == 0) return RSBWT_OK;
+    if (T < 2u) T = 2;
+    if (T > 16u) T = 16;  // 8 B * 4^16 = 34 GB
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    uint64_t *d_tab = nullptr;
+    const uint64_t bytes = 8ull << (2u * T);
+    hipError_t e = hipMalloc(&d_tab, bytes);
+    if (e == hipSuccess) {
+        e = build_ktable(h->view, T, d_tab, h->num_cus, g.c->st[0]);
+        if (e != hipSuccess) (void)hipFree(d_tab);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_hip(e, "building the k-mer table");
+    }
+    h->view.ktab = d_tab;
+    h->view.ktab_depth = T;
+    h->hbm_bytes += bytes;
+    return upload_view(h);
+}
+
 static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
                        uint32_t flags, rsbwt_t **out) {
     rsbwt_t *h = new (std::nothrow) rsbwt();
@@ -128,10 +215,9 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         h->num_cus = prop.multiProcessorCount;
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&h->d_work, 16 * sizeof(unsigned long long))) != hipSuccess) {
+    if ((e = hipMalloc(&h->d_work, WORK_WORDS * sizeof(unsigned long long))) != hipSuccess) {
         rsbwt_close(h);
-        return fail_hip(e, "creating stream/events");
+        return fail_hip(e, "allocating counters");
     }
     for (int i = 0; i < rsbwt::RING; ++i) {
         if ((e = hipEventCreate(&h->ev_start[i])) != hipSuccess ||
@@ -141,58 +227,40 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         }
     }
     build_result br;
-    int range_error = 0;
-    e = build_device_index(d_runs, num_runs, flags & RSBWT_DIR_SHIFT_MASK, h->stream, &br, &range_error);
-    if (e != hipSuccess) {
-        rsbwt_close(h);
-        if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the index");
-        return fail_hip(e, "build_device_index");
+    int berr = 0;
+    {
+        ctx_guard g(h->pool);
+        if (!g.c) { rsbwt_close(h); return fail(RSBWT_EHIP, "cannot create a HIP stream"); }
+        const uint32_t want_span = (flags & RSBWT_SPAN_MASK) >> RSBWT_SPAN_SHIFT;
+        e = build_lines(d_runs, num_runs, want_span, g.c->st[0], &br, &berr);
     }
-    if (range_error) {
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         rsbwt_close(h);
-        return fail(RSBWT_ERANGE, "shard too large: at most 2^40 symbols and 2^32 blocks");
+        return fail_hip(e, "building the index");
+    }
+    if (berr == BUILD_ERANGE) {
+        rsbwt_close(h);
+        return fail(RSBWT_ERANGE, "shard too large: at most 2^40 symbols and 2^32 lines");
+    }
+    if (berr == BUILD_EFORMAT) {
+        rsbwt_close(h);
+        return fail(RSBWT_EFORMAT, "run byte with a symbol code above 4 ($ACGT = 0..4, include/bwt/alphabet.h:8-9)");
     }
     h->view = br.view;
     h->num_runs = br.num_runs;
     h->hbm_bytes = br.hbm_bytes;
-    // single-request search layout: on request, or (auto) when it is affordable and fits
-    {
-        const uint32_t mode = flags & RSBWT_SLOTS_MASK;
-        const uint32_t want_S = (flags & RSBWT_SLOT_SPAN_MASK) >> RSBWT_SLOT_SPAN_SHIFT;
-        bool build = mode == RSBWT_SLOTS_ON;
-        slot_params sp;
-        if (mode == RSBWT_SLOTS_AUTO && h->view.n > 0 && choose_slot_span(h->view.n, h->num_runs, want_S, &sp)) {
-            size_t free_b = 0, total_b = 0;
-            // the builder may shrink the span by a step or two (slots.hip): allow for 1.4x the
-            // starting estimate.  Index + slots within 45 % of the device leaves room for the k-mer
-            // table and the batch buffers with one shard per GPU.
-            const uint64_t est = sp.nslots * RSBWT_BLOCK_BYTES * 7 / 5;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                build = (h->hbm_bytes + est) <= total_b * 45 / 100 && est <= free_b / 2;
-        }
-        if (build && h->view.n > 0) {
-            uint64_t bytes = 0;
-            int rerr = 0;
-            e = build_slots(h->view, h->num_runs, want_S, h->stream, &h->slots, &bytes, &rerr);
-            if (e != hipSuccess || rerr) {
-                h->slots = slot_view{};
-                (void)hipGetLastError();
-                if (mode == RSBWT_SLOTS_ON) {
-                    rsbwt_close(h);
-                    if (rerr) return fail(RSBWT_ERANGE, "slot layout does not fit this shard (2^32 blocks, span < 4096)");
-                    if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the slot layout");
-                    return fail_hip(e, "build_slots");
-                }
-            } else {
-                h->hbm_bytes += bytes;
-            }
-        }
-    }
+    h->far_lines = br.far_lines;
+    h->chunk_windows = br.chunk_windows;
+    h->far_windows = br.far_windows;
+    h->spilled_symbols = br.spilled_symbols;
+    int rc = upload_view(h);
+    if (rc) { rsbwt_close(h); return rc; }
     // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries take no more
     // HBM than the index itself and no more than a quarter of what is still free (HBM is there
     // to be used: every level replaces one LF step, two Occ lookups, of each query by the same
     // single 8-byte read), and whose T-mers still have ~1 expected occurrence (4^T <= n).
-    // 8 B * 4^16 = 34 GB is the ceiling.
+    // 8 B * 4^16 = 34 GB is the ceiling.  (rsbwt_set_open sizes the tables of its shards together.)
     uint32_t T = (flags & RSBWT_KTAB_MASK) >> RSBWT_KTAB_SHIFT;
     if (T == 31u || h->view.n == 0) T = 0;
     else if (T == 0u) {
@@ -202,24 +270,10 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         T = 1;
         while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= h->view.n) ++T;
         if (T < 2u) T = 0;
-    } else if (T < 2u) T = 2;
-    if (T > 16u) T = 16;  // 8 B * 4^16 = 34 GB
+    }
     if (T) {
-        uint64_t *d_tab = nullptr;
-        const uint64_t bytes = 8ull << (2u * T);
-        e = hipMalloc(&d_tab, bytes);
-        if (e == hipSuccess) {
-            e = build_ktable(h->view, &h->slots, T, d_tab, h->num_cus, h->stream);
-            if (e != hipSuccess) (void)hipFree(d_tab);
-        }
-        if (e != hipSuccess) {
-            rsbwt_close(h);
-            if (e == hipErrorOutOfMemory) return fail(RSBWT_ENOMEM, "HBM allocation failed while building the k-mer table");
-            return fail_hip(e, "build_ktable");
-        }
-        h->view.ktab = d_tab;
-        h->view.ktab_depth = T;
-        h->hbm_bytes += bytes;
+        rc = rsbwt_attach_ktab(h, T);
+        if (rc) { rsbwt_close(h); return rc; }
     }
     *out = h;
     return RSBWT_OK;
@@ -304,20 +358,16 @@ int rsbwt_open(const char *bwt_path, int device, uint32_t flags, rsbwt_t **out) 
 void rsbwt_close(rsbwt_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->view.blocks) (void)hipFree((void *)h->view.blocks);
-    if (h->view.dir) (void)hipFree((void *)h->view.dir);
+    h->pool.destroy();
+    if (h->view.lines) (void)hipFree((void *)h->view.lines);
     if (h->view.ktab) (void)hipFree((void *)h->view.ktab);
-    if (h->slots.slots) (void)hipFree((void *)h->slots.slots);
+    if (h->d_view) (void)hipFree(h->d_view);
     if (h->d_sel) (void)hipFree(h->d_sel);
-    if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     for (int i = 0; i < rsbwt::RING; ++i) {
         if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
         if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
     }
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
 }
 
@@ -334,15 +384,34 @@ char rsbwt_f(const rsbwt_t *h, uint64_t index) {
 }
 uint64_t rsbwt_num_runs(const rsbwt_t *h) { return h->num_runs; }
 uint64_t rsbwt_num_strings(const rsbwt_t *h) { return h->num_strings; }
-uint64_t rsbwt_num_blocks(const rsbwt_t *h) { return h->view.nblocks; }
-uint32_t rsbwt_dir_shift(const rsbwt_t *h) { return h->view.dir_shift; }
+uint64_t rsbwt_num_lines(const rsbwt_t *h) { return h->view.nlines; }
 uint32_t rsbwt_ktab_depth(const rsbwt_t *h) { return h->view.ktab_depth; }
-uint32_t rsbwt_slot_span(const rsbwt_t *h) { return h->slots.slots ? h->slots.p.S : 0u; }
-uint64_t rsbwt_slot_overflow_blocks(const rsbwt_t *h) { return h->slots.slots ? h->slots.noverflow : 0; }
+uint32_t rsbwt_window_span(const rsbwt_t *h) { return h->view.n ? h->view.sp.S : 0u; }
+uint64_t rsbwt_far_lines(const rsbwt_t *h) { return h->far_lines; }
+uint64_t rsbwt_spilled_symbols(const rsbwt_t *h) { return h->spilled_symbols; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
 // ---- class BWT mirrors ------------------------------------------------------------------------
+
+// the sampled select table (getOccAt, read extraction): built once, on first use
+static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->d_sel) return RSBWT_OK;
+    const uint64_t words = 5 * select_sample_stride(h->view);
+    uint32_t *d = nullptr;
+    HIP_OK(hipMalloc(&d, words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(e, "select sample kernel");
+    }
+    h->d_sel = d;
+    h->hbm_bytes += words * sizeof(uint32_t);
+    return RSBWT_OK;
+}
 
 // kind 0: occ(syms, vals)  1: char(vals)  2: occ_at(syms, vals)
 static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *vals, size_t n, void *out) {
@@ -351,23 +420,26 @@ static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *
     if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipStream_t st = g.c->st[0];
+    if (kind == 2 && (rc = ensure_select_samples(h, st)) != RSBWT_OK) return rc;
     const size_t out_bytes = (kind == 1) ? n : n * 8;
     const size_t need = n * 8 + n + out_bytes + 64;
-    if ((rc = h->stage(need)) != RSBWT_OK) return rc;
-    uint8_t *base = (uint8_t *)h->d_stage;
+    if ((rc = g.c->stage(need)) != RSBWT_OK) return rc;
+    uint8_t *base = (uint8_t *)g.c->d_stage;
     uint64_t *d_vals = (uint64_t *)base;
     uint8_t *d_out = base + n * 8;              // 8-aligned
     uint8_t *d_syms = d_out + ((out_bytes + 7) & ~(size_t)7);
-    HIP_OK(hipMemcpyAsync(d_vals, vals, n * 8, hipMemcpyHostToDevice, h->stream));
-    if (kind != 1) HIP_OK(hipMemcpyAsync(d_syms, syms, n, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(d_vals, vals, n * 8, hipMemcpyHostToDevice, st));
+    if (kind != 1) HIP_OK(hipMemcpyAsync(d_syms, syms, n, hipMemcpyHostToDevice, st));
     hipError_t e = hipSuccess;
-    if (kind == 0) e = launch_occ_batch(h->view, d_syms, d_vals, n, d_out, h->stream);
-    else if (kind == 1) e = launch_char_batch(h->view, d_vals, n, d_out, h->stream);
-    else e = launch_occ_at_batch(h->view, d_syms, d_vals, n, d_out, h->stream);
+    if (kind == 0) e = launch_occ_batch(h->view, d_syms, d_vals, n, d_out, st);
+    else if (kind == 1) e = launch_char_batch(h->view, d_vals, n, d_out, st);
+    else e = launch_occ_at_batch(h->view, h->d_sel, d_syms, d_vals, n, d_out, st);
     if (e != hipSuccess) return fail_hip(e, "mirror kernel launch");
-    HIP_OK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     return RSBWT_OK;
 }
 
@@ -388,18 +460,20 @@ int rsbwt_occ_at(rsbwt_t *h, char b, uint64_t bc, uint64_t *index) { return mirr
 
 int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path) {
     if (!bwt_path || !bpi2_path) return fail(RSBWT_EINVAL, "null argument");
-    bpi2_index ix;
-    std::string err;
-    int rc = bpi2_from_bwt(bwt_path, &ix, &err);
-    if (rc == RSBWT_OK) rc = bpi2_save(ix, bpi2_path, &err);
-    if (rc != RSBWT_OK) return fail(rc, "%s", err.c_str());
+    try {
+        bpi2_index ix;
+        std::string err;
+        int rc = bpi2_from_bwt(bwt_path, &ix, &err);
+        if (rc == RSBWT_OK) rc = bpi2_save(ix, bpi2_path, &err);
+        if (rc != RSBWT_OK) return fail(rc, "%s", err.c_str());
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed while building the .bpi2 index");
+    }
     return RSBWT_OK;
 }
 
-int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
-                     uint64_t *mismatches) {
-    if (!h || !bpi2_path || !checked || !mismatches) return fail(RSBWT_EINVAL, "null argument");
-    *checked = *mismatches = 0;
+static int bpi2_check_impl(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
+                           uint64_t *mismatches) {
     bpi2_index f;
     std::string err;
     int rc = bpi2_load(bpi2_path, &f, &err);
@@ -493,6 +567,17 @@ int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, ui
     return RSBWT_OK;
 }
 
+int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
+                     uint64_t *mismatches) {
+    if (!h || !bpi2_path || !checked || !mismatches) return fail(RSBWT_EINVAL, "null argument");
+    *checked = *mismatches = 0;
+    try {
+        return bpi2_check_impl(h, bpi2_path, max_samples, checked, mismatches);
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed while checking %s", bpi2_path);
+    }
+}
+
 // ---- batched search ---------------------------------------------------------------------------
 
 int rsbwt_pack_kmers_dev(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
@@ -506,40 +591,106 @@ int rsbwt_pack_kmers_dev(const void *d_kmers, size_t Q, uint32_t k, size_t strid
     return RSBWT_OK;
 }
 
-static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
-                      void *d_lower, void *d_upper, bool counts_only, hipStream_t stream,
-                      const wave_search_extra *extra = nullptr) {
-    if (!h) return fail(RSBWT_EINVAL, "null handle");
+}  // extern "C"
+
+namespace rsb {
+
+// One fused search launch over the shards whose device views are d_views[0..nshards) on the current
+// device, timed and counted through `m`.  k >= 1 (k == 0 is answered on the host by the callers that
+// allow it); k <= 65535 (the resume position of a traced search is a 16-bit field).
+int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
+                  const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                  hipStream_t stream, const search_extra *extra) {
     if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
-    int rc = use_device(h->device);
-    if (rc) return rc;
-    if (h->view.n == 0 && Q) return fail(RSBWT_EINVAL, "empty index");
+    if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1 for device-resident searches");
+    if (k > 65535u) return fail(RSBWT_ERANGE, "k %u: at most 65535 symbols per k-mer", k);
+    std::lock_guard<std::mutex> lock(m.mu);
     unsigned long long *work = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lock(h->mu);
-        if (h->counting) {
-            work = h->d_work;
-            HIP_OK(hipMemsetAsync(work, 0, 16 * sizeof(unsigned long long), stream));
-        }
-        const int slot = (int)(h->launches % rsbwt::RING);
-        hipError_t e = launch_search(h->view, &h->slots, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, h->num_cus, stream, h->ev_start[slot], h->ev_stop[slot], extra);
-        if (e != hipSuccess) return fail_hip(e, "search kernel launch");
-        h->launches++;
+    if (m.counting) {
+        work = m.d_work;
+        HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), stream));
     }
+    const int slot = (int)(m.launches % search_meter::RING);
+    hipError_t e = launch_search(d_views, nshards, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, num_cus,
+                                 stream, m.ev_start[slot], m.ev_stop[slot], extra);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_hip(e, "search kernel launch");
+    }
+    m.launches++;
     return RSBWT_OK;
 }
 
-int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
-                             void *d_lower, void *d_upper, void *stream) {
-    return search_dev(h, d_packed, d_valid, Q, k, d_lower, d_upper, false, (hipStream_t)stream);
+}  // namespace rsb
+
+static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                      void *d_lower, void *d_upper, bool counts_only, hipStream_t stream,
+                      const search_extra *extra = nullptr) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if (h->view.n == 0 && Q) return fail(RSBWT_EINVAL, "empty index");
+    return search_launch(*h, h->d_view, 1, h->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, stream, extra);
 }
 
-int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
-                    void *d_counts, void *stream) {
-    return search_dev(h, d_packed, d_valid, Q, k, d_counts, nullptr, true, (hipStream_t)stream);
+// Host buffers: slices of at most 2M k-mers alternate between the context's two streams and two
+// halves of its staging buffer: while the host sits in slice i's copy back, the GPU already
+// searches slice i + 1 (its k-mers went up before that copy was issued).  `nshards` result rows of
+// Q values each come back per slice (lower[s * Q + q]).
+namespace rsb {
+int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
+                      const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
+                      bool counts_only) {
+    const uint32_t wpq = words_per_kmer(k);
+    ctx_guard g(pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    const size_t SLICE = std::max<size_t>(1u << 16, (2u << 20) / nshards);
+    const size_t m_max = std::min(SLICE, Q);
+    const size_t a_ascii = (((m_max - 1) * stride + k) + 15) & ~(size_t)15;
+    const size_t a_packed = m_max * wpq * 8;
+    const size_t a_valid = (m_max + 15) & ~(size_t)15;
+    const size_t a_res = (size_t)nshards * m_max * 8;
+    const size_t half = a_ascii + a_packed + a_valid + 2 * a_res;
+    int rc;
+    if ((rc = g.c->stage(Q > SLICE ? 2 * half : half)) != RSBWT_OK) return rc;
+    struct slice_t {
+        size_t q0 = 0, m = 0;
+        uint8_t *d_lo = nullptr, *d_up = nullptr;
+        hipStream_t st = nullptr;
+    } prev;
+    auto collect = [&](const slice_t &sl) -> int {  // results of a slice whose search is under way
+        for (uint32_t s = 0; s < nshards; ++s) {
+            HIP_OK(hipMemcpyAsync(lower + s * Q + sl.q0, sl.d_lo + (size_t)s * sl.m * 8, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
+            if (!counts_only)
+                HIP_OK(hipMemcpyAsync(upper + s * Q + sl.q0, sl.d_up + (size_t)s * sl.m * 8, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
+        }
+        HIP_OK(hipStreamSynchronize(sl.st));
+        return RSBWT_OK;
+    };
+    size_t i = 0;
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE, ++i) {
+        slice_t cur;
+        cur.q0 = q0;
+        cur.m = std::min(SLICE, Q - q0);
+        cur.st = g.c->st[i & 1];
+        uint8_t *base = (uint8_t *)g.c->d_stage + (i & 1) * half;
+        uint8_t *d_ascii = base, *d_packed = d_ascii + a_ascii, *d_valid = d_packed + a_packed;
+        cur.d_lo = d_valid + a_valid;
+        cur.d_up = cur.d_lo + a_res;
+        const size_t ascii_bytes = (cur.m - 1) * stride + k;  // the last k-mer needs only k bytes
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, cur.st));
+        hipError_t e = launch_pack(d_ascii, cur.m, k, stride, d_packed, d_valid, cur.st);
+        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+        rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st, nullptr);
+        if (rc) return rc;
+        if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
+        prev = cur;
+    }
+    if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
+    return RSBWT_OK;
 }
+}  // namespace rsb
 
-// host buffers: stage through HBM in slices of at most 4M k-mers
 static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                        uint64_t *lower, uint64_t *upper, bool counts_only) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
@@ -555,54 +706,20 @@ static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size
         }
         return RSBWT_OK;
     }
-    const uint32_t wpq = words_per_kmer(k);
-    // Slices of at most 2M k-mers alternate between two streams and two halves of the staging
-    // buffer: while the host sits in slice i's copy back, the GPU already searches slice i + 1
-    // (its k-mers went up before that copy was issued).
-    const size_t SLICE = 2u << 20;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->stream2 && Q > SLICE) {
-        hipError_t e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
-        if (e != hipSuccess) return fail_hip(e, "hipStreamCreate");
-    }
-    const size_t m_max = std::min(SLICE, Q);
-    const size_t a_ascii = (((m_max - 1) * stride + k) + 15) & ~(size_t)15;
-    const size_t a_packed = m_max * wpq * 8;
-    const size_t a_valid = (m_max + 15) & ~(size_t)15;
-    const size_t half = a_ascii + a_packed + a_valid + 2 * m_max * 8;
-    if ((rc = h->stage(Q > SLICE ? 2 * half : half)) != RSBWT_OK) return rc;
-    struct slice_t {
-        size_t q0 = 0, m = 0;
-        uint8_t *d_lo = nullptr, *d_up = nullptr;
-        hipStream_t st = nullptr;
-    } prev;
-    auto collect = [&](const slice_t &sl) -> int {  // results of a slice whose search is under way
-        HIP_OK(hipMemcpyAsync(lower + sl.q0, sl.d_lo, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
-        if (!counts_only) HIP_OK(hipMemcpyAsync(upper + sl.q0, sl.d_up, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
-        HIP_OK(hipStreamSynchronize(sl.st));
-        return RSBWT_OK;
-    };
-    size_t i = 0;
-    for (size_t q0 = 0; q0 < Q; q0 += SLICE, ++i) {
-        slice_t cur;
-        cur.q0 = q0;
-        cur.m = std::min(SLICE, Q - q0);
-        cur.st = (i & 1) ? h->stream2 : h->stream;
-        uint8_t *base = (uint8_t *)h->d_stage + (i & 1) * half;
-        uint8_t *d_ascii = base, *d_packed = d_ascii + a_ascii, *d_valid = d_packed + a_packed;
-        cur.d_lo = d_valid + a_valid;
-        cur.d_up = cur.d_lo + m_max * 8;
-        const size_t ascii_bytes = (cur.m - 1) * stride + k;  // the last k-mer needs only k bytes
-        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, cur.st));
-        hipError_t e = launch_pack(d_ascii, cur.m, k, stride, d_packed, d_valid, cur.st);
-        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
-        rc = search_dev(h, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st);
-        if (rc) return rc;
-        if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
-        prev = cur;
-    }
-    if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
-    return RSBWT_OK;
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    return search_host_views(*h, h->pool, h->d_view, 1, h->num_cus, kmers, Q, k, stride, lower, upper, counts_only);
+}
+
+extern "C" {
+
+int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                             void *d_lower, void *d_upper, void *stream) {
+    return search_dev(h, d_packed, d_valid, Q, k, d_lower, d_upper, false, (hipStream_t)stream);
+}
+
+int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                    void *d_counts, void *stream) {
+    return search_dev(h, d_packed, d_valid, Q, k, d_counts, nullptr, true, (hipStream_t)stream);
 }
 
 int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
@@ -617,29 +734,27 @@ int rsbwt_count(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stri
 // ---- 1-mismatch search ------------------------------------------------------------------------
 
 // The [m][3k+1] variant intervals of m packed k-mers (variants_kernel's order) into d_lo/d_up.
-// With the wave kernel and a k-mer table that does not cover the whole k-mer, the k-mers
-// themselves are searched first with a trace, and every variant whose substituted position lies
-// left of the table's reach resumes from its k-mer's interval at that position instead of being
-// searched from scratch (it shares that whole suffix).  `scratch` holds the trace and the k-mers'
-// own results: variants_scratch_bytes().
+// With a k-mer table that does not cover the whole k-mer, the k-mers themselves are searched first
+// with a trace, and every variant whose substituted position lies left of the table's reach resumes
+// from its k-mer's interval at that position instead of being searched from scratch (it shares that
+// whole suffix).  `scratch` holds the trace and the k-mers' own results: variants_scratch_bytes().
 static size_t variants_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
-    if (!search_uses_wave_kernel(h->view, &h->slots)) return 0;
-    const uint32_t tn = wave_trace_entries(h->view, k);
+    const uint32_t tn = trace_entries(h->view, k);
     return tn ? m * (size_t)tn * 16 + 2 * m * 8 : 0;
 }
 
 static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_t m, uint32_t k, const void *d_vpk,
                            const void *d_vok, void *d_lo, void *d_up, uint8_t *scratch, hipStream_t stream) {
     const size_t V = 3 * (size_t)k + 1;
-    const uint32_t tn = search_uses_wave_kernel(h->view, &h->slots) ? wave_trace_entries(h->view, k) : 0u;
+    const uint32_t tn = trace_entries(h->view, k);
     if (tn == 0) return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream);
     uint8_t *d_trace = scratch, *d_olo = d_trace + m * (size_t)tn * 16, *d_oup = d_olo + m * 8;
-    wave_search_extra traced;
+    search_extra traced;
     traced.d_trace_out = d_trace;
     traced.trace_n = tn;
     int rc = search_dev(h, d_pk, d_ok, m, k, d_olo, d_oup, false, stream, &traced);
     if (rc) return rc;
-    wave_search_extra resumed;
+    search_extra resumed;
     resumed.d_trace_in = d_trace;
     resumed.trace_n = tn;
     resumed.variants = (uint32_t)V;
@@ -652,31 +767,34 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
     if (Q == 0) return RSBWT_OK;
     if (!kmers || !lower || !upper) return fail(RSBWT_EINVAL, "null argument");
     if (k == 0 || stride < k) return fail(RSBWT_EINVAL, "bad k/stride");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     int rc = use_device(h->device);
     if (rc) return rc;
     const uint32_t wpq = words_per_kmer(k);
     const size_t V = 3 * (size_t)k + 1;
     const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipStream_t st = g.c->st[0];
     for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
         const size_t m = std::min(SLICE, Q - q0), mv = m * V;
         const size_t ascii_bytes = (m - 1) * stride + k;
         const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
         const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
         const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
-        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_scr)) != RSBWT_OK) return rc;
-        uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+        if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_scr)) != RSBWT_OK) return rc;
+        uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
         uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
         uint8_t *d_scr = d_up + mv * 8;
-        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
-        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
-        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
+        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, st);
         if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, h->stream);
+        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, st);
         if (rc) return rc;
-        HIP_OK(hipMemcpyAsync(lower + q0 * V, d_lo, mv * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipMemcpyAsync(upper + q0 * V, d_up, mv * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
+        HIP_OK(hipMemcpyAsync(lower + q0 * V, d_lo, mv * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(upper + q0 * V, d_up, mv * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
     }
     return RSBWT_OK;
 }
@@ -690,12 +808,15 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
     if (k == 0 || stride < k) return fail(RSBWT_EINVAL, "bad k/stride");
     if (k > 32767u) return fail(RSBWT_ERANGE, "k %u: positions are reported as int16", k);
     if (Q > 0xFFFFFFFFull) return fail(RSBWT_ERANGE, "at most 2^32 - 1 k-mers per call");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     int rc = use_device(h->device);
     if (rc) return rc;
     const uint32_t wpq = words_per_kmer(k);
     const size_t V = 3 * (size_t)k + 1;
     const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipStream_t st = g.c->st[0];
     std::vector<uint32_t> counts;
     std::vector<uint64_t> offsets;
     size_t total = 0;
@@ -707,33 +828,33 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
         const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
         const size_t a_cnt = (m * 4 + 15) & ~(size_t)15, a_off = m * 8, a_hits = mv * sizeof(rsbwt_hit_1mm);
         const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
-        if ((rc = h->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits + a_scr)) != RSBWT_OK) return rc;
-        uint8_t *d_ascii = (uint8_t *)h->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+        if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits + a_scr)) != RSBWT_OK) return rc;
+        uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
         uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
         uint8_t *d_cnt = d_up + mv * 8, *d_off = d_cnt + a_cnt, *d_hits = d_off + a_off, *d_scr = d_hits + a_hits;
-        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, h->stream));
-        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, h->stream);
-        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, h->stream);
+        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
+        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, st);
         if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, h->stream);
+        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, st);
         if (rc) return rc;
-        e = launch_hits1mm_count(d_lo, d_up, m, (uint32_t)V, d_cnt, h->stream);
+        e = launch_hits1mm_count(d_lo, d_up, m, (uint32_t)V, d_cnt, st);
         if (e != hipSuccess) return fail_hip(e, "hit count kernel launch");
         counts.resize(m);
         offsets.resize(m);
-        HIP_OK(hipMemcpyAsync(counts.data(), d_cnt, m * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
+        HIP_OK(hipMemcpyAsync(counts.data(), d_cnt, m * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
         uint64_t run = 0;
         for (size_t i = 0; i < m; ++i) {
             offsets[i] = run;
             run += counts[i];
         }
         if (!overflow && total + run <= cap && run) {
-            HIP_OK(hipMemcpyAsync(d_off, offsets.data(), m * 8, hipMemcpyHostToDevice, h->stream));
-            e = launch_hits1mm_write(d_lo, d_up, d_pk, m, (uint32_t)V, k, d_off, (uint32_t)q0, d_hits, h->stream);
+            HIP_OK(hipMemcpyAsync(d_off, offsets.data(), m * 8, hipMemcpyHostToDevice, st));
+            e = launch_hits1mm_write(d_lo, d_up, d_pk, m, (uint32_t)V, k, d_off, (uint32_t)q0, d_hits, st);
             if (e != hipSuccess) return fail_hip(e, "hit write kernel launch");
-            HIP_OK(hipMemcpyAsync(hits + total, d_hits, run * sizeof(rsbwt_hit_1mm), hipMemcpyDeviceToHost, h->stream));
-            HIP_OK(hipStreamSynchronize(h->stream));
+            HIP_OK(hipMemcpyAsync(hits + total, d_hits, run * sizeof(rsbwt_hit_1mm), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
         } else if (total + run > cap) {
             overflow = true;  // keep counting so that the caller learns the size it needs
         }
@@ -746,6 +867,33 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
 
 // ---- read extraction --------------------------------------------------------------------------
 
+}  // extern "C"
+
+// rows in host memory -> reads in HBM (d_out: n x stride, d_len / d_plen: n x u32), slice by slice
+// through `fn(i0, m, d_out, d_len, d_plen)`, which consumes a slice before the next one overwrites it
+template <class F>
+static int extract_slices(rsbwt_t *h, call_ctx *c, const uint64_t *rows, size_t n, uint32_t stride, size_t extra_bytes,
+                          F &&fn) {
+    hipStream_t st = c->st[0];
+    int rc = ensure_select_samples(h, st);
+    if (rc) return rc;
+    const size_t SLICE = 1u << 20;
+    for (size_t i0 = 0; i0 < n; i0 += SLICE) {
+        const size_t m = std::min(SLICE, n - i0);
+        const size_t a_rows = m * 8, a_out = (m * (size_t)stride + 15) & ~(size_t)15, a_len = (m * 4 + 15) & ~(size_t)15;
+        if ((rc = c->stage(a_rows + a_out + 2 * a_len + extra_bytes)) != RSBWT_OK) return rc;
+        uint8_t *base = (uint8_t *)c->d_stage;
+        uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
+        HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_extract(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, st);
+        if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
+        if ((rc = fn(i0, m, d_out, d_len, d_pl, d_len + a_len)) != RSBWT_OK) return rc;
+    }
+    return RSBWT_OK;
+}
+
+extern "C" {
+
 int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_t stride, uint32_t *len,
                   uint32_t *prefix_len) {
     if (!h || (!rows && n) || (!out && n)) return fail(RSBWT_EINVAL, "null argument");
@@ -754,94 +902,199 @@ int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_
     if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->d_sel) {
-        const uint64_t words = 4 * select_sample_stride(h->view);
-        HIP_OK(hipMalloc(&h->d_sel, words * sizeof(uint32_t)));
-        HIP_OK(hipMemsetAsync(h->d_sel, 0, words * sizeof(uint32_t), h->stream));
-        hipError_t e = launch_select_samples(h->view, h->d_sel, h->stream);
-        if (e != hipSuccess) return fail_hip(e, "select sample kernel launch");
-        h->hbm_bytes += words * sizeof(uint32_t);
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipStream_t st = g.c->st[0];
+    return extract_slices(h, g.c, rows, n, stride, 0,
+                          [&](size_t i0, size_t m, uint8_t *d_out, uint8_t *d_len, uint8_t *d_pl, uint8_t *) -> int {
+                              HIP_OK(hipMemcpyAsync(out + i0 * (size_t)stride, d_out, m * (size_t)stride, hipMemcpyDeviceToHost, st));
+                              if (len) HIP_OK(hipMemcpyAsync(len + i0, d_len, m * 4, hipMemcpyDeviceToHost, st));
+                              if (prefix_len) HIP_OK(hipMemcpyAsync(prefix_len + i0, d_pl, m * 4, hipMemcpyDeviceToHost, st));
+                              HIP_OK(hipStreamSynchronize(st));
+                              return RSBWT_OK;
+                          });
+}
+
+// ---- query / query_exactmatch (src/bwt/query.cpp:87-120) ------------------------------------------
+
+// rows of the intervals of a batch: row list + the k-mer each belongs to.  An interval that is not a
+// proper row range (lower > upper, or the reference's (0, 2^64-1) corner, which it would walk off
+// the BWT with) contributes no row.
+static void interval_rows(const uint64_t *lo, const uint64_t *up, size_t Q, uint64_t n, std::vector<uint64_t> *rows,
+                          std::vector<uint32_t> *owner, uint64_t *first) {
+    uint64_t total = 0;
+    for (size_t q = 0; q < Q; ++q) {
+        first[q] = total;
+        if (lo[q] <= up[q] && up[q] < n) total += up[q] - lo[q] + 1;
     }
-    const size_t SLICE = 1u << 20;
-    for (size_t i0 = 0; i0 < n; i0 += SLICE) {
-        const size_t m = std::min(SLICE, n - i0);
-        const size_t a_rows = m * 8, a_out = (m * (size_t)stride + 15) & ~(size_t)15, a_len = m * 4;
-        if ((rc = h->stage(a_rows + a_out + 2 * a_len)) != RSBWT_OK) return rc;
-        uint8_t *base = (uint8_t *)h->d_stage;
-        uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
-        HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, h->stream));
-        hipError_t e = launch_extract(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->stream);
-        if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
-        HIP_OK(hipMemcpyAsync(out + i0 * (size_t)stride, d_out, m * (size_t)stride, hipMemcpyDeviceToHost, h->stream));
-        if (len) HIP_OK(hipMemcpyAsync(len + i0, d_len, a_len, hipMemcpyDeviceToHost, h->stream));
-        if (prefix_len) HIP_OK(hipMemcpyAsync(prefix_len + i0, d_pl, a_len, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
+    first[Q] = total;
+    if (!rows) return;
+    rows->resize(total);
+    owner->resize(total);
+    for (size_t q = 0; q < Q; ++q) {
+        const uint64_t c = first[q + 1] - first[q];
+        for (uint64_t i = 0; i < c; ++i) {
+            (*rows)[first[q] + i] = lo[q] + i;
+            (*owner)[first[q] + i] = (uint32_t)q;
+        }
     }
-    return RSBWT_OK;
+}
+
+int rsbwt_query_exactmatch(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, uint8_t *found) {
+    if (!h || (!kmers && Q) || (!found && Q)) return fail(RSBWT_EINVAL, "null argument");
+    if (Q == 0) return RSBWT_OK;
+    if (Q > 0xFFFFFFFFull) return fail(RSBWT_ERANGE, "at most 2^32 - 1 strings per call");
+    memset(found, 0, Q);
+    if (k == 0) return RSBWT_OK;
+    try {
+        std::vector<uint64_t> lo(Q), up(Q), first(Q + 1), rows;
+        std::vector<uint32_t> owner;
+        int rc = rsbwt_find_intervals(h, kmers, Q, k, stride, lo.data(), up.data());
+        if (rc) return rc;
+        interval_rows(lo.data(), up.data(), Q, h->view.n, &rows, &owner, first.data());
+        if (rows.empty()) return RSBWT_OK;
+        ctx_guard g(h->pool);
+        if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+        hipStream_t st = g.c->st[0];
+        // the k-mers once, next to the staging buffer (they are compared with every extracted read)
+        void *d_km = nullptr;
+        const size_t km_bytes = (Q - 1) * stride + k;
+        HIP_OK(hipMalloc(&d_km, km_bytes));
+        hipError_t e = hipMemcpyAsync(d_km, kmers, km_bytes, hipMemcpyHostToDevice, st);
+        std::vector<uint8_t> flags(std::min<size_t>(rows.size(), 1u << 20));
+        const uint32_t rstride = ((k + 1u) + 15u) & ~15u;  // a read longer than k cannot equal the query
+        if (e == hipSuccess)
+            rc = extract_slices(h, g.c, rows.data(), rows.size(), rstride, (1u << 20) * 5,
+                                [&](size_t i0, size_t m, uint8_t *d_out, uint8_t *d_len, uint8_t *, uint8_t *d_extra) -> int {
+                                    uint8_t *d_owner = d_extra, *d_flags = d_extra + (1u << 20) * 4;
+                                    HIP_OK(hipMemcpyAsync(d_owner, owner.data() + i0, m * 4, hipMemcpyHostToDevice, st));
+                                    hipError_t e2 = launch_match_reads(d_out, d_len, m, rstride, d_owner, d_km, k, stride, d_flags, st);
+                                    if (e2 != hipSuccess) return fail_hip(e2, "match kernel launch");
+                                    HIP_OK(hipMemcpyAsync(flags.data(), d_flags, m, hipMemcpyDeviceToHost, st));
+                                    HIP_OK(hipStreamSynchronize(st));
+                                    for (size_t i = 0; i < m; ++i)
+                                        if (flags[i]) found[owner[i0 + i]] = 1;
+                                    return RSBWT_OK;
+                                });
+        else rc = fail_hip(e, "hipMemcpyAsync(kmers)");
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_km);
+        return rc;
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed");
+    }
+}
+
+int rsbwt_query(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first, char *reads,
+                uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
+    if (!h || (!kmers && Q) || !first || !nreads) return fail(RSBWT_EINVAL, "null argument");
+    *nreads = 0;
+    first[0] = 0;
+    if (Q == 0) return RSBWT_OK;
+    if (read_stride == 0) return fail(RSBWT_EINVAL, "read_stride must be positive");
+    try {
+        std::vector<uint64_t> lo(Q), up(Q), rows;
+        std::vector<uint32_t> owner;
+        if (k == 0) {
+            for (size_t q = 0; q <= Q; ++q) first[q] = 0;
+            return RSBWT_OK;
+        }
+        int rc = rsbwt_find_intervals(h, kmers, Q, k, stride, lo.data(), up.data());
+        if (rc) return rc;
+        interval_rows(lo.data(), up.data(), Q, h->view.n, nullptr, nullptr, first);
+        *nreads = (size_t)first[Q];
+        if (first[Q] > cap_reads) return fail(RSBWT_ERANGE, "%llu reads, room for %zu", (unsigned long long)first[Q], cap_reads);
+        if (first[Q] == 0) return RSBWT_OK;
+        if (!reads || !read_len) return fail(RSBWT_EINVAL, "null argument");
+        interval_rows(lo.data(), up.data(), Q, h->view.n, &rows, &owner, first);
+        return rsbwt_extract(h, rows.data(), rows.size(), reads, read_stride, read_len, nullptr);
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed");
+    }
 }
 
 // ---- measurement ------------------------------------------------------------------------------
+
+}  // extern "C"
+
+namespace rsb {
+
+int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count) {
+    std::lock_guard<std::mutex> lock(m.mu);
+    size_t n = (size_t)std::min<uint64_t>(m.launches, search_meter::RING);
+    if (n > cap) n = cap;
+    for (size_t i = 0; i < n; ++i) {  // oldest of the n first
+        const int slot = (int)((m.launches - n + i) % search_meter::RING);
+        HIP_OK(hipEventSynchronize(m.ev_stop[slot]));
+        HIP_OK(hipEventElapsedTime(&ms[i], m.ev_start[slot], m.ev_stop[slot]));
+    }
+    *count = n;
+    return RSBWT_OK;
+}
+
+int meter_work(search_meter &m, uint64_t *words, size_t nwords) {
+    std::lock_guard<std::mutex> lock(m.mu);
+    if (!m.launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    HIP_OK(hipEventSynchronize(m.ev_stop[(m.launches - 1) % search_meter::RING]));
+    unsigned long long w[WORK_WORDS];
+    HIP_OK(hipMemcpy(w, m.d_work, sizeof w, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nwords && i < (size_t)WORK_WORDS; ++i) words[i] = w[i];
+    return RSBWT_OK;
+}
+
+}  // namespace rsb
+
+extern "C" {
 
 int rsbwt_last_search_ms(rsbwt_t *h, float *ms) {
     if (!h || !ms) return fail(RSBWT_EINVAL, "null argument");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
-    const int slot = (int)((h->launches - 1) % rsbwt::RING);
-    HIP_OK(hipEventSynchronize(h->ev_stop[slot]));
-    HIP_OK(hipEventElapsedTime(ms, h->ev_start[slot], h->ev_stop[slot]));
-    return RSBWT_OK;
+    size_t cnt = 0;
+    rc = meter_history_ms(*h, ms, 1, &cnt);
+    if (rc == RSBWT_OK && cnt == 0) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
+    return rc;
 }
 
 int rsbwt_search_history_ms(rsbwt_t *h, float *ms, size_t cap, size_t *count) {
     if (!h || (!ms && cap) || !count) return fail(RSBWT_EINVAL, "null argument");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    size_t n = (size_t)std::min<uint64_t>(h->launches, rsbwt::RING);
-    if (n > cap) n = cap;
-    for (size_t i = 0; i < n; ++i) {  // oldest of the n first
-        const int slot = (int)((h->launches - n + i) % rsbwt::RING);
-        HIP_OK(hipEventSynchronize(h->ev_stop[slot]));
-        HIP_OK(hipEventElapsedTime(&ms[i], h->ev_start[slot], h->ev_stop[slot]));
-    }
-    *count = n;
-    return RSBWT_OK;
+    return meter_history_ms(*h, ms, cap, count);
 }
 
 int rsbwt_set_counting(rsbwt_t *h, int on) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    std::lock_guard<std::mutex> lock(h->mu);
     h->counting = on != 0;
     return RSBWT_OK;
 }
 
-int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups, uint64_t *block_reads) {
+int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups, uint64_t *line_reads) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
-    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
-    unsigned long long w[4];
-    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    uint64_t w[WORK_WORDS];
+    if ((rc = meter_work(*h, w, WORK_WORDS)) != RSBWT_OK) return rc;
     if (lf_steps) *lf_steps = w[0];
     if (occ_lookups) *occ_lookups = w[1];
-    if (block_reads) *block_reads = w[2];
+    if (line_reads) *line_reads = w[2];
     return RSBWT_OK;
+}
+
+int rsbwt_last_search_counters(rsbwt_t *h, uint64_t *words16) {
+    if (!h || !words16) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    return meter_work(*h, words16, WORK_WORDS);
 }
 
 int rsbwt_last_search_phases(rsbwt_t *h, uint64_t *cycles, uint64_t *passes) {
     if (!h || !cycles || !passes) return fail(RSBWT_EINVAL, "null argument");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
-    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
-    unsigned long long w[16];
-    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    uint64_t w[WORK_WORDS];
+    if ((rc = meter_work(*h, w, WORK_WORDS)) != RSBWT_OK) return rc;
     for (int i = 0; i < 6; ++i) cycles[i] = w[4 + i];
     *passes = w[10];
     return RSBWT_OK;
@@ -851,11 +1104,8 @@ int rsbwt_last_search_ktab_lookups(rsbwt_t *h, uint64_t *lookups) {
     if (!h || !lookups) return fail(RSBWT_EINVAL, "null argument");
     int rc = use_device(h->device);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lock(h->mu);
-    if (!h->launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
-    HIP_OK(hipEventSynchronize(h->ev_stop[(h->launches - 1) % rsbwt::RING]));
-    unsigned long long w[4];
-    HIP_OK(hipMemcpy(w, h->d_work, sizeof w, hipMemcpyDeviceToHost));
+    uint64_t w[WORK_WORDS];
+    if ((rc = meter_work(*h, w, WORK_WORDS)) != RSBWT_OK) return rc;
     *lookups = w[3];
     return RSBWT_OK;
 }
@@ -880,69 +1130,6 @@ int rsbwt_sample_present_kmers_dev(rsbwt_t *h, size_t Q, uint32_t k, size_t stri
     if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     hipError_t e = launch_sample_present(h->view, Q, k, stride, seed, d_kmers, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "sample kernel launch");
-    return RSBWT_OK;
-}
-
-// ---- shard sets -------------------------------------------------------------------------------
-
-int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
-                   uint32_t flags, rsbwt_set_t **out) {
-    if (!out || (!bwt_paths && num_shards)) return fail(RSBWT_EINVAL, "null argument");
-    *out = nullptr;
-    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
-    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
-    s->owns = true;
-    for (size_t i = 0; i < num_shards; ++i) {
-        rsbwt_t *h = nullptr;
-        // many shards per GPU: the slot layout (about as large as the index) only on explicit request
-        const uint32_t f = (num_shards > 1 && (flags & RSBWT_SLOTS_MASK) == RSBWT_SLOTS_AUTO) ? (flags | RSBWT_SLOTS_OFF) : flags;
-        int rc = rsbwt_open(bwt_paths[i], device_map ? device_map[i] : 0, f, &h);
-        if (rc) { rsbwt_set_close(s); return rc; }
-        s->shards.push_back(h);
-    }
-    *out = s;
-    return RSBWT_OK;
-}
-
-int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
-    if (!out || (!handles && num_shards)) return fail(RSBWT_EINVAL, "null argument");
-    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
-    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
-    s->owns = false;
-    s->shards.assign(handles, handles + num_shards);
-    *out = s;
-    return RSBWT_OK;
-}
-
-void rsbwt_set_close(rsbwt_set_t *s) {
-    if (!s) return;
-    if (s->owns)
-        for (rsbwt_t *h : s->shards) rsbwt_close(h);
-    delete s;
-}
-
-size_t rsbwt_set_size(const rsbwt_set_t *s) { return s ? s->shards.size() : 0; }
-rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i) { return (s && i < s->shards.size()) ? s->shards[i] : nullptr; }
-
-int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
-                             uint64_t *lower, uint64_t *upper) {
-    if (!s) return fail(RSBWT_EINVAL, "null set");
-    for (size_t i = 0; i < s->shards.size(); ++i) {
-        int rc = rsbwt_find_intervals(s->shards[i], kmers, Q, k, stride, lower + i * Q, upper + i * Q);
-        if (rc) return rc;
-    }
-    return RSBWT_OK;
-}
-
-int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
-    if (!s || (!counts && Q)) return fail(RSBWT_EINVAL, "null argument");
-    std::vector<uint64_t> tmp(Q);
-    for (size_t q = 0; q < Q; ++q) counts[q] = 0;
-    for (size_t i = 0; i < s->shards.size(); ++i) {
-        int rc = rsbwt_count(s->shards[i], kmers, Q, k, stride, tmp.data());
-        if (rc) return rc;
-        for (size_t q = 0; q < Q; ++q) counts[q] += tmp[q];
-    }
     return RSBWT_OK;
 }
 

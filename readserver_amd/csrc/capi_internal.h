@@ -1,0 +1,75 @@
+// capi_internal.h -- what the C-ABI translation units (capi.hip, sets.hip) share: the handle
+// structs behind include/rsbwt.h's opaque types, per-call contexts, and the search launcher.
+#ifndef RSBWT_CAPI_INTERNAL_H
+#define RSBWT_CAPI_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rsbwt.h"
+#include "kernels.h"
+#include "line_format.h"
+
+namespace rsb {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail_hip(hipError_t e, const char *what);
+int use_device(int device);
+
+// A stream pair and a staging buffer for the duration of one host-buffer call.
+struct call_ctx {
+    hipStream_t st[2] = {nullptr, nullptr};
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    int stage(size_t bytes);  // grows the staging buffer; RSBWT_OK or RSBWT_ENOMEM
+};
+
+struct ctx_pool {
+    static constexpr int MAX_CTX = 8;  // the reference's query pool has 8 threads (service.cpp:88)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<call_ctx *> free_;
+    int created = 0;
+    call_ctx *acquire();  // blocks while MAX_CTX calls are in flight; nullptr = no stream could be made
+    void release(call_ctx *c);
+    void destroy();       // with no call in flight
+};
+
+// HIP-event pairs of the most recent search launches + the counting mode's counters
+struct search_meter {
+    static constexpr int RING = 64;
+    hipEvent_t ev_start[RING] = {}, ev_stop[RING] = {};
+    uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
+    bool counting = false;
+    unsigned long long *d_work = nullptr;  // WORK_WORDS counters (search_lines.hip)
+    std::mutex mu;
+};
+
+int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
+                  const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                  hipStream_t stream, const search_extra *extra);
+int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
+                      const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
+                      bool counts_only);
+int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
+int meter_work(search_meter &m, uint64_t *words, size_t nwords);
+
+}  // namespace rsb
+
+struct rsbwt : rsb::search_meter {
+    int device = 0;
+    int num_cus = 256;
+    rsb::shard_view view;              // host copy
+    rsb::shard_view *d_view = nullptr; // the same in HBM, for kernels that take views from memory
+    uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
+    uint64_t far_lines = 0, chunk_windows = 0, far_windows = 0, spilled_symbols = 0;
+    rsb::ctx_pool pool;
+    uint32_t *d_sel = nullptr;  // sampled select table, built on first use
+};
+
+#endif

@@ -1,4 +1,5 @@
-// kernels.h -- host-side launchers of the query kernels (kernels.hip) and index builder (index.hip).
+// kernels.h -- host-side launchers of the query kernels (kernels.hip, search_lines.hip) and of the
+// index builder (build_lines.hip).
 #ifndef RSBWT_KERNELS_H
 #define RSBWT_KERNELS_H
 
@@ -6,74 +7,76 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "block_format.h"
+#include "line_format.h"
 
 namespace rsb {
 
 hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
                        void *d_valid, hipStream_t stream);
-// `sv` may be null or hold no slots: the search then runs on the classic blocks + directory
-// ev0/ev1 (optional) are recorded on `stream` immediately around the search kernel itself.
-hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
-                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                         unsigned long long *d_work, int num_cus, hipStream_t stream,
-                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                         const struct wave_search_extra *extra = nullptr);  // extra: wave kernel only
-// search_wave.hip: the wave-cooperative form of the same search (needs slots or dir_shift == 8)
-struct wave_search_extra {
-    // 1-mismatch search.  A traced search records, per k-mer, the interval it holds
-    // when about to take each of its first trace_n symbols ([Q][trace_n] x {lower, upper}); the
-    // search of the k-mers' variants (`variants` per k-mer, variants_kernel's order) then starts
+
+// search_lines.hip: batched findInterval of Q packed k-mers in each of the nshards shards whose
+// views are the device array d_shards (all on the current device).  d_lower/d_upper: [nshards][Q]
+// (d_lower alone receives counts with counts_only).  ev0/ev1 (optional) are recorded on `stream`
+// immediately around the search kernel itself.
+struct search_extra {
+    // 1-mismatch search, one shard.  A traced search records, per k-mer, the interval
+    // it holds when about to take each of its first trace_n symbols ([Q][trace_n] x {lower, upper});
+    // the search of the k-mers' variants (`variants` per k-mer, variants_kernel's order) then starts
     // every variant whose substituted position is < trace_n from that interval.
     void *d_trace_out = nullptr;
     const void *d_trace_in = nullptr;
     uint32_t trace_n = 0, variants = 0;
 };
-hipError_t launch_search_wave(const rsbwt_view &ix, const slot_view *sv, const void *d_packed,
-                              const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper,
-                              bool counts_only, unsigned long long *d_work, int num_cus, hipStream_t stream,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                              const wave_search_extra *extra = nullptr);
-uint32_t wave_trace_entries(const rsbwt_view &ix, uint32_t k);
-// does launch_search run the wave kernel on this index?
-bool search_uses_wave_kernel(const rsbwt_view &ix, const slot_view *sv);
-// slots.hip
-bool choose_slot_span(uint64_t n, uint64_t num_runs, uint32_t want_S, slot_params *sp);
-hipError_t build_slots(const rsbwt_view &ix, uint64_t num_runs, uint32_t want_S, hipStream_t stream,
-                       slot_view *out, uint64_t *bytes, int *range_error);
-hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, uint64_t *d_entries,
-                        int num_cus, hipStream_t stream);
-hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,
+hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
+                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                         unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                         hipEvent_t ev1 = nullptr, const search_extra *extra = nullptr);
+uint32_t trace_entries(const shard_view &ix, uint32_t k);
+constexpr int WORK_WORDS = 16;  // counters of a counting launch (search_lines.hip, WORK_*)
+
+// k-mer table: fills d_entries (4^T entries) by searching every T-mer.  `view` is the host copy of
+// the shard's view (no table yet), d_view a device copy the searches may use.
+hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, int num_cus, hipStream_t stream);
+
+// class BWT mirrors, batched
+hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void *d_index, size_t n,
                             void *d_out, hipStream_t stream);
-hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n, void *d_out,
+hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n, void *d_out,
                              hipStream_t stream);
-hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
-                               void *d_out, hipStream_t stream);
+// d_sel: the sampled select table (launch_select_samples)
+hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
+                               size_t n, void *d_out, hipStream_t stream);
 hipError_t launch_hits1mm_count(const void *d_lower, const void *d_upper, size_t m, uint32_t V, void *d_counts,
                                 hipStream_t stream);
 hipError_t launch_hits1mm_write(const void *d_lower, const void *d_upper, const void *d_packed, size_t m, uint32_t V,
                                 uint32_t k, const void *d_offsets, uint32_t query0, void *d_hits, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
-// read extraction: sampled select table (4 x stride u32) and the two walk kernels
-uint64_t select_sample_stride(const rsbwt_view &ix);
-hipError_t launch_select_samples(const rsbwt_view &ix, uint32_t *d_sel, hipStream_t stream);
-hipError_t launch_extract(const rsbwt_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
+// read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each
+// symbol) and the walk kernel
+uint64_t select_sample_stride(const shard_view &ix);
+hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream);
+hipError_t launch_extract(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
                           void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream);
+// query / query_exactmatch (query.cpp:87-120) over extracted reads
+hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
+                              const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream);
 hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream);
-hipError_t launch_sample_present(const rsbwt_view &ix, size_t Q, uint32_t k, size_t stride,
+hipError_t launch_sample_present(const shard_view &ix, size_t Q, uint32_t k, size_t stride,
                                  uint64_t seed, void *d_kmers, hipStream_t stream);
 
-// index.hip: build blocks + directory in HBM from run bytes in HBM.  On success fills `view`
-// (blocks/dir are hipMalloc'ed and owned by the caller).  dir_shift 0 = choose from the mean
-// run length.  Synchronises `stream`.
+// build_lines.hip: builds the window lines in HBM from run bytes in HBM.  On success fills `view`
+// (lines are hipMalloc'ed and owned by the caller).  want_span 0 = choose S from the data.
+// Synchronises `stream`.  build_error: 0 ok, BUILD_ERANGE, BUILD_EFORMAT.
+enum { BUILD_OK = 0, BUILD_ERANGE = 1, BUILD_EFORMAT = 2 };
 struct build_result {
-    rsbwt_view view;
+    shard_view view;
     uint64_t num_runs;
     uint64_t hbm_bytes;
+    uint64_t far_lines, chunk_windows, far_windows, spilled_symbols;
 };
-hipError_t build_device_index(const void *d_runs, uint64_t num_runs, uint32_t dir_shift,
-                              hipStream_t stream, build_result *out, int *range_error);
+hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span, hipStream_t stream,
+                       build_result *out, int *build_error);
 
 }  // namespace rsb
 #endif

@@ -1,10 +1,6 @@
-// kernels.hip -- query kernels of the popBWT engine (gfx950).
-//
-// Hot path: search_kernel = batched findInterval (src/bwt/query.cpp:24-41).  A query is owned
-// by an octet of lanes = two DPP quads: quad L resolves Occ(b, lower-1), quad U resolves
-// Occ(b, upper) (updateInterval, query.cpp:11-15), in the same instructions.  A wavefront
-// carries 8 queries; each octet walks its own list of queries and refills as soon as one ends,
-// so short (early-terminating) queries do not idle the wave.
+// kernels.hip -- the kernels around the search (gfx950): k-mer packing, the k-mer table build,
+// the class BWT mirrors, read extraction, 1-mismatch variants and hit lists, synthetic inputs.
+// The batched search itself is search_lines.hip; the layout is line_format.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -12,8 +8,9 @@
 
 #include <algorithm>
 
-#include "bwt_device.h"
 #include "kernels.h"
+#include "line_format.h"
+#include "rank_device.h"
 #include "synth_runs.h"
 
 namespace rsb {
@@ -104,143 +101,6 @@ pack_dense_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_t k, uint3
     valid[q] = ok ? 1 : 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// Batched backward search.
-// ------------------------------------------------------------------------------------------
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool KTAB, bool EXACT8>
-__global__ void __launch_bounds__(256)
-search_kernel(const rsbwt_view ix, const uint64_t *__restrict__ packed,
-              const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
-              uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
-              unsigned long long *__restrict__ work) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = lane & 3u;          // lane in quad
-    const uint32_t role = (lane >> 2) & 1u;  // 0: lower-1 side, 1: upper side
-    const size_t octet = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const size_t noctets = ((size_t)gridDim.x * blockDim.x) >> 3;
-    const uint4 *lane_base = ix.blocks + 2u * t;
-
-    // C[] and the symbol totals, indexed by symbol rank, in LDS: a dynamically indexed kernel
-    // argument would otherwise become a dependent global load at the end of every step.
-    __shared__ uint64_t s_C[8], s_total[8];
-    if (threadIdx.x < 5) {
-        s_C[threadIdx.x] = ix.C[threadIdx.x];
-        s_total[threadIdx.x] = ix.total[threadIdx.x];
-    }
-    __syncthreads();
-
-    size_t q = octet;
-    bool fresh = true;   // the next iteration starts query q
-    int j = 0;           // index of the next symbol to prepend
-    uint64_t word = 0;   // packed word holding symbol j
-    uint64_t lo = 0, hi = 0;
-    unsigned long long w_steps = 0, w_occ = 0, w_blocks = 0, w_ktab = 0;
-
-    while (q < Q) {
-        bool done = false;
-        if (fresh) {
-            fresh = false;
-            j = (int)k - 1;
-            const uint64_t *pq = packed + q * wpq;
-            const uint8_t okb = valid[q];  // both loads issue together
-            word = pq[(uint32_t)j >> 5];
-            if (okb == 0) {
-                if ((lane & 7u) == 0u) {
-                    if (COUNTS_ONLY) out_lower[q] = 0;
-                    else { out_lower[q] = 1; out_upper[q] = 0; }
-                }
-                q += noctets;
-                fresh = true;
-                continue;
-            }
-            bool from_table = false;
-            if (KTAB) {
-                // the last T symbols of the k-mer select a precomputed interval
-                const uint32_t T = ix.ktab_depth;
-                const uint32_t off = 2u * (k - T);      // bit offset of symbol k-T in the packing
-                const uint32_t w0 = off >> 6, sh = off & 63u;
-                uint64_t bits = (w0 == ((uint32_t)j >> 5) ? word : pq[w0]) >> sh;
-                if (sh + 2u * T > 64u) bits |= word << (64u - sh);  // spills into the last word
-                const uint64_t code = bits & ((1ull << (2u * T)) - 1ull);
-                const uint64_t e = ix.ktab[code];
-                const uint32_t width = (uint32_t)(e >> RSBWT_COUNT_BITS);
-                if (COUNT_WORK) w_ktab += 1;
-                if (width != RSBWT_KTAB_WIDE) {
-                    from_table = true;
-                    lo = e & RSBWT_COUNT_MASK;
-                    hi = lo + width - 1ull;
-                    j = (int)(k - T) - 1;
-                    // an already-empty tabulated suffix ends the search (query.cpp:35-37); the
-                    // unsigned compare keeps the reference's (0, 2^64-1) corner going, as it does
-                    done = (lo > hi) || (j < 0);
-                    if (!done && ((uint32_t)j >> 5) != ((k - 1u) >> 5)) word = pq[(uint32_t)j >> 5];
-                }
-            }
-            if (!from_table) {
-                const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-                // initInterval (query.cpp:18-21): Occ(b, n-1) is the symbol's total.
-                lo = s_C[b];
-                hi = lo + s_total[b] - 1ull;
-                --j;
-                done = j < 0;
-            }
-        }
-        if (!done) {
-            if ((j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
-            const uint32_t b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
-            // updateInterval (query.cpp:11-15)
-            const uint64_t pb = s_C[b];
-            // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
-            // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
-            // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
-            const uint64_t p_raw = role ? hi : lo - 1ull;
-            const bool skip = p_raw == ~0ull;
-            const uint64_t p = skip ? 0ull : p_raw;
-            lane_block lb;
-            block_meta bm;
-            uint32_t off;
-            const uint64_t blk = quad_fetch<EXACT8>(ix, lane_base, p, t, lb, bm, off);
-            uint64_t occ = quad_rank(lb, bm, t, b, off);
-            occ = skip ? 0ull : occ;
-            const uint64_t other = dpp_mov64<DPP_ROW_HALF_MIRROR>(occ);
-            const uint64_t occL = role ? other : occ;
-            const uint64_t occU = role ? occ : other;
-            if (COUNT_WORK) {
-                const uint64_t oblk = dpp_mov64<DPP_ROW_HALF_MIRROR>(blk);
-                if ((lane & 7u) == 0u) {  // role 0, so `skip` is the L side's
-                    w_steps += 1;
-                    w_occ += skip ? 1 : 2;
-                    w_blocks += (skip || oblk == blk) ? 1 : 2;  // (an upper-side skip counts as a read of block 0)
-                }
-            }
-            lo = pb + occL;
-            hi = pb + occU - 1ull;
-            --j;
-            done = (lo > hi) || (j < 0);  // query.cpp:35-37
-        }
-        if (done) {
-            if ((lane & 7u) == 0u) {
-                if (COUNTS_ONLY) {
-                    out_lower[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
-                } else {
-                    out_lower[q] = lo;
-                    out_upper[q] = hi;
-                }
-            }
-            q += noctets;
-            fresh = true;
-        }
-    }
-    if (COUNT_WORK) {
-        if ((lane & 7u) == 0u && (w_steps || w_ktab)) {
-            atomicAdd(&work[0], w_steps);
-            atomicAdd(&work[1], w_occ);
-            atomicAdd(&work[2], w_blocks);
-            atomicAdd(&work[3], w_ktab);
-        }
-    }
-}
-
 // k-mer table build: codes -> packed queries, and (lower, upper) -> 8-byte entries
 __global__ void ktab_codes_kernel(uint64_t base, size_t m, uint64_t *__restrict__ packed,
                                   uint8_t *__restrict__ valid) {
@@ -257,144 +117,148 @@ __global__ void ktab_encode_kernel(const uint64_t *__restrict__ lower, const uin
     if (i < m) {
         const uint64_t lo = lower[i], up = upper[i];
         uint64_t width = up + 1ull - lo;  // 0 when empty: an empty result always has upper = lower - 1
-        if (lo > up && up + 1ull != lo) width = RSBWT_KTAB_WIDE;  // never produced; stay safe
-        if (width >= RSBWT_KTAB_WIDE) width = RSBWT_KTAB_WIDE;
-        entries[i] = (lo & RSBWT_COUNT_MASK) | (width << RSBWT_COUNT_BITS);
+        if (lo > up && up + 1ull != lo) width = KTAB_WIDE;  // never produced; stay safe
+        if (width >= KTAB_WIDE) width = KTAB_WIDE;
+        entries[i] = (lo & COUNT_MASK) | (width << COUNT_BITS);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// class BWT mirrors, batched: one quad per item.
+// One LF step's worth of a window line, thread-private: the symbol at position p and the number
+// of its occurrences up to p (getChar + getOcc of that symbol, query.cpp:49-57).  The header
+// names the quarter holding the position, so 24 pieces are walked instead of 96; the ~1.5 % of
+// positions past their window's own pieces take the general walk (line_format.h).
+// ------------------------------------------------------------------------------------------
+__device__ uint32_t thread_char_occ(const shard_view &v, uint64_t p, uint64_t *occ_of_char) {
+    uint32_t pin;
+    const uint32_t w = fast_window(p, v.sp.S, v.sp.inv, pin);
+    const uint32_t o = pin + 1u;
+    const uint32_t *L = v.lines + (uint64_t)(w + (w >> GROUP_SHIFT)) * LINE_DWORDS;
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(L), h1 = *reinterpret_cast<const uint4 *>(L + 4);
+    const uint32_t m0 = h0.y >> 8, m1 = h0.w >> 8;
+    const uint32_t s1 = m0 & 0x3FFu, s2 = (m0 >> 10) & 0x7FFu;
+    const uint32_t s3 = s2 + (m1 & 0x3FFu), span = s3 + ((m1 >> 10) & 0x3FFu);
+    if (o > span) return view_char_occ(v, p, occ_of_char);
+    const uint32_t cq = (o > s1 ? 1u : 0u) + (o > s2 ? 1u : 0u) + (o > s3 ? 1u : 0u);
+    const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+    const uint2 *Q = reinterpret_cast<const uint2 *>(L + HDR_DWORDS + 6u * cq);
+    const uint2 a = Q[0], b2 = Q[1], c2 = Q[2];
+    const uint32_t r[6] = {a.x, a.y, b2.x, b2.y, c2.x, c2.y};
+    // the piece holding the position
+    uint32_t rem = o - start, c = 0, upto = 0;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const uint32_t u = (r[i >> 2] >> (8 * (i & 3))) & 0xFFu, len = u & 31u;
+        const bool here = rem != 0u && rem <= len;
+        c = here ? (u >> 5) : c;
+        upto = here ? (uint32_t)i : upto;
+        rem = rem > len ? rem - len : 0u;
+    }
+    if (c == 0u) {  // '$': callers stop here (query.cpp:52); its count comes from the general walk
+        return view_char_occ(v, p, occ_of_char);
+    }
+    // occurrences of c among the quarter's pieces up to the position
+    uint32_t in = 0;
+    rem = o - start;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const uint32_t u = (r[i >> 2] >> (8 * (i & 3))) & 0xFFu, len = u & 31u;
+        const uint32_t take = len < rem ? len : rem;
+        in += ((u >> 5) == c) ? take : 0u;
+        rem -= take;
+    }
+    (void)upto;
+    uint32_t before = 0;
+    if (cq >= 2u) {
+        const uint32_t hm = ((c <= 2u) ? h1.y : h1.w) >> 8;
+        before = (hm >> (11u * ((c - 1u) & 1u))) & 0x7FFu;
+    }
+    if (cq & 1u) {
+        const uint2 *P = reinterpret_cast<const uint2 *>(L + HDR_DWORDS + 6u * (cq - 1u));
+        const uint2 x0 = P[0], x1 = P[1], x2 = P[2];
+        const uint32_t bb = c * 0x01010101u;
+        uint32_t m = dword_matched(x0.x, bb, 0u);
+        m = dword_matched(x0.y, bb, m);
+        m = dword_matched(x1.x, bb, m);
+        m = dword_matched(x1.y, bb, m);
+        m = dword_matched(x2.x, bb, m);
+        m = dword_matched(x2.y, bb, m);
+        before += m;
+    }
+    const uint32_t wlo = c == 1u ? h0.x : c == 2u ? h0.z : c == 3u ? h1.x : h1.z;
+    const uint32_t whi = c == 1u ? h0.y : c == 2u ? h0.w : c == 3u ? h1.y : h1.w;
+    *occ_of_char = (((uint64_t)(whi & 0xFFu) << 32) | wlo) + before + in;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// class BWT mirrors, batched: one thread per item (line_format.h's scalar readers).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ascii_rank(uint8_t ch) {
     return ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'T' ? 4u : 0u;
 }
 
-// Occ for any symbol rank 0..4; `$` comes from P0 minus the four stored counts.
-__device__ __forceinline__ uint64_t quad_occ_any(const rsbwt_view &ix, uint32_t b, uint64_t p,
-                                                 uint32_t t) {
-    lane_block lb;
-    block_meta bm;
-    uint32_t off;
-    quad_fetch<false>(ix, ix.blocks + 2u * t, p, t, lb, bm, off);
-    uint64_t r = quad_rank(lb, bm, t, b, off);  // for b == 0: just the in-block '$' symbols
-    if (b == 0u) {
-        const uint64_t cnt = ((uint64_t)(lb.hdr_hi & 0xFFu) << 32) | lb.hdr_lo;
-        r += (p - off) - quad_sum64(cnt);  // P0 = p - off
-    }
-    return r;
-}
-
-__global__ void occ_batch_kernel(const rsbwt_view ix, const uint8_t *__restrict__ syms,
-                                 const uint64_t *__restrict__ index, size_t n,
-                                 uint64_t *__restrict__ out) {
-    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
-    const uint32_t t = threadIdx.x & 3u;
-    for (size_t i = quad; i < n; i += nquads) {
-        const uint32_t b = ascii_rank(syms[i]);
-        uint64_t p = index[i];
-        uint64_t r = 0;
-        if (p != ~0ull && ix.n != 0) {  // getOcc(b, -1) = 0
-            if (p >= ix.n) p = ix.n - 1;
-            r = quad_occ_any(ix, b, p, t);
-        }
-        if (t == 0u) out[i] = r;
-    }
-}
-
-__global__ void char_batch_kernel(const rsbwt_view ix, const uint64_t *__restrict__ index, size_t n,
-                                  uint8_t *__restrict__ out) {
-    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
-    const uint32_t t = threadIdx.x & 3u;
-    for (size_t i = quad; i < n; i += nquads) {
-        uint64_t p = index[i];
+__global__ void __launch_bounds__(256)
+occ_batch_kernel(const shard_view ix, const uint8_t *__restrict__ syms, const uint64_t *__restrict__ index, size_t n,
+                 uint64_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = ascii_rank(syms[i]);
+    uint64_t p = index[i];
+    uint64_t r = 0;
+    if (p != ~0ull && ix.n != 0) {  // getOcc(b, -1) = 0
         if (p >= ix.n) p = ix.n - 1;
-        lane_block lb;
-        block_meta bm;
-        uint32_t off;
-        quad_fetch<false>(ix, ix.blocks + 2u * t, p, t, lb, bm, off);
-        const uint32_t c = quad_char(lb, bm, t, off);
-        if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
+        r = view_occ(ix, b, p);
+    }
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256)
+char_batch_kernel(const shard_view ix, const uint64_t *__restrict__ index, size_t n, uint8_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t p = index[i];
+    if (p >= ix.n) p = ix.n - 1;
+    out[i] = (uint8_t)("$ACGT"[view_char(ix, p)]);
+}
+
+// Sampled select: sel[c][m] = window holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
+constexpr uint32_t SEL_SHIFT = 8;  // one sample per 256 occurrences: the header search spans a few windows
+
+__global__ void __launch_bounds__(256)
+select_sample_kernel(const shard_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ix.nwin) return;
+    for (uint32_t c = 0; c <= 4; ++c) {
+        const uint64_t cb = count_before_window(ix, w, c);
+        const uint64_t ce = count_before_window(ix, w + 1, c);
+        if (ce == cb) continue;
+        // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
+        for (uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT; (m << SEL_SHIFT) < ce; ++m)
+            sel[c * stride_m + m] = (uint32_t)w;
     }
 }
 
-// Count of symbol b (1..4) before block j; `$` (0) from P0.  One thread, two or four loads.
-__device__ __forceinline__ uint64_t block_count_before(const rsbwt_view &ix, uint64_t j, uint32_t b) {
-    const uint64_t *w = (const uint64_t *)ix.blocks;  // header word t at u64 index 16*j + 4*t
-    if (b != 0u) return w[16 * j + 4 * (b - 1u)] & RSBWT_COUNT_MASK;
-    const uint64_t w0 = w[16 * j], w1 = w[16 * j + 4], w2 = w[16 * j + 8], w3 = w[16 * j + 12];
-    const uint64_t P0 = (w0 >> 40) | (((w1 >> 40) & 0xFFFFull) << 24);
-    return P0 - ((w0 & RSBWT_COUNT_MASK) + (w1 & RSBWT_COUNT_MASK) + (w2 & RSBWT_COUNT_MASK) +
-                 (w3 & RSBWT_COUNT_MASK));
+// getOccAt with the sample table bounding the header search (BPTree::select's role)
+__device__ uint64_t thread_occ_at_sampled(const shard_view &ix, const uint32_t *__restrict__ sel,
+                                          uint64_t stride_m, uint32_t b, uint64_t bc) {
+    const uint64_t m = (bc - 1) >> SEL_SHIFT;
+    const uint64_t lo = sel[b * stride_m + m];
+    const uint64_t hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? sel[b * stride_m + m + 1] : ix.nwin - 1;
+    return view_occ_at(ix, b, bc, lo, hi);
 }
 
-// Offset inside block j of its `offset`-th b (offset >= 1, at most the block's count of b):
-// RLEBWT::getOccAt's scan (src/bwt/rlebwt.cpp:245-263), a quarter (32 B = two 16-byte loads) at a
-// time -- quarters before the one holding the occurrence are only added up, 4 runs per dot4.
-__device__ uint64_t thread_select_in_block(const rsbwt_view &ix, uint64_t j, uint32_t b, uint64_t offset) {
-    const uint4 *blk = ix.blocks + 8 * j;
-    const uint32_t bb = b * 0x01010101u;
-    uint64_t index = 0;
-    for (uint32_t t = 0; t < 4u; ++t) {
-        const uint4 a = blk[2 * t], c = blk[2 * t + 1];
-        const uint32_t r[6] = {a.z, a.w, c.x, c.y, c.z, c.w};
-        uint32_t matched = 0, total = 0;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            matched = dword_matched(r[d], bb, matched);
-            total = __builtin_amdgcn_udot4(r[d] & 0x1F1F1F1Fu, 0x01010101u, total, false);
-        }
-        if (offset > matched && t < 3u) {
-            offset -= matched;
-            index += total;
-            continue;
-        }
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t u = (r[d] >> (8 * k)) & 0xFFu, len = u & 31u;
-                if ((u >> 5) != b) { index += len; continue; }
-                if (offset <= len) return index + offset - 1;
-                offset -= len;
-                index += len;
-            }
-        }
-    }
-    return index;
-}
-
-// getOccAt(b, bc): position of the bc-th b (bc >= 1).  Floor search over the block headers
-// (BPTree::select's role, include/bwt/BPTree.h:50-67), then RLEBWT::getOccAt's scan
-// (src/bwt/rlebwt.cpp:245-263) over the block's 96 runs.  One thread per item.
-__device__ uint64_t thread_occ_at(const rsbwt_view &ix, uint32_t b, uint64_t bc) {
-    uint64_t lo = 0, hi = ix.nblocks - 1;  // largest j with count_before(j) < bc
-    while (hi > lo) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (block_count_before(ix, mid, b) >= bc) hi = mid - 1;
-        else lo = mid;
-    }
-    const uint64_t j = lo;
-    const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
-    const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
-    return P0 + thread_select_in_block(ix, j, b, bc - block_count_before(ix, j, b));
-}
-
-__global__ void occ_at_batch_kernel(const rsbwt_view ix, const uint8_t *__restrict__ syms,
-                                    const uint64_t *__restrict__ bc, size_t n,
-                                    uint64_t *__restrict__ out) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = gid; i < n; i += nthreads) {
-        const uint32_t b = ascii_rank(syms[i]);
-        uint64_t c = bc[i];
-        const uint64_t tot = ix.total[b];
-        uint64_t r = ix.n;  // out of range -> n
-        if (c >= 1 && c <= tot) r = thread_occ_at(ix, b, c);
-        out[i] = r;
-    }
+__global__ void __launch_bounds__(256)
+occ_at_batch_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
+                    const uint8_t *__restrict__ syms, const uint64_t *__restrict__ bc, size_t n,
+                    uint64_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = ascii_rank(syms[i]);
+    const uint64_t c = bc[i];
+    uint64_t r = ix.n;  // out of range -> n
+    if (c >= 1 && c <= ix.total[b]) r = thread_occ_at_sampled(ix, sel, stride_m, b, c);
+    out[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,36 +286,31 @@ __global__ void synth_runs_kernel(uint8_t *__restrict__ runs, uint64_t num_runs,
 
 // K-mers that occur in the index: start at a random row r, emit F(r) as the last symbol, then
 // repeatedly prepend BWT[r] and move r <- LF(r).  Every suffix of the k-mer then has a non-empty
-// interval.  A walk that meets '$' restarts from another row.  One quad per k-mer.
-__global__ void sample_present_kernel(const rsbwt_view ix, size_t Q, uint32_t k, size_t stride,
-                                      uint64_t seed, uint8_t *__restrict__ kmers) {
-    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
-    const uint32_t t = threadIdx.x & 3u;
+// interval.  A walk that meets '$' restarts from another row.  One thread per k-mer.
+__global__ void __launch_bounds__(256)
+sample_present_kernel(const shard_view ix, size_t Q, uint32_t k, size_t stride, uint64_t seed,
+                      uint8_t *__restrict__ kmers) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
     const uint64_t nonterm = ix.n - ix.C[1];  // rows whose first symbol is not '$'
-    for (size_t q = quad; q < Q; q += nquads) {
-        uint8_t *out = kmers + q * stride;
-        bool ok = false;
-        for (uint32_t attempt = 0; attempt < 64 && !ok && nonterm > 0; ++attempt) {
-            uint64_t r = ix.C[1] + synth_mix64(seed ^ synth_mix64(q * 64 + attempt)) % nonterm;
-            uint32_t f = 1;
-            while (f < 4 && ix.C[f + 1] <= r) ++f;
-            if (t == 0u) out[k - 1] = (uint8_t)("$ACGT"[f]);
-            ok = true;
-            for (int i = (int)k - 2; i >= 0; --i) {
-                lane_block lb;
-                block_meta bm;
-                uint32_t off;
-                quad_fetch<false>(ix, ix.blocks + 2u * t, r, t, lb, bm, off);
-                const uint32_t c = quad_char(lb, bm, t, off);
-                if (c == 0u) { ok = false; break; }
-                r = ix.C[c] + quad_rank(lb, bm, t, c, off) - 1ull;  // LF(r)
-                if (t == 0u) out[i] = (uint8_t)("$ACGT"[c]);
-            }
+    uint8_t *out = kmers + q * stride;
+    bool ok = false;
+    for (uint32_t attempt = 0; attempt < 64 && !ok && nonterm > 0; ++attempt) {
+        uint64_t r = ix.C[1] + synth_mix64(seed ^ synth_mix64(q * 64 + attempt)) % nonterm;
+        uint32_t f = 1;
+        while (f < 4 && ix.C[f + 1] <= r) ++f;
+        out[k - 1] = (uint8_t)("$ACGT"[f]);
+        ok = true;
+        for (int i = (int)k - 2; i >= 0; --i) {
+            uint64_t occ = 0;
+            const uint32_t c = thread_char_occ(ix, r, &occ);
+            if (c == 0u) { ok = false; break; }
+            r = ix.C[c] + occ - 1ull;  // LF(r)
+            out[i] = (uint8_t)("$ACGT"[c]);
         }
-        if (!ok && t == 0u)
-            for (uint32_t i = 0; i < k; ++i) out[i] = 'A';
     }
+    if (!ok)
+        for (uint32_t i = 0; i < k; ++i) out[i] = 'A';
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,73 +396,32 @@ hits1mm_write_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restr
 // ------------------------------------------------------------------------------------------
 // Read extraction (query.cpp:43-85): the read whose suffix is SA row `row`.
 // ------------------------------------------------------------------------------------------
-// Sampled select: sel[c-1][m] = block holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
-constexpr uint32_t SEL_SHIFT = 8;  // one sample per 256 occurrences: the header search spans 1-3 blocks
-
-__global__ void __launch_bounds__(256)
-select_sample_kernel(const rsbwt_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ix.nblocks) return;
-    for (uint32_t c = 1; c <= 4; ++c) {
-        const uint64_t cb = block_count_before(ix, j, c);
-        const uint64_t ce = (j + 1 < ix.nblocks) ? block_count_before(ix, j + 1, c) : ix.total[c];
-        if (ce == cb) continue;
-        // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
-        for (uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT; (m << SEL_SHIFT) < ce; ++m)
-            sel[(c - 1) * stride_m + m] = (uint32_t)j;
-    }
-}
-
-// getOccAt with the sample table bounding the header search (BPTree::select's role)
-__device__ uint64_t thread_occ_at_sampled(const rsbwt_view &ix, const uint32_t *__restrict__ sel,
-                                          uint64_t stride_m, uint32_t b, uint64_t bc) {
-    const uint64_t m = (bc - 1) >> SEL_SHIFT;
-    uint64_t lo = sel[(b - 1) * stride_m + m];
-    uint64_t hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? sel[(b - 1) * stride_m + m + 1] : ix.nblocks - 1;
-    while (hi > lo) {  // largest j in [lo, hi] with count_before(j) < bc
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (block_count_before(ix, mid, b) >= bc) hi = mid - 1;
-        else lo = mid;
-    }
-    const uint64_t j = lo;
-    const uint64_t *w = (const uint64_t *)ix.blocks + 16 * j;
-    const uint64_t P0 = (w[0] >> 40) | (((w[4] >> 40) & 0xFFFFull) << 24);
-    return P0 + thread_select_in_block(ix, j, b, bc - block_count_before(ix, j, b));
-}
-
-// extractPrefix (query.cpp:43-63): LF walk left until '$'.  One quad per row; the characters are
+// extractPrefix (query.cpp:43-63): LF walk left until '$'.  One thread per row; the characters are
 // produced right to left, so they are written downwards from the end of the row's buffer.
 __global__ void __launch_bounds__(256)
-extract_prefix_kernel(const rsbwt_view ix, const uint64_t *__restrict__ rows, size_t n,
+extract_prefix_kernel(const shard_view ix, const uint64_t *__restrict__ rows, size_t n,
                       uint8_t *__restrict__ out, uint32_t stride, uint32_t *__restrict__ plen) {
-    const size_t quad = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
-    const uint32_t t = threadIdx.x & 3u;
-    const uint4 *lane_base = ix.blocks + 2u * t;
-    for (size_t i = quad; i < n; i += nquads) {
-        uint64_t idx = rows[i];
-        uint8_t *buf = out + i * (size_t)stride;
-        uint32_t len = 0;
-        bool fits = idx < ix.n;
-        while (fits) {
-            lane_block lb;
-            block_meta bm;
-            uint32_t off;
-            quad_fetch<false>(ix, lane_base, idx, t, lb, bm, off);
-            const uint32_t c = quad_char(lb, bm, t, off);
-            if (c == 0u) break;
-            if (len == stride) { fits = false; break; }  // the reference would spin (query.cpp:48)
-            idx = ix.C[c] + quad_rank(lb, bm, t, c, off) - 1ull;  // C[b] + Occ(b, idx-1)
-            if (t == 0u) buf[stride - 1u - len] = (uint8_t)("$ACGT"[c]);
-            ++len;
-        }
-        if (t == 0u) plen[i] = fits ? len : 0xFFFFFFFFu;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t idx = rows[i];
+    uint8_t *buf = out + i * (size_t)stride;
+    uint32_t len = 0;
+    bool fits = idx < ix.n;
+    while (fits) {
+        uint64_t occ = 0;
+        const uint32_t c = thread_char_occ(ix, idx, &occ);
+        if (c == 0u) break;
+        if (len == stride) { fits = false; break; }  // the reference would spin (query.cpp:48)
+        idx = ix.C[c] + occ - 1ull;  // C[b] + Occ(b, idx-1)
+        buf[stride - 1u - len] = (uint8_t)("$ACGT"[c]);
+        ++len;
     }
+    plen[i] = fits ? len : 0xFFFFFFFFu;
 }
 
 // extractPostfix (query.cpp:65-85): F / select walk right until '$', appended after the prefix.
 __global__ void __launch_bounds__(256)
-extract_postfix_kernel(const rsbwt_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
+extract_postfix_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
                        const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out,
                        uint32_t stride, const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,6 +443,21 @@ extract_postfix_kernel(const rsbwt_view ix, const uint32_t *__restrict__ sel, ui
     tlen[i] = len;
 }
 
+// query / query_exactmatch (query.cpp:87-120) over the extracted rows of a batch of k-mers: row i
+// belongs to k-mer owner[i]; flags[i] = 1 when the read equals the k-mer (exact match: the whole read
+// is the query, query.cpp:112-116).
+__global__ void __launch_bounds__(256)
+match_reads_kernel(const uint8_t *__restrict__ reads, const uint32_t *__restrict__ len, size_t n, uint32_t stride,
+                   const uint32_t *__restrict__ owner, const uint8_t *__restrict__ kmers, uint32_t k, size_t kstride,
+                   uint8_t *__restrict__ flags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool eq = len[i] == k;
+    const uint8_t *r = reads + i * (size_t)stride, *w = kmers + (size_t)owner[i] * kstride;
+    for (uint32_t t = 0; eq && t < k; ++t) eq = r[t] == w[t];
+    flags[i] = eq ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------------
@@ -634,6 +467,7 @@ static inline int grid_for(size_t items_per_block, size_t items, int max_blocks)
     if (g > (size_t)max_blocks) g = (size_t)max_blocks;
     return (int)g;
 }
+static inline unsigned blocks256(size_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
                        void *d_valid, hipStream_t stream) {
@@ -650,137 +484,82 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
     return hipGetLastError();
 }
 
-template <bool CW, bool CO, bool KT>
-static void launch_search_e(bool exact8, int grid, hipStream_t stream, const rsbwt_view &ix,
-                            const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq,
-                            uint64_t *lo, uint64_t *up, unsigned long long *work) {
-    if (exact8)
-        hipLaunchKernelGGL((search_kernel<CW, CO, KT, true>), dim3(grid), dim3(256), 0, stream, ix, pk, vd,
-                           Q, k, wpq, lo, up, work);
-    else
-        hipLaunchKernelGGL((search_kernel<CW, CO, KT, false>), dim3(grid), dim3(256), 0, stream, ix, pk,
-                           vd, Q, k, wpq, lo, up, work);
-}
-
-template <bool CW, bool CO>
-static void launch_search_t(bool ktab, int grid, hipStream_t stream, const rsbwt_view &ix,
-                            const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k, uint32_t wpq,
-                            uint64_t *lo, uint64_t *up, unsigned long long *work) {
-    const bool exact8 = ix.dir_shift == 8;
-    if (ktab) launch_search_e<CW, CO, true>(exact8, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
-    else launch_search_e<CW, CO, false>(exact8, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, work);
-}
-
-// RSBWT_SEARCH_KERNEL=octet|wave picks the kernel form (default: wave where the index allows it)
-static bool prefer_wave_kernel() {
-    static const int v = [] {
-        const char *e = getenv("RSBWT_SEARCH_KERNEL");
-        return (e && e[0] == 'o') ? 0 : 1;
-    }();
-    return v != 0;
-}
-
-bool search_uses_wave_kernel(const rsbwt_view &ix, const slot_view *sv) {
-    const bool have_slots = sv && sv->slots;
-    return (have_slots || ix.dir_shift == 8) && prefer_wave_kernel();
-}
-
-hipError_t launch_search(const rsbwt_view &ix, const slot_view *sv, const void *d_packed, const void *d_valid,
-                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
-                         unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0,
-                         hipEvent_t ev1, const wave_search_extra *extra) {
-    if (Q == 0) return hipSuccess;
-    const bool have_slots = sv && sv->slots;
-    if ((have_slots || ix.dir_shift == 8) && prefer_wave_kernel())
-        return launch_search_wave(ix, have_slots ? sv : nullptr, d_packed, d_valid, Q, k, d_lower, d_upper,
-                                  counts_only, d_work, num_cus, stream, ev0, ev1, extra);
-    if (extra) return hipErrorInvalidValue;  // traced / resumed searches exist in the wave kernel only
-    if (ev0) (void)hipEventRecord(ev0, stream);
-    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    // 32 queries per 256-thread workgroup; 8 workgroups per CU fill the 32 wave slots.
-    const int grid = grid_for(32, Q, num_cus * 8);
-    const uint64_t *pk = (const uint64_t *)d_packed;
-    const uint8_t *vd = (const uint8_t *)d_valid;
-    uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
-    const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
-    if (d_work) {
-        if (counts_only) launch_search_t<true, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_search_t<true, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-    } else {
-        if (counts_only) launch_search_t<false, true>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-        else launch_search_t<false, false>(ktab, grid, stream, ix, pk, vd, Q, k, wpq, lo, up, d_work);
-    }
-    const hipError_t le = hipGetLastError();
-    if (ev1) (void)hipEventRecord(ev1, stream);
-    return le;
-}
-
-// Fills ix.ktab-to-be `d_entries` (4^T entries) by searching every T-mer with the table-less
-// kernel, in slices that bound the temporary memory.  `ix` must not have a table yet.
-hipError_t build_ktable(const rsbwt_view &ix, const slot_view *sv, uint32_t T, uint64_t *d_entries,
-                        int num_cus, hipStream_t stream) {
+// Fills `d_entries` (4^T entries) by searching every T-mer, in slices that bound the temporary
+// memory.  `view` must not have a table yet.
+hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, int num_cus, hipStream_t stream) {
     const uint64_t total = 1ull << (2u * T);
     const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 24);
-    uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr;
+    uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr, *d_half = nullptr;
     uint8_t *d_ok = nullptr;
-    hipError_t e;
-    if ((e = hipMalloc(&d_pk, SL * 8)) != hipSuccess) return e;
-    if ((e = hipMalloc(&d_lo, SL * 8)) != hipSuccess) { (void)hipFree(d_pk); return e; }
-    if ((e = hipMalloc(&d_up, SL * 8)) != hipSuccess) { (void)hipFree(d_pk); (void)hipFree(d_lo); return e; }
-    if ((e = hipMalloc(&d_ok, SL)) != hipSuccess) { (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); return e; }
-    rsbwt_view plain = ix;
+    shard_view *d_view = nullptr;
+    shard_view plain = view;
     plain.ktab = nullptr;
     plain.ktab_depth = 0;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&] {
+        if (d_pk) (void)hipFree(d_pk);
+        if (d_lo) (void)hipFree(d_lo);
+        if (d_up) (void)hipFree(d_up);
+        if (d_ok) (void)hipFree(d_ok);
+        if (d_half) (void)hipFree(d_half);
+        if (d_view) (void)hipFree(d_view);
+    };
+    if ((e = hipMalloc(&d_pk, SL * 8)) != hipSuccess || (e = hipMalloc(&d_lo, SL * 8)) != hipSuccess ||
+        (e = hipMalloc(&d_up, SL * 8)) != hipSuccess || (e = hipMalloc(&d_ok, SL)) != hipSuccess ||
+        (e = hipMalloc(&d_view, sizeof(shard_view))) != hipSuccess) {
+        cleanup();
+        return e;
+    }
     // a deep table is built on top of a shallow one: with the (T/2)-mer table in place, each of
     // the 4^T searches starts from its last T/2 symbols' entry and takes half the LF steps
-    uint64_t *d_half = nullptr;
     if (T >= 10u) {
         const uint32_t T0 = T / 2u;
-        if ((e = hipMalloc(&d_half, 8ull << (2u * T0))) == hipSuccess) e = build_ktable(ix, sv, T0, d_half, num_cus, stream);
+        if ((e = hipMalloc(&d_half, 8ull << (2u * T0))) == hipSuccess) e = build_ktable(view, T0, d_half, num_cus, stream);
         if (e != hipSuccess) {
-            (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); (void)hipFree(d_ok);
-            if (d_half) (void)hipFree(d_half);
+            cleanup();
             return e;
         }
         plain.ktab = d_half;
         plain.ktab_depth = T0;
     }
+    if ((e = hipMemcpy(d_view, &plain, sizeof plain, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return e;
+    }
     for (uint64_t base = 0; base < total && e == hipSuccess; base += SL) {
         const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
-        const int g = (int)((m + 255) / 256);
-        hipLaunchKernelGGL(ktab_codes_kernel, dim3(g), dim3(256), 0, stream, base, m, d_pk, d_ok);
-        e = launch_search(plain, sv, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
+        hipLaunchKernelGGL(ktab_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base, m, d_pk, d_ok);
+        e = launch_search(d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(ktab_encode_kernel, dim3(g), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
+        hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d_pk); (void)hipFree(d_lo); (void)hipFree(d_up); (void)hipFree(d_ok);
-    if (d_half) (void)hipFree(d_half);
+    cleanup();
     return e;
 }
 
-hipError_t launch_occ_batch(const rsbwt_view &ix, const void *d_syms, const void *d_index, size_t n,
+hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void *d_index, size_t n,
                             void *d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(occ_batch_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+    hipLaunchKernelGGL(occ_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix,
                        (const uint8_t *)d_syms, (const uint64_t *)d_index, n, (uint64_t *)d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_char_batch(const rsbwt_view &ix, const void *d_index, size_t n, void *d_out,
+hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n, void *d_out,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(char_batch_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+    hipLaunchKernelGGL(char_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix,
                        (const uint64_t *)d_index, n, (uint8_t *)d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_occ_at_batch(const rsbwt_view &ix, const void *d_syms, const void *d_bc, size_t n,
-                               void *d_out, hipStream_t stream) {
+hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
+                               size_t n, void *d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(occ_at_batch_kernel, dim3(grid_for(256, n, 8192)), dim3(256), 0, stream, ix,
-                       (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
+                       select_sample_stride(ix), (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
     return hipGetLastError();
 }
 
@@ -807,32 +586,42 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
     if (Q == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
     const size_t total = Q * (3 * (size_t)k + 1);
-    hipLaunchKernelGGL(variants_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(variants_kernel, dim3(blocks256(total)), dim3(256), 0, stream,
                        (const uint64_t *)d_packed, (const uint8_t *)d_valid, Q, k, wpq, (uint64_t *)d_vpacked,
                        (uint8_t *)d_vvalid);
     return hipGetLastError();
 }
 
-uint64_t select_sample_stride(const rsbwt_view &ix) {
+uint64_t select_sample_stride(const shard_view &ix) {
     uint64_t mx = 0;
-    for (int c = 1; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
+    for (int c = 0; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
     return (mx >> SEL_SHIFT) + 2;
 }
 
-hipError_t launch_select_samples(const rsbwt_view &ix, uint32_t *d_sel, hipStream_t stream) {
-    hipLaunchKernelGGL(select_sample_kernel, dim3((unsigned)((ix.nblocks + 255) / 256)), dim3(256), 0, stream, ix,
-                       d_sel, select_sample_stride(ix));
+hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream) {
+    if (ix.nwin == 0) return hipSuccess;
+    hipLaunchKernelGGL(select_sample_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel,
+                       select_sample_stride(ix));
     return hipGetLastError();
 }
 
-hipError_t launch_extract(const rsbwt_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
+hipError_t launch_extract(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
                           void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(extract_prefix_kernel, dim3(grid_for(64, n, 8192)), dim3(256), 0, stream, ix,
+    hipLaunchKernelGGL(extract_prefix_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix,
                        (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen);
-    hipLaunchKernelGGL(extract_postfix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ix, d_sel,
+    hipLaunchKernelGGL(extract_postfix_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
                        (const uint32_t *)d_plen, (uint32_t *)d_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
+                              const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(match_reads_kernel, dim3(blocks256(n)), dim3(256), 0, stream, (const uint8_t *)d_reads,
+                       (const uint32_t *)d_len, n, stride, (const uint32_t *)d_owner, (const uint8_t *)d_kmers, k, kstride,
+                       (uint8_t *)d_flags);
     return hipGetLastError();
 }
 
@@ -843,10 +632,10 @@ hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hip
     return hipGetLastError();
 }
 
-hipError_t launch_sample_present(const rsbwt_view &ix, size_t Q, uint32_t k, size_t stride,
+hipError_t launch_sample_present(const shard_view &ix, size_t Q, uint32_t k, size_t stride,
                                  uint64_t seed, void *d_kmers, hipStream_t stream) {
     if (Q == 0 || k == 0) return hipSuccess;
-    hipLaunchKernelGGL(sample_present_kernel, dim3(grid_for(64, Q, 8192)), dim3(256), 0, stream, ix,
+    hipLaunchKernelGGL(sample_present_kernel, dim3(blocks256(Q)), dim3(256), 0, stream, ix,
                        Q, k, stride, seed, (uint8_t *)d_kmers);
     return hipGetLastError();
 }

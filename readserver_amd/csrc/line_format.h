@@ -1,0 +1,428 @@
+// line_format.h -- the HBM layout of one popBWT shard: "window lines" (DESIGN.md section 3).
+//
+// The BWT is cut into WINDOWS of S symbols.  Window w is one 128-byte line at a computable
+// address, so an Occ lookup (RLEBWT::getOcc, src/bwt/rlebwt.cpp:268-301) is ONE HBM request:
+//
+//     w = p / S                 (any S in 2..2944; kernels divide by an f64 multiply + one fix-up step)
+//     line(w) = w + (w >> 4)    (every 16 window lines are followed by their group's SPILL line)
+//
+// The run bytes are ReadServer's RLUnit bytes verbatim (include/bwt/rlunit.h:8-11:
+// rank(sym) << 5 | len, len 1..31, rank $=0 A=1 C=2 G=3 T=4; alphabet.h:8-9), split where a run
+// crosses a window border ("pieces").  S is chosen from the data so that a window holds ~90 pieces
+// on average; the 1.5 % or so of positions whose piece does not fit their window's line are found
+// one more request away (spill chunk / far line), so memory is ~1.5 bytes per run byte, whatever
+// the local run lengths, against 4/3 for blocks cut by run count -- which need a second,
+// dependent request (a directory) to be found.
+//
+// WINDOW LINE = 32 dwords:
+//   dwords 0..7    four header words (u64, little endian), word t for symbol t+1 (A, C, G, T):
+//        bits  0..39  # of that symbol in BWT[0, w*S)                       (absolute)
+//        bits 40..63  meta_t:
+//            meta_0 = s1 | s2 << 10              quarters are pieces [0,24) [24,48) [48,72) [72,96);
+//            meta_1 = d3 | d4 << 10 | kind << 20   s_t = symbols held by quarters 0..t-1,
+//                                                  d3 = s3 - s2, d4 = span - s3,
+//                                                  span = symbols held by this line's own pieces
+//            meta_2 = halfA | halfC << 11 | (cdw/2 & 3) << 22     half_x = # of x in quarters 0 and 1
+//            meta_3 = halfG | halfT << 11 | (cdw/2 >> 2) << 22
+//        kind = 0: the line holds its whole window (span = symbols of the window)
+//        kind = 1: the window has 97..120 pieces: the excess (<= 24 pieces) is a CHUNK at dword
+//                  cdw (even) of the group's spill line
+//        kind = 2: the line holds 92 pieces and its last dword (31) the index of a FAR line that
+//                  continues the window (more than 120 pieces, or the spill line was full)
+//   dwords 8..31   96 piece bytes (unused = 0; a valid piece has len >= 1)
+//   $ before the window = w*S - (A + C + G + T).
+//
+// SPILL LINE (line 17g + 16 of group g) = chunks at even dwords, each
+//   dword 0   totA | totC << 12 | (csym & 0xFF) << 24      tot_x = # of x in the 96 own pieces of
+//   dword 1   totG | totT << 12 | (csym >> 8) << 24        the window's line; csym = symbols held
+//   dwords 2.. the excess pieces, zero-padded to an even number of dwords (at most 6)
+//
+// FAR LINE (index >= first_far) = a window line whose counts are absolute at ITS first piece; it
+//   may itself continue in another far line (kind = 2).
+//
+// K-MER TABLE (8 B per T-mer, 4^T entries): the interval findInterval returns for every string of
+// T symbols over ACGT: bits 0..39 lower, bits 40..63 width = upper - lower + 1 (0 = empty, upper =
+// lower - 1; RSBWT_KTAB_WIDE = not tabulated).  Code of a T-mer = its 2-bit packing.
+//
+// Everything below is plain C++ usable on the host and in kernels: the layout logic (what the
+// builder writes, what a scalar reader finds) is one piece of code for both, so tests can hold it
+// to naive ranks on the CPU while all queries run on the GPU only.
+#ifndef RSBWT_LINE_FORMAT_H
+#define RSBWT_LINE_FORMAT_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RSB_HD __host__ __device__ inline
+#else
+#define RSB_HD inline
+#endif
+
+namespace rsb {
+
+constexpr uint32_t LINE_BYTES = 128;
+constexpr uint32_t LINE_DWORDS = 32;
+constexpr uint32_t HDR_DWORDS = 8;
+constexpr uint32_t LINE_PIECES = 96;
+constexpr uint32_t QUARTER_PIECES = 24;
+constexpr uint32_t FAR_PIECES = 92;    // own pieces of a line whose last dword is a far link
+constexpr uint32_t CHUNK_MAX_PIECES = 24;
+constexpr uint32_t GROUP_SHIFT = 4;    // 16 window lines + 1 spill line
+constexpr uint32_t GROUP = 1u << GROUP_SHIFT;
+constexpr uint32_t KIND_WHOLE = 0, KIND_CHUNK = 1, KIND_FAR = 2;
+constexpr uint32_t COUNT_BITS = 40;
+constexpr uint64_t COUNT_MASK = (1ull << COUNT_BITS) - 1;
+constexpr uint64_t MAX_SYMBOLS = 1ull << 40;  // per shard; counts are 40-bit
+constexpr uint32_t MAX_SPAN = 2944;           // S <= 92 * 32: a line of full units never needs more
+constexpr uint32_t KTAB_WIDE = 0xFFFFFFu;
+
+// w = p / S.  Kernels compute it as (uint32)((double)p * inv) plus one fix-up step: inv is 1/S
+// rounded down by 2^-50 relative, so for p < 2^40 the product's floor is w or w - 1, never above.
+struct span_params {
+    uint32_t S, reserved;
+    double inv;
+};
+
+// What a kernel needs to search one shard.  Plain pointers into HBM.
+struct shard_view {
+    const uint32_t *lines;  // nlines * 32 dwords
+    uint64_t n;             // symbols (getBWLen)
+    uint64_t nwin;          // windows = ceil(n / S)
+    uint64_t nlines;        // ngroups * 17 + far lines
+    uint64_t first_far;     // = ngroups * 17
+    span_params sp;
+    uint32_t ktab_depth;    // T (0 = no table)
+    const uint64_t *ktab;
+    uint64_t C[5];          // C[c] = # symbols with rank < c   (getPC)
+    uint64_t total[5];      // occurrences of each symbol in the whole BWT
+};
+
+RSB_HD uint64_t window_of(const span_params &sp, uint64_t p) { return p / sp.S; }
+RSB_HD uint64_t line_of_window(uint64_t w) { return w + (w >> GROUP_SHIFT); }
+RSB_HD uint64_t spill_line_of_window(uint64_t w) { return ((w >> GROUP_SHIFT) * (GROUP + 1)) + GROUP; }
+
+struct line_meta {
+    uint64_t cnt[4];
+    uint32_t s1, s2, s3, span, kind, cdw;
+    uint32_t half[4];
+};
+
+RSB_HD line_meta parse_line(const uint32_t *L) {
+    line_meta m;
+    uint32_t meta[4];
+    for (int t = 0; t < 4; ++t) {
+        m.cnt[t] = ((uint64_t)(L[2 * t + 1] & 0xFFu) << 32) | L[2 * t];
+        meta[t] = L[2 * t + 1] >> 8;
+    }
+    m.s1 = meta[0] & 0x3FFu;
+    m.s2 = (meta[0] >> 10) & 0x7FFu;
+    m.s3 = m.s2 + (meta[1] & 0x3FFu);
+    m.span = m.s3 + ((meta[1] >> 10) & 0x3FFu);
+    m.kind = (meta[1] >> 20) & 3u;
+    m.half[0] = meta[2] & 0x7FFu;
+    m.half[1] = (meta[2] >> 11) & 0x7FFu;
+    m.half[2] = meta[3] & 0x7FFu;
+    m.half[3] = (meta[3] >> 11) & 0x7FFu;
+    m.cdw = 2u * (((meta[2] >> 22) & 3u) | (((meta[3] >> 22) & 3u) << 2));
+    return m;
+}
+
+RSB_HD uint32_t dword_piece(const uint32_t *D, uint32_t i) { return (D[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
+
+// Visits the pieces of window w in order -- own pieces, then the spill chunk or the far lines --
+// until f(sym, len) returns true.
+template <class F>
+RSB_HD void walk_window(const shard_view &v, uint64_t w, F &&f) {
+    uint64_t line = line_of_window(w);
+    for (uint32_t guard = 0; guard < 64; ++guard) {  // a window has at most S <= 2944 pieces = 33 lines
+        const uint32_t *L = v.lines + line * LINE_DWORDS;
+        const line_meta m = parse_line(L);
+        const uint32_t own = m.kind == KIND_FAR ? FAR_PIECES : LINE_PIECES;
+        for (uint32_t i = 0; i < own; ++i) {
+            const uint32_t u = dword_piece(L + HDR_DWORDS, i);
+            if ((u & 31u) == 0u) break;
+            if (f(u >> 5, u & 31u)) return;
+        }
+        if (m.kind == KIND_CHUNK) {
+            const uint32_t *Cn = v.lines + spill_line_of_window(w) * LINE_DWORDS + m.cdw;
+            const uint32_t csym = (Cn[0] >> 24) | ((Cn[1] >> 24) << 8);
+            uint32_t seen = 0;
+            for (uint32_t i = 0; i < CHUNK_MAX_PIECES && seen < csym; ++i) {
+                const uint32_t u = dword_piece(Cn + 2, i);
+                if ((u & 31u) == 0u) break;
+                seen += u & 31u;
+                if (f(u >> 5, u & 31u)) return;
+            }
+            return;
+        }
+        if (m.kind != KIND_FAR) return;
+        line = L[LINE_DWORDS - 1];
+        if (line < v.first_far || line >= v.nlines) return;  // corrupt link: never for a built index
+    }
+}
+
+// # of symbol b (rank 0..4) in BWT[0, w*S)
+RSB_HD uint64_t count_before_window(const shard_view &v, uint64_t w, uint32_t b) {
+    if (w >= v.nwin) return v.total[b];
+    const uint32_t *L = v.lines + line_of_window(w) * LINE_DWORDS;
+    if (b != 0u) return (((uint64_t)(L[2 * (b - 1) + 1] & 0xFFu)) << 32) | L[2 * (b - 1)];
+    uint64_t s = 0;
+    for (int t = 0; t < 4; ++t) s += (((uint64_t)(L[2 * t + 1] & 0xFFu)) << 32) | L[2 * t];
+    return w * v.sp.S - s;
+}
+
+// RLEBWT::getOcc (src/bwt/rlebwt.cpp:268-301): # of symbol b in BWT[0..p], p < n.
+RSB_HD uint64_t view_occ(const shard_view &v, uint32_t b, uint64_t p) {
+    const uint64_t w = window_of(v.sp, p);
+    uint32_t rem = (uint32_t)(p - w * v.sp.S) + 1u;
+    uint64_t occ = count_before_window(v, w, b);
+    walk_window(v, w, [&](uint32_t sym, uint32_t len) {
+        const uint32_t take = len < rem ? len : rem;
+        if (sym == b) occ += take;
+        rem -= take;
+        return rem == 0u;
+    });
+    return occ;
+}
+
+// RLEBWT::getChar (src/bwt/rlebwt.cpp:202-227): rank of the symbol at position p < n.
+RSB_HD uint32_t view_char(const shard_view &v, uint64_t p) {
+    const uint64_t w = window_of(v.sp, p);
+    uint32_t rem = (uint32_t)(p - w * v.sp.S) + 1u, c = 0;
+    walk_window(v, w, [&](uint32_t sym, uint32_t len) {
+        c = sym;
+        if (len >= rem) return true;
+        rem -= len;
+        return false;
+    });
+    return c;
+}
+
+// getChar and getOcc of that symbol at once: the LF step of extractPrefix (query.cpp:49-57).
+RSB_HD uint32_t view_char_occ(const shard_view &v, uint64_t p, uint64_t *occ_of_char) {
+    const uint64_t w = window_of(v.sp, p);
+    uint32_t rem = (uint32_t)(p - w * v.sp.S) + 1u, c = 0;
+    uint32_t in[5] = {0, 0, 0, 0, 0};
+    walk_window(v, w, [&](uint32_t sym, uint32_t len) {
+        c = sym;
+        const uint32_t take = len < rem ? len : rem;
+        if (sym < 5u) in[sym] += take;
+        rem -= take;
+        return rem == 0u;
+    });
+    *occ_of_char = count_before_window(v, w, c) + in[c];
+    return c;
+}
+
+// RLEBWT::getOccAt (src/bwt/rlebwt.cpp:233-266): position of the bc-th b (1 <= bc <= total[b]).
+// The window is found by a floor search over the window headers between lo and hi (BPTree::select's
+// role, include/bwt/BPTree.h:50-67); callers narrow [lo, hi] with a sample table.
+RSB_HD uint64_t view_occ_at(const shard_view &v, uint32_t b, uint64_t bc, uint64_t lo, uint64_t hi) {
+    while (hi > lo) {  // largest w in [lo, hi] with count_before(w) < bc
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (count_before_window(v, mid, b) >= bc) hi = mid - 1;
+        else lo = mid;
+    }
+    uint64_t left = bc - count_before_window(v, lo, b);
+    uint64_t pos = lo * v.sp.S;
+    bool found = false;
+    walk_window(v, lo, [&](uint32_t sym, uint32_t len) {
+        if (sym == b) {
+            if (left <= len) {
+                pos += left - 1;
+                found = true;
+                return true;
+            }
+            left -= len;
+        }
+        pos += len;
+        return false;
+    });
+    return found ? pos : v.n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The builder's core, shared by the GPU kernels (build_lines.hip) and the host-side layout test.
+// ---------------------------------------------------------------------------------------------
+
+// Sequential reader of the run bytes from a known position on.
+struct run_reader {
+    const uint8_t *runs;
+    uint64_t R;
+    uint64_t r;       // next run byte to read
+    uint32_t left;    // symbols of the current run not yet handed out
+    uint32_t sym;
+    uint64_t cnt[4];  // A,C,G,T handed out so far (absolute)
+
+    // starts at run index r0, `skip` symbols into it, with the counts of everything before
+    RSB_HD void start(const uint8_t *runs_, uint64_t R_, uint64_t r0, const uint64_t cnt0[4]) {
+        runs = runs_;
+        R = R_;
+        r = r0;
+        left = 0;
+        sym = 0;
+        for (int c = 0; c < 4; ++c) cnt[c] = cnt0[c];
+    }
+    // next piece of at most `want` symbols; 0 at the end of the stream
+    RSB_HD uint32_t take(uint32_t want, uint32_t *piece_sym) {
+        while (left == 0u) {
+            if (r >= R) return 0u;
+            const uint8_t u = runs[r++];
+            left = u & 31u;  // zero-length units hold no symbol: skipped
+            sym = u >> 5;
+        }
+        const uint32_t len = left < want ? left : want;
+        left -= len;
+        *piece_sym = sym;
+        if (sym >= 1u && sym <= 4u) cnt[sym - 1u] += len;
+        return len;
+    }
+    RSB_HD void skip_symbols(uint64_t k) {
+        uint32_t s;
+        while (k) {
+            const uint32_t len = take(k > 31u ? 31u : (uint32_t)k, &s);
+            if (!len) return;
+            k -= len;
+        }
+    }
+};
+
+struct group_stats {
+    uint32_t far_lines;       // far lines this group needs
+    uint32_t chunk_windows;   // windows continued in the spill line
+    uint32_t far_windows;     // windows continued in far lines
+    uint64_t spilled_symbols; // symbols not held by their window's own line
+};
+
+// Packs one window / far line: counts at its first piece, its np pieces, how it continues.
+RSB_HD void emit_line(uint32_t *L, const uint64_t cnt0[4], const uint8_t *pieces, uint32_t np, uint32_t kind,
+                      uint32_t cdw, uint32_t far_link) {
+    uint32_t start[5] = {0, 0, 0, 0, 0};
+    uint32_t half[4] = {0, 0, 0, 0};
+    uint32_t sofar = 0;
+    for (uint32_t q = 0; q < 4; ++q) {
+        start[q] = sofar;
+        for (uint32_t i = q * QUARTER_PIECES; i < (q + 1) * QUARTER_PIECES && i < np; ++i) {
+            const uint32_t len = pieces[i] & 31u, sym = pieces[i] >> 5;
+            sofar += len;
+            if (q < 2 && sym >= 1u && sym <= 4u) half[sym - 1u] += len;
+        }
+    }
+    start[4] = sofar;
+    const uint32_t meta[4] = {start[1] | (start[2] << 10),
+                              (start[3] - start[2]) | ((start[4] - start[3]) << 10) | (kind << 20),
+                              half[0] | (half[1] << 11) | (((cdw >> 1) & 3u) << 22),
+                              half[2] | (half[3] << 11) | (((cdw >> 3) & 3u) << 22)};
+    for (uint32_t t = 0; t < 4; ++t) {
+        const uint64_t word = (cnt0[t] & COUNT_MASK) | ((uint64_t)meta[t] << COUNT_BITS);
+        L[2 * t] = (uint32_t)word;
+        L[2 * t + 1] = (uint32_t)(word >> 32);
+    }
+    for (uint32_t d = 0; d < LINE_DWORDS - HDR_DWORDS; ++d) {
+        uint32_t x = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = 4 * d + k;
+            if (i < np) x |= (uint32_t)pieces[i] << (8 * k);
+        }
+        L[HDR_DWORDS + d] = x;
+    }
+    if (kind == KIND_FAR) L[LINE_DWORDS - 1] = far_link;
+}
+
+// Lays out group g (windows 16g .. 16g+15).  `rd` stands at symbol 16*g*S.  With WRITE the 17 lines
+// of the group and its far lines (from absolute line far_base on) are written; without, only the
+// statistics are gathered -- by the same decisions, so that a counting pass sizes the far region.
+template <bool WRITE>
+RSB_HD group_stats build_group(const span_params &sp, uint64_t n, uint64_t nwin, uint64_t g, run_reader &rd,
+                               uint32_t *lines, uint64_t far_base) {
+    group_stats st = {0, 0, 0, 0};
+    uint32_t spill[LINE_DWORDS];
+    for (uint32_t d = 0; d < LINE_DWORDS; ++d) spill[d] = 0;
+    uint32_t sdw = 0;  // next free dword of the spill line (even)
+    constexpr uint32_t BUF = LINE_PIECES + CHUNK_MAX_PIECES;
+    uint8_t buf[BUF];
+    for (uint32_t wi = 0; wi < GROUP; ++wi) {
+        const uint64_t w = g * GROUP + wi;
+        if (w >= nwin) break;
+        const uint64_t wstart = w * (uint64_t)sp.S;
+        uint32_t remaining = (uint32_t)((n - wstart) < sp.S ? (n - wstart) : sp.S);
+        const uint32_t wsyms = remaining;
+        uint64_t cnt_line[4] = {rd.cnt[0], rd.cnt[1], rd.cnt[2], rd.cnt[3]};
+        uint64_t line = line_of_window(w);
+        uint32_t nb = 0;
+        bool first = true;
+        for (;;) {
+            while (remaining && nb < BUF) {
+                uint32_t s;
+                const uint32_t len = rd.take(remaining, &s);
+                if (!len) { remaining = 0; break; }
+                buf[nb++] = (uint8_t)((s << 5) | len);
+                remaining -= len;
+            }
+            const bool ends = remaining == 0u;
+            uint32_t keep, kind = KIND_WHOLE, cdw = 0, link = 0;
+            if (ends && nb <= LINE_PIECES) {
+                keep = nb;
+            } else {
+                const uint32_t extra = nb > LINE_PIECES ? nb - LINE_PIECES : 0u;
+                const uint32_t need = 2u + 2u * ((extra + 7u) / 8u);  // header + pieces, in dwords, even
+                if (first && ends && extra <= CHUNK_MAX_PIECES && sdw + need <= LINE_DWORDS) {
+                    keep = LINE_PIECES;
+                    kind = KIND_CHUNK;
+                    cdw = sdw;
+                    uint32_t tot[4] = {0, 0, 0, 0}, csym = 0;
+                    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
+                        const uint32_t sy = buf[i] >> 5;
+                        if (sy >= 1u && sy <= 4u) tot[sy - 1u] += buf[i] & 31u;
+                    }
+                    for (uint32_t i = LINE_PIECES; i < nb; ++i) {
+                        csym += buf[i] & 31u;
+                        spill[sdw + 2u + ((i - LINE_PIECES) >> 2)] |= (uint32_t)buf[i] << (8u * ((i - LINE_PIECES) & 3u));
+                    }
+                    spill[sdw] = tot[0] | (tot[1] << 12) | ((csym & 0xFFu) << 24);
+                    spill[sdw + 1] = tot[2] | (tot[3] << 12) | ((csym >> 8) << 24);
+                    sdw += need;
+                    st.chunk_windows += 1;
+                    st.spilled_symbols += csym;
+                } else {
+                    keep = FAR_PIECES;
+                    kind = KIND_FAR;
+                    link = (uint32_t)(far_base + st.far_lines);
+                    st.far_lines += 1;
+                    if (first) st.far_windows += 1;
+                }
+            }
+            uint32_t held = 0;
+            for (uint32_t i = 0; i < keep; ++i) held += buf[i] & 31u;
+            if (first && kind == KIND_FAR) st.spilled_symbols += wsyms - held;
+            if (WRITE) emit_line(lines + line * LINE_DWORDS, cnt_line, buf, keep, kind, cdw, link);
+            if (kind != KIND_FAR) break;
+            // the window goes on in the far line: counts at its first piece, pieces shifted down
+            for (uint32_t i = 0; i < keep; ++i) {
+                const uint32_t sy = buf[i] >> 5;
+                if (sy >= 1u && sy <= 4u) cnt_line[sy - 1u] += buf[i] & 31u;
+            }
+            for (uint32_t i = keep; i < nb; ++i) buf[i - keep] = buf[i];
+            nb -= keep;
+            line = link;
+            first = false;
+        }
+    }
+    if (WRITE && sdw) {
+        uint32_t *Sp = lines + (g * (GROUP + 1) + GROUP) * LINE_DWORDS;
+        for (uint32_t d = 0; d < LINE_DWORDS; ++d) Sp[d] = spill[d];
+    }
+    return st;
+}
+
+inline span_params make_span(uint32_t S) {
+    span_params sp;
+    sp.S = S < 2u ? 2u : (S > MAX_SPAN ? MAX_SPAN : S);
+    sp.reserved = 0;
+    sp.inv = (1.0 / (double)sp.S) * (1.0 - 0x1p-50);
+    return sp;
+}
+
+}  // namespace rsb
+#endif

@@ -1,0 +1,599 @@
+// search_lines.hip -- batched findInterval over window lines, wave-cooperative (gfx950).
+//
+// findInterval, src/bwt/query.cpp:24-41, for a batch of k-mers against one or several shards
+// resident on this GPU (every query goes to every shard: src/service/server.cpp:124,578).
+//   * a wavefront carries 32 (query, shard) searches: lane i resolves Occ(b, lower-1) of search i,
+//     lane i+32 Occ(b, upper) (updateInterval, query.cpp:11-15); a wave works on one shard at a
+//     time, so everything that depends on the shard sits in scalar registers;
+//   * one Occ lookup = ONE 128-byte request: the window line of position p is at a computable
+//     address (line_format.h).  Lines are fetched the way the memory system likes them
+//     (tools/gather_bench.hip): a full line per octet of lanes, by LDS-DMA straight into the wave's
+//     LDS stage, each distinct line of a query once;
+//   * every lane then ranks ITS line out of LDS: the header names the quarter holding the
+//     position and what the first half holds of every symbol; at most one earlier quarter is added
+//     up 4 runs at a time (v_dot4_u32_u8 against a 0/1 match mask) and the quarter itself is
+//     scanned run by run (SDWA, 4.5 VALU per run);
+//   * the ~1.5 % of lookups whose position lies past the pieces its window's line holds (spill
+//     chunk / far line) are NOT chased inside the pass: the lane keeps what it learned (base count,
+//     where to go, symbols left) and fetches the continuation in its next pass, while the other
+//     lanes step on -- no wave ever waits a second round trip for one lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "kernels.h"
+#include "line_format.h"
+#include "rank_device.h"
+
+namespace rsb {
+
+// LDS stage: 128 B per lane, 8 KB per wave, 32 KB per 4-wave workgroup, so 5 workgroups
+// (20 waves) would fit a CU's 160 KB; 4 are launched.
+constexpr int SLOT_U4 = 8;
+constexpr int WG_WAVES = 4;  // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
+
+// The stage is written by LDS-DMA and parsed as dwords / 8- / 16-byte pieces: the read types may
+// alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
+typedef uint32_t __attribute__((may_alias)) lds_u32;
+typedef uint2 __attribute__((may_alias)) lds_u2;
+typedef uint4 __attribute__((may_alias)) lds_u4;
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
+
+// Fetch of up to 64 lines into the wave's LDS stage, direct to LDS (global_load_lds_dwordx4,
+// gfx950): no register round trip, no ds_write pass.  One instruction writes 1 KB of LDS in lane
+// order, so the work is split the way that makes this the stage layout itself: instruction k
+// (0..7) serves lanes T = 8o + k, the eight lanes of octet o each bringing 16 B of the line
+// lane T wants (a full 128-B line per octet: the request shape tools/gather_bench.hip measures
+// fastest).  Lane T's line then sits at k * 1 KB + o * 128 B, chunk c at position c ^ k -- the
+// swizzle is applied on the SOURCE side (lane l of the octet loads chunk (l & 7) ^ k).
+// want == ~0u: that lane needs nothing (its octet's lanes are masked off for that instruction and
+// the row keeps what it held).
+__device__ __forceinline__ void glds_fetch(const char *lines, uint32_t want, uint32_t lane, uint32_t stage_lds) {
+    uint32_t tb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        tb[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~7u) + k) << 2), (int)want);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (tb[k] != ~0u) {
+            const char *src = lines + (uint64_t)tb[k] * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
+            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, 0);
+        }
+    }
+}
+// the lines are in LDS once every outstanding load has returned
+// (the builtin, not inline asm: hipcc's wait-count bookkeeping then knows nothing is outstanding and
+// does not add its own vmcnt(0) at the head of the next pass, in front of that pass's loads)
+__device__ __forceinline__ void glds_wait() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
+
+// Start state of every (query, shard) search, computed ahead of the search so that a search
+// entering the wave costs one independent 16-byte load instead of a chain (validity byte + packed
+// word -> k-mer table entry) in front of every pass.  Record = { lower | flags, upper }.
+constexpr uint64_t INIT_INVALID = 1ull << 63;   // symbol outside ACGT: result (1, 0)
+constexpr uint64_t INIT_FALLBACK = 1ull << 62;  // not from the k-mer table: continue at symbol k-2
+constexpr uint64_t INIT_EXPLICIT = 1ull << 61;  // continue at the symbol named in bits 40..55 (1-mismatch variants)
+
+__device__ __forceinline__ bool view_uses_ktab(const shard_view &ix, uint32_t k) {
+    return ix.ktab != nullptr && ix.ktab_depth >= 2u && k >= ix.ktab_depth;
+}
+
+__device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const uint64_t *pq, uint32_t k) {
+    ulonglong2 rec;
+    const uint64_t last = pq[(k - 1u) >> 5];
+    if (view_uses_ktab(ix, k)) {
+        const uint32_t T = ix.ktab_depth;
+        const uint32_t off = 2u * (k - T);
+        const uint32_t w0 = off >> 6, sh = off & 63u;
+        uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
+        if (sh + 2u * T > 64u) bits |= last << (64u - sh);
+        const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
+        const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+        if (width != KTAB_WIDE) {
+            rec.x = e & COUNT_MASK;
+            rec.y = rec.x + width - 1ull;
+            return rec;
+        }
+    }
+    // initInterval, query.cpp:18-21
+    const uint32_t b = (uint32_t)((last >> (2u * ((k - 1u) & 31u))) & 3u) + 1u;
+    rec.x = ix.C[b] | INIT_FALLBACK;
+    rec.y = ix.C[b] + ix.total[b] - 1ull;
+    return rec;
+}
+
+// one thread per (shard, query): init[s * Q + q]
+__global__ void __launch_bounds__(256)
+search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                   const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
+                   ulonglong2 *__restrict__ init) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * nshards) return;
+    const size_t s = i / Q, q = i - s * Q;
+    ulonglong2 rec;
+    if (valid[q] == 0) {
+        rec.x = INIT_INVALID;
+        rec.y = 0;
+    } else {
+        rec = start_record(shards[s], packed + q * wpq, k);
+    }
+    init[i] = rec;
+}
+
+// Start records of the 3k+1 variants of m k-mers (1-mismatch search, variants_kernel's order).  A
+// variant whose substituted position is left of the k-mer table's reach shares its whole suffix
+// with the k-mer itself: it starts from the interval the k-mer's own (traced) search had when it
+// was about to take that position -- trace[q][pos] -- and takes the substituted symbol first.
+__global__ void __launch_bounds__(256)
+search_init_1mm_kernel(const shard_view *__restrict__ shard, const uint64_t *__restrict__ vpacked,
+                       const uint8_t *__restrict__ vvalid, size_t mv, uint32_t k, uint32_t wpq, uint32_t V,
+                       const ulonglong2 *__restrict__ trace, uint32_t trace_n,
+                       ulonglong2 *__restrict__ init) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mv) return;
+    ulonglong2 rec;
+    if (vvalid[i] == 0) {
+        rec.x = INIT_INVALID;
+        rec.y = 0;
+    } else {
+        const size_t q = i / V;
+        const uint32_t v = (uint32_t)(i - q * V);
+        const uint32_t pos = v ? (v - 1u) / 3u : ~0u;
+        if (pos < trace_n) {
+            const ulonglong2 t = trace[q * trace_n + pos];
+            rec.x = (t.x & COUNT_MASK) | ((uint64_t)pos << COUNT_BITS) | INIT_EXPLICIT;
+            rec.y = t.y;
+        } else {
+            rec = start_record(*shard, vpacked + i * wpq, k);
+        }
+    }
+    init[i] = rec;
+}
+
+// work[] of a counting launch
+enum { WORK_STEPS = 0, WORK_OCC = 1, WORK_LINES = 2, WORK_KTAB = 3, WORK_PHASE0 = 4, WORK_PASSES = 10, WORK_HOPS = 11 };
+
+// LONGK: k > 32, i.e. a query spans several packed words.  A template parameter because with the
+// reload on the path -- however it is guarded at run time -- hipcc waits for vmcnt(0) at the top of
+// every pass, which also waits for the start-up loads just issued by entering lanes.
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK>
+__global__ void __launch_bounds__(64 * WG_WAVES)
+search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                    const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
+                    size_t Q, uint32_t k, uint32_t wpq,
+                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
+                    unsigned long long *__restrict__ work,
+                    ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk) {
+    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t side = lane >> 5;  // 0: lower-1 side, 1: upper side
+    uint4 *stage = s_stage[wave];
+    // LDS byte address of this wave's stage, in a scalar register (it goes to M0)
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
+    // dword d of this lane's line: chunk d >> 2 at (d >> 2) ^ swz(lane) of the row
+    // (lane & 7) * 1 KB + (lane >> 3) * 128 B; lanes l and l + 32 share k and the swizzle
+    const uint32_t swz = lane & 7u;
+    const lds_u32 *own_row = reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
+#define MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
+
+    unsigned long long w_steps = 0, w_occ = 0, w_lines = 0, w_hops = 0, w_ktab = 0;
+    // counting mode also stamps where a pass spends its cycles (shares only: the stamps fence)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, stamp = 0, passes = 0;
+#define STAMP(i)                                                        \
+    if (COUNT_WORK) {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        ph[i] += now_ - stamp;                                          \
+        stamp = now_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+    if (COUNT_WORK) stamp = __builtin_amdgcn_s_memtime();
+
+    // A wave searches one shard at a time: it starts on shard blockIdx % nshards (workgroups are
+    // dealt round-robin over the XCDs, so with 8 shards each XCD starts on its own) and draws
+    // queries from that shard's pool until it is empty, then moves to the next shard that still has
+    // queries; equal shards finish together and the tail is shared by all waves.
+    uint32_t sid = blockIdx.x % nshards;
+    for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
+        const shard_view *sv = shards + sid;
+        const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
+        const uint32_t S = sv->sp.S;
+        const double inv = sv->sp.inv;
+        const uint32_t nlines = (uint32_t)sv->nlines;
+        const bool ktab = view_uses_ktab(*sv, k);
+        // symbol a table-started query continues with, and the packed word holding it
+        const int j_table = ktab ? (int)(k - sv->ktab_depth) - 1 : (int)k - 2;
+        const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
+        const ulonglong2 *init_s = init + (size_t)sid * Q;
+        uint64_t *out_lo = out_lower + (size_t)sid * Q;
+        uint64_t *out_up = COUNTS_ONLY ? nullptr : out_upper + (size_t)sid * Q;
+        unsigned long long *pool = next_query + sid;
+        // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
+        // ds_bpermute reads (selects out of scalar registers cost 15 VALU instructions a pass; a
+        // dynamically indexed load would be a dependent global load in every pass)
+        uint32_t ctab_lo, ctab_hi;
+        {
+            const uint64_t cv = sv->C[1u + (lane & 3u)];
+            ctab_lo = (uint32_t)cv;
+            ctab_hi = (uint32_t)(cv >> 32);
+        }
+
+        // Queries are handed out dynamically: a wave draws chunks of QCHUNK consecutive queries from
+        // the shard's counter (one atomic per chunk) and gives the next one to whichever lane pair
+        // has finished (ballot + popcount, no further atomics).
+        const uint32_t QCHUNK = qchunk;
+        uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
+        bool drained = false;                  // the shard's counter ran past Q
+        size_t q = 0;          // the query this lane pair is stepping
+        bool has_q = false;
+        size_t nq = 0;         // the one it runs next, start record already prefetched
+        bool has_n = false;
+        ulonglong2 nrec = {0, 0};
+        uint64_t nword = 0;
+        int j = 0;
+        uint64_t word = 0, lo = 0, hi = 0;
+        // the lookup of the current step: `ready` = this side's Occ is in occ_hold; cont != 0 = the
+        // position lies past this window's own pieces and the lookup goes on, in the next pass, in
+        // the group's spill line (KIND_CHUNK: at dword cdw, base count cacc) or in far line cblk
+        bool ready = false;
+        uint64_t occ_hold = 0, cacc = 0;
+        uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0;
+
+        for (;;) {
+            // ---- a pair whose query ended in the last pass takes up the one it had prefetched: it
+            // steps in this very pass
+            bool done = false;
+            if (!has_q && has_n) {
+                has_q = true;
+                has_n = false;
+                q = nq;
+                if (nrec.x & INIT_INVALID) {
+                    lo = 1;
+                    hi = 0;
+                    j = -1;
+                    done = true;
+                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search
+                    lo = nrec.x & COUNT_MASK;
+                    hi = nrec.y;
+                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                    word = nword;
+                    done = lo > hi;  // the shared suffix was already absent (query.cpp:35-37)
+                    if (LONGK) {
+                        if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                    }
+                } else {
+                    const bool fallback = !ktab || (nrec.x & INIT_FALLBACK) != 0ull;
+                    lo = nrec.x & COUNT_MASK;
+                    hi = nrec.y;
+                    j = fallback ? (int)k - 2 : j_table;
+                    word = nword;
+                    if (COUNT_WORK && !fallback && side == 0u) w_ktab += 1;
+                    // a tabulated suffix that is already empty ends the search (query.cpp:35-37)
+                    done = (j < 0) || (!fallback && lo > hi);
+                    if (LONGK) {
+                        if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                    }
+                }
+            }
+            // ---- hand the next queries to the lane pairs that have none in reserve
+            if (pool_next >= pool_end && !drained) {
+                unsigned long long c = 0;
+                if (lane == 0u) c = atomicAdd(pool, (unsigned long long)QCHUNK);
+                c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                    __builtin_amdgcn_readfirstlane((uint32_t)c);
+                pool_next = c;
+                pool_end = c + QCHUNK < Q ? c + QCHUNK : Q;
+                if (c >= Q) { drained = true; pool_next = pool_end = 0; }
+            }
+            bool got_n = false;
+            {
+                const uint32_t want_mask = (uint32_t)__builtin_amdgcn_ballot_w64(!has_n);  // low half = pairs
+                const uint32_t before = __builtin_popcount(want_mask & ((1u << (lane & 31u)) - 1u));
+                const uint64_t mine = pool_next + before;
+                if (!has_n && mine < pool_end) {
+                    nq = (size_t)mine;
+                    got_n = true;
+                }
+                const uint64_t taken = pool_next + __builtin_popcount(want_mask);
+                pool_next = taken < pool_end ? taken : pool_end;
+            }
+            if (__builtin_amdgcn_ballot_w64(has_q || got_n) == 0ull) {
+                if (drained) break;
+                continue;  // pool exhausted mid-pass: refill at the top
+            }
+            // The two start-up loads of a query taken into reserve fly together with this pass's
+            // line fetches.
+            ulonglong2 rec = {0, 0};
+            uint64_t first_word = 0;
+            if (got_n) {
+                rec = init_s[nq];
+                first_word = packed[nq * wpq + w_table];
+            }
+            const bool alive = has_q;
+            const bool stepping = alive && !done;
+            const bool fresh = stepping && !ready && cont == 0u;  // starts the lookup of a new LF step
+
+            // ---- this lane's lookup: symbol, position -> window line
+            uint32_t b = 1, line = 0, o = 0, w = 0;
+            if (stepping) {
+                if (LONGK) {
+                    if (fresh && (j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                }
+                b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+            }
+            if (fresh) {
+                // traced search (1-mismatch): the interval this query has when about to take symbol j
+                if (trace && side == 0u && (uint32_t)j < trace_n) trace[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
+                // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
+                // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
+                // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
+                const uint64_t p = side ? hi : lo - 1ull;
+                if (p == ~0ull) {
+                    occ_hold = 0;
+                    ready = true;
+                } else {
+                    uint32_t pin;
+                    w = fast_window(p, S, inv, pin);
+                    line = w + (w >> GROUP_SHIFT);
+                    o = pin + 1u;
+                    if (line >= nlines) line = 0;  // never for p < n; keeps a bad position from faulting
+                    if (COUNT_WORK) w_occ += 1;
+                }
+            }
+            const bool looking = stepping && !ready;  // fetches this pass: a new lookup or a continuation
+            // C[b], with every lane active: a ds_bpermute returns 0 from a masked-off source lane
+            const uint64_t pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_hi) << 32) |
+                                (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_lo);
+            STAMP(0)  // pass set-up: symbol, position, line
+
+            // ---- fetch: one request per distinct line.  Lanes with nothing to look up ask for
+            // nothing, and the upper side of a query whose two positions fall in the same line reads
+            // the lower side's row instead of fetching the line again.
+            uint32_t want = looking ? (cont ? cblk : line) : ~0u;
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(want, want, false, false);  // full exec
+                const uint32_t other_want = side ? sw[0] : sw[1];
+                if (side != 0u && want == other_want) want = ~0u;
+            }
+            const bool shared_row = looking && want == ~0u;
+            if (COUNT_WORK && want != ~0u) {
+                if (cont) w_hops += 1;
+                else w_lines += 1;
+            }
+            glds_fetch(lines_bytes, want, lane, stage_lds);
+            STAMP(1)  // issue of the line loads
+            glds_wait();
+            STAMP(2)  // wait for the lines
+            const lds_u32 *mine0 = shared_row ? own_row - 4 * 32 : own_row;  // row of lane - 32
+
+            // ---- Occ(b, p) out of this lane's staged line.  RLEBWT::getOcc, src/bwt/rlebwt.cpp:268-301.
+            bool do_scan = false;
+            uint64_t base = 0;
+            uint32_t dw = HDR_DWORDS, rem = 0;
+            if (looking) {
+                if (cont != KIND_CHUNK) {
+                    // a window line (or the far line that continues it): the count word of symbol b and
+                    // the quarter starts
+                    const uint32_t oe = cont ? co : o;
+                    const uint2 cw = *reinterpret_cast<const lds_u2 *>(MINE(2u * (b - 1u)));
+                    const uint4 h0 = *reinterpret_cast<const lds_u4 *>(MINE(0));
+                    const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
+                    const uint32_t m0 = h0.y >> 8, m1 = h0.w >> 8;
+                    const uint32_t s1 = m0 & 0x3FFu, s2 = (m0 >> 10) & 0x7FFu;
+                    const uint32_t s3 = s2 + (m1 & 0x3FFu), span = s3 + ((m1 >> 10) & 0x3FFu);
+                    const uint32_t kind = (m1 >> 20) & 3u;
+                    if (oe <= span) {
+                        const uint32_t cq = (oe > s1 ? 1u : 0u) + (oe > s2 ? 1u : 0u) + (oe > s3 ? 1u : 0u);
+                        const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+                        // what quarters 0 and 1 hold of b
+                        const uint32_t hm = *MINE(5u + 2u * ((b - 1u) >> 1)) >> 8;
+                        const uint32_t hb = (hm >> (11u * ((b - 1u) & 1u))) & 0x7FFu;
+                        // an odd quarter also needs the quarter before it: added up 4 runs per dot4
+                        const uint32_t qd = HDR_DWORDS + 6u * (cq & 2u);
+                        const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(qd));
+                        const uint2 x1 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 2u));
+                        const uint2 x2 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 4u));
+                        const uint32_t bb = __umul24(b, 0x010101u) | (b << 24);  // b in every byte
+                        uint32_t m = dword_matched(x0.x, bb, 0u);
+                        m = dword_matched(x0.y, bb, m);
+                        m = dword_matched(x1.x, bb, m);
+                        m = dword_matched(x1.y, bb, m);
+                        m = dword_matched(x2.x, bb, m);
+                        m = dword_matched(x2.y, bb, m);
+                        base = cnt + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
+                        dw = HDR_DWORDS + 6u * cq;
+                        rem = oe - start;
+                        do_scan = true;
+                    } else if (kind == KIND_FAR) {
+                        cblk = *MINE(LINE_DWORDS - 1u);
+                        if (cblk >= nlines) cblk = 0;  // never for a built index
+                        cont = KIND_FAR;
+                        co = oe - span;
+                    } else if (kind == KIND_CHUNK && cont == 0u) {
+                        const uint32_t m2 = *MINE(5) >> 8, m3 = *MINE(7) >> 8;
+                        cacc = cnt;
+                        cdw = 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
+                        cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                        cont = KIND_CHUNK;
+                        co = oe - span;
+                    } else {  // a position beyond what the index holds: never for p < n
+                        base = cnt;
+                        do_scan = true;
+                    }
+                } else {
+                    // the spill chunk: what the window's own 96 pieces hold of b, then the excess pieces
+                    const uint2 hd = *reinterpret_cast<const lds_u2 *>(MINE(cdw));
+                    const uint32_t hw = (b <= 2u) ? hd.x : hd.y;
+                    const uint32_t tot = (hw >> (12u * ((b - 1u) & 1u))) & 0xFFFu;
+                    base = cacc + tot;
+                    dw = cdw + 2u;
+                    rem = co;
+                    do_scan = true;
+                }
+                // a window has at most 33 lines: the bound only guards against a corrupt chain, so that
+                // every wave drains
+                if (!do_scan && ++tries > 72u) do_scan = true;
+            }
+            // the scan of the (at most) 24 pieces at dword dw, run by run (rlebwt.cpp:281-298);
+            // lanes with nothing to scan take part with rem = 0
+            {
+                const uint2 y0 = *reinterpret_cast<const lds_u2 *>(MINE(dw & 31u));
+                const uint2 y1 = *reinterpret_cast<const lds_u2 *>(MINE((dw + 2u) & 31u));
+                const uint2 y2 = *reinterpret_cast<const lds_u2 *>(MINE((dw + 4u) & 31u));
+                const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
+                const uint32_t sc = runs_scan<6>(r6, b, rem);
+                if (do_scan) {
+                    occ_hold = base + sc;
+                    ready = true;
+                    cont = 0;
+                    tries = 0;
+                }
+            }
+            STAMP(3)  // rank out of LDS
+            // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
+            const uint32_t occ_hi = (uint32_t)(occ_hold >> 32) | (ready ? 0x80000000u : 0u);
+            const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ_hold, (uint32_t)occ_hold, false, false);
+            const auto sw_hi = __builtin_amdgcn_permlane32_swap(occ_hi, occ_hi, false, false);
+            const uint32_t other_hi = side ? sw_hi[0] : sw_hi[1];
+            const uint64_t other = ((uint64_t)(other_hi & 0x7FFFFFFFu) << 32) | (side ? sw_lo[0] : sw_lo[1]);
+            STAMP(4)  // exchange
+            if (stepping && ready && (other_hi & 0x80000000u)) {
+                const uint64_t occL = side ? other : occ_hold;
+                const uint64_t occU = side ? occ_hold : other;
+                if (COUNT_WORK && side == 0u) w_steps += 1;
+                lo = pb + occL;
+                hi = pb + occU - 1ull;
+                --j;
+                done = (lo > hi) || (j < 0);  // query.cpp:35-37
+                ready = false;
+            }
+            if (got_n) {
+                nrec = rec;
+                nword = first_word;
+                has_n = true;
+            }
+            if (alive && done) {
+                if (trace && side == 0u) {
+                    // the positions it never reached: a search resumed there ends where this one did
+                    for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
+                        trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
+                }
+                if (side == 0u) {
+                    if (COUNTS_ONLY) {
+                        out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                    } else {
+                        out_lo[q] = lo;
+                        out_up[q] = hi;
+                    }
+                }
+                has_q = false;
+            }
+            STAMP(5)  // update, start-up decode, result stores
+            if (COUNT_WORK) ++passes;
+        }
+    }
+    if (COUNT_WORK) {
+        if (lane == 0u) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&work[WORK_PHASE0 + i], ph[i]);
+            atomicAdd(&work[WORK_PASSES], passes);
+        }
+        if (w_steps) atomicAdd(&work[WORK_STEPS], w_steps);
+        if (w_occ) atomicAdd(&work[WORK_OCC], w_occ);
+        if (w_lines) atomicAdd(&work[WORK_LINES], w_lines);
+        if (w_ktab) atomicAdd(&work[WORK_KTAB], w_ktab);
+        if (w_hops) atomicAdd(&work[WORK_HOPS], w_hops);
+    }
+#undef MINE
+#undef STAMP
+}
+
+template <bool CW, bool CO>
+static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uint32_t nshards, const uint64_t *pk,
+                     const ulonglong2 *init, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
+                     uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n) {
+    // queries per draw from the pool: at least ~4 draws per wave, so that a batch of a few
+    // thousand queries (a service micro-batch, the k-mers of a 1-mismatch slice) still occupies
+    // every wave launched instead of the first few
+    uint32_t qchunk = 1024;
+    while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
+    if (wpq > 1)
+        hipLaunchKernelGGL((search_lines_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
+    else
+        hipLaunchKernelGGL((search_lines_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
+}
+
+hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
+                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+                         unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                         const search_extra *extra) {
+    if (Q == 0 || nshards == 0) return hipSuccess;
+    if (extra && nshards != 1) return hipErrorInvalidValue;  // traced / resumed searches: one shard
+    ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
+    const uint32_t trace_n = extra ? extra->trace_n : 0u;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    // 32 searches per wave, 4 waves per workgroup
+    const size_t per_wg = 32u * WG_WAVES;
+    size_t g = (Q * nshards + per_wg - 1) / per_wg;
+    // Workgroups per CU: LDS admits 5 (20 waves), but 4 are as fast (the request path, not the
+    // number of lookups in flight, is what saturates) and leave 32 KB of LDS and wave slots per CU
+    // to kernels that run beside the search -- RCCL's, when the previous batch's intervals are
+    // gathered at N > 1.  RSBWT_WAVE_WGS_PER_CU overrides.
+    static const int wgs_per_cu = [] {
+        const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 4;
+    }();
+    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    if (g > cap) g = cap;
+    const int grid = (int)g;
+    const uint64_t *pk = (const uint64_t *)d_packed;
+    const uint8_t *vd = (const uint8_t *)d_valid;
+    uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
+    // start records of this batch + the shards' query counters: stream-ordered scratch, so
+    // concurrent calls do not share state
+    const size_t nrec = Q * nshards;
+    ulonglong2 *init = nullptr;
+    hipError_t e = hipMallocAsync((void **)&init, nrec * sizeof(ulonglong2) + nshards * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    unsigned long long *ctr = (unsigned long long *)(init + nrec);
+    e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(init, stream);
+        return e;
+    }
+    const unsigned ig = (unsigned)((nrec + 255) / 256);
+    if (extra && extra->d_trace_in)
+        hipLaunchKernelGGL(search_init_1mm_kernel, dim3(ig), dim3(256), 0, stream, d_shards, pk, vd, Q, k, wpq,
+                           extra->variants, (const ulonglong2 *)extra->d_trace_in, trace_n, init);
+    else
+        hipLaunchKernelGGL(search_init_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq, init);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (d_work) {
+        if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        else launch_k<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+    } else {
+        if (counts_only) launch_k<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        else launch_k<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+    }
+    e = hipGetLastError();
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    const hipError_t e2 = hipFreeAsync(init, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+// Entries per k-mer of a traced search = the positions left of the k-mer table's reach (0: the
+// 1-mismatch search has nothing to share: no table, or k within it)
+uint32_t trace_entries(const shard_view &ix, uint32_t k) {
+    const bool ktab = ix.ktab != nullptr && ix.ktab_depth >= 2 && k >= ix.ktab_depth;
+    if (!ktab || k <= ix.ktab_depth || k - ix.ktab_depth > 0xFFFFu) return 0;
+    return k - ix.ktab_depth;
+}
+
+}  // namespace rsb

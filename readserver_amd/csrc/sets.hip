@@ -1,0 +1,484 @@
+// sets.hip -- shard sets: the shards one process holds on its GPU(s), searched by one
+// call.  Every query goes to every shard (src/service/server.cpp:124,578); per-shard results are only
+// concatenated (intervals) or summed (counts) (server.cpp:184-197,404-410).
+//
+// The shards of one device form a GROUP and are searched by ONE fused launch (search_lines.hip:
+// (query, shard) pairs drawn from per-shard pools): the batch is uploaded and packed once per device,
+// not once per shard.  Devices are driven concurrently, one host thread each.  With more than one
+// device the per-device count sums are reduced onto the first device over RCCL (xGMI) and cross PCIe
+// once; interval gathers onto one GPU are offered for GPU-resident consumers
+// (rsbwt_set_gather_intervals_dev).  RCCL is bound at run time (dlopen): a single-GPU deployment
+// needs no librccl.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/rsbwt.h"
+#include "capi_internal.h"
+
+using namespace rsb;
+
+namespace {
+
+#define HIP_OK(x)                                              \
+    do {                                                       \
+        hipError_t _e = (x);                                   \
+        if (_e != hipSuccess) return fail_hip(_e, #x);         \
+    } while (0)
+
+struct rccl_api {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+rccl_api &rccl() {
+    static rccl_api api = [] {
+        rccl_api a;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+#define RCCL_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, sym))
+        RCCL_SYM(CommInitAll, "ncclCommInitAll");
+        RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        RCCL_SYM(GroupStart, "ncclGroupStart");
+        RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        RCCL_SYM(Send, "ncclSend");
+        RCCL_SYM(Recv, "ncclRecv");
+        RCCL_SYM(Reduce, "ncclReduce");
+        RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+        a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.Reduce && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+
+// counts[S][m] -> sum[m]
+__global__ void __launch_bounds__(256)
+sum_rows_kernel(const uint64_t *__restrict__ rows, uint32_t S, size_t m, uint64_t *__restrict__ sum) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint64_t s = 0;
+    for (uint32_t r = 0; r < S; ++r) s += rows[(size_t)r * m + i];
+    sum[i] = s;
+}
+
+}  // namespace
+
+// the shards of one device
+struct dev_group : search_meter {
+    int device = 0;
+    int num_cus = 256;
+    std::vector<size_t> idx;         // positions in the set, ascending
+    shard_view *d_views = nullptr;   // [idx.size()] in HBM
+    ctx_pool pool;
+    ncclComm_t comm = nullptr;
+};
+
+struct rsbwt_set {
+    std::vector<rsbwt_t *> shards;
+    bool owns = false;
+    std::vector<dev_group *> groups;
+    bool comms_tried = false, comms_ok = false;
+    std::mutex mu;
+};
+
+namespace {
+
+int publish_views(rsbwt_set_t *s) {
+    for (dev_group *g : s->groups) {
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        std::vector<shard_view> v;
+        for (size_t i : g->idx) v.push_back(s->shards[i]->view);
+        HIP_OK(hipMemcpy(g->d_views, v.data(), v.size() * sizeof(shard_view), hipMemcpyHostToDevice));
+    }
+    return RSBWT_OK;
+}
+
+int make_groups(rsbwt_set_t *s) {
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        rsbwt_t *h = s->shards[i];
+        if (!h) return fail(RSBWT_EINVAL, "null shard handle");
+        dev_group *g = nullptr;
+        for (dev_group *x : s->groups)
+            if (x->device == h->device) g = x;
+        if (!g) {
+            g = new (std::nothrow) dev_group();
+            if (!g) return fail(RSBWT_ENOMEM, "host allocation failed");
+            g->device = h->device;
+            g->num_cus = h->num_cus;
+            s->groups.push_back(g);
+        }
+        g->idx.push_back(i);
+    }
+    for (dev_group *g : s->groups) {
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        HIP_OK(hipMalloc(&g->d_views, g->idx.size() * sizeof(shard_view)));
+        HIP_OK(hipMalloc(&g->d_work, WORK_WORDS * sizeof(unsigned long long)));
+        for (int i = 0; i < search_meter::RING; ++i) {
+            HIP_OK(hipEventCreate(&g->ev_start[i]));
+            HIP_OK(hipEventCreate(&g->ev_stop[i]));
+        }
+    }
+    return publish_views(s);
+}
+
+// one communicator per device group, all in this process (ncclCommInitAll); false = no RCCL here
+bool ensure_comms(rsbwt_set_t *s) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->comms_tried) return s->comms_ok;
+    s->comms_tried = true;
+    if (s->groups.size() < 2 || !rccl().ok) return false;
+    std::vector<int> devs;
+    for (dev_group *g : s->groups) devs.push_back(g->device);
+    std::vector<ncclComm_t> comms(devs.size());
+    if (rccl().CommInitAll(comms.data(), (int)devs.size(), devs.data()) != ncclSuccess) return false;
+    for (size_t i = 0; i < devs.size(); ++i) s->groups[i]->comm = comms[i];
+    s->comms_ok = true;
+    return true;
+}
+
+// runs fn(group index) for every device group, concurrently when there are several
+template <class F>
+int for_each_group(rsbwt_set_t *s, F &&fn) {
+    const size_t G = s->groups.size();
+    if (G == 1) return fn(0);
+    std::vector<int> rcs(G, RSBWT_OK);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; ++g)
+        th.emplace_back([&, g] {
+            rcs[g] = fn(g);
+            if (rcs[g]) errs[g] = rsbwt_last_error();  // the message is thread-local: carry it over
+        });
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < G; ++g)
+        if (rcs[g]) return fail(rcs[g], "%s", errs[g].c_str());
+    return RSBWT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rsbwt_set_close(rsbwt_set_t *s) {
+    if (!s) return;
+    for (dev_group *g : s->groups) {
+        (void)hipSetDevice(g->device);
+        g->pool.destroy();
+        if (g->comm && rccl().ok) (void)rccl().CommDestroy(g->comm);
+        if (g->d_views) (void)hipFree(g->d_views);
+        if (g->d_work) (void)hipFree(g->d_work);
+        for (int i = 0; i < search_meter::RING; ++i) {
+            if (g->ev_start[i]) (void)hipEventDestroy(g->ev_start[i]);
+            if (g->ev_stop[i]) (void)hipEventDestroy(g->ev_stop[i]);
+        }
+        delete g;
+    }
+    if (s->owns)
+        for (rsbwt_t *h : s->shards) rsbwt_close(h);
+    delete s;
+}
+
+int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
+    if (!out || (!handles && num_shards)) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    if (num_shards == 0) return fail(RSBWT_EINVAL, "a shard set needs at least one shard");
+    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
+    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
+    s->owns = false;
+    s->shards.assign(handles, handles + num_shards);
+    int rc = make_groups(s);
+    if (rc) { rsbwt_set_close(s); return rc; }
+    *out = s;
+    return RSBWT_OK;
+}
+
+int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
+                   uint32_t flags, rsbwt_set_t **out) {
+    if (!out || (!bwt_paths && num_shards)) return fail(RSBWT_EINVAL, "null argument");
+    *out = nullptr;
+    if (num_shards == 0) return fail(RSBWT_EINVAL, "a shard set needs at least one shard");
+    rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
+    if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
+    s->owns = true;
+    // The k-mer tables of the shards of one GPU share what HBM the lines leave, so with depth "auto"
+    // the shards are opened without tables and the depth is chosen per device afterwards.
+    const uint32_t T_req = (flags & RSBWT_KTAB_MASK) >> RSBWT_KTAB_SHIFT;
+    const uint32_t open_flags = T_req == 0u ? ((flags & ~RSBWT_KTAB_MASK) | RSBWT_KTAB_NONE) : flags;
+    for (size_t i = 0; i < num_shards; ++i) {
+        rsbwt_t *h = nullptr;
+        int rc = rsbwt_open(bwt_paths[i], device_map ? device_map[i] : 0, open_flags, &h);
+        if (rc) { rsbwt_set_close(s); return rc; }
+        s->shards.push_back(h);
+    }
+    int rc = make_groups(s);
+    if (rc == RSBWT_OK && T_req == 0u) rc = rsbwt_set_attach_ktabs(s, 0);
+    if (rc) { rsbwt_set_close(s); return rc; }
+    *out = s;
+    return RSBWT_OK;
+}
+
+// Builds the k-mer tables of the shards that have none.  depth 0 = per device, the deepest T whose
+// tables (one per shard of that device) fit a third of the device's free HBM, none larger than its
+// shard's lines, with 4^T <= the smallest shard's length; at most 16.
+int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    for (dev_group *g : s->groups) {
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        uint32_t T = depth;
+        if (T == 0u) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+            uint64_t min_n = ~0ull, min_bytes = ~0ull, need = 0;
+            for (size_t i : g->idx) {
+                const rsbwt_t *h = s->shards[i];
+                if (h->view.ktab || h->view.n == 0) continue;
+                ++need;
+                min_n = std::min(min_n, h->view.n);
+                min_bytes = std::min(min_bytes, h->hbm_bytes);
+            }
+            if (!need) continue;
+            const uint64_t budget = std::min<uint64_t>(min_bytes, free_b / 3 / need);
+            T = 1;
+            while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= min_n) ++T;
+            if (T < 2u) continue;
+        }
+        for (size_t i : g->idx) {
+            rc = rsbwt_attach_ktab(s->shards[i], T);
+            if (rc) return rc;
+        }
+    }
+    return publish_views(s);
+}
+
+size_t rsbwt_set_size(const rsbwt_set_t *s) { return s ? s->shards.size() : 0; }
+rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i) { return (s && i < s->shards.size()) ? s->shards[i] : nullptr; }
+size_t rsbwt_set_devices(const rsbwt_set_t *s) { return s ? s->groups.size() : 0; }
+
+// Host buffers.  lower/upper: [num_shards][Q] in the set's shard order.
+int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                             uint64_t *lower, uint64_t *upper) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers || !lower || !upper) return fail(RSBWT_EINVAL, "null argument");
+    if (stride < k) return fail(RSBWT_EINVAL, "stride %zu < k %u", stride, k);
+    const size_t S = s->shards.size();
+    if (k == 0) {
+        for (size_t i = 0; i < S * Q; ++i) { lower[i] = 1; upper[i] = 0; }
+        return RSBWT_OK;
+    }
+    for (rsbwt_t *h : s->shards)
+        if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index in the set");
+    return for_each_group(s, [&](size_t gi) -> int {
+        dev_group *g = s->groups[gi];
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        // a group's shards are searched into a [S_g][Q] block; when they sit next to each other in
+        // the set (the usual map: shard s -> GPU s / 8) that block IS the output
+        const size_t Sg = g->idx.size();
+        const bool contiguous = g->idx.back() - g->idx.front() + 1 == Sg;
+        if (contiguous)
+            return search_host_views(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, kmers, Q, k, stride,
+                                     lower + g->idx.front() * Q, upper + g->idx.front() * Q, false);
+        std::vector<uint64_t> lo(Sg * Q), up(Sg * Q);
+        rc = search_host_views(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, kmers, Q, k, stride, lo.data(), up.data(), false);
+        if (rc) return rc;
+        for (size_t j = 0; j < Sg; ++j) {
+            memcpy(lower + g->idx[j] * Q, lo.data() + j * Q, Q * 8);
+            memcpy(upper + g->idx[j] * Q, up.data() + j * Q, Q * 8);
+        }
+        return RSBWT_OK;
+    });
+}
+
+// counts[Q] summed over the set's shards, the way the front-end sums per-partition replies
+// (src/service/server.cpp:184-197): per device one fused search + a row sum; the per-device sums
+// are reduced onto the first device over RCCL when there are several, and cross PCIe once.
+int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
+    if (!s || (!counts && Q)) return fail(RSBWT_EINVAL, "null argument");
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers) return fail(RSBWT_EINVAL, "null argument");
+    if (stride < k) return fail(RSBWT_EINVAL, "stride %zu < k %u", stride, k);
+    if (k == 0) {
+        for (size_t q = 0; q < Q; ++q) counts[q] = 0;
+        return RSBWT_OK;
+    }
+    if (k > 65535u) return fail(RSBWT_ERANGE, "k %u: at most 65535 symbols per k-mer", k);
+    for (rsbwt_t *h : s->shards)
+        if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index in the set");
+    const size_t G = s->groups.size();
+    const bool use_rccl = G > 1 && ensure_comms(s);
+    const uint32_t wpq = k ? (k + 31u) / 32u : 1u;
+    const size_t SLICE = 1u << 20;
+    std::vector<std::vector<uint64_t>> part(use_rccl ? 0 : G);
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+        const size_t m = std::min(SLICE, Q - q0);
+        std::vector<call_ctx *> ctx(G, nullptr);
+        std::vector<uint64_t *> d_sum(G, nullptr);
+        // phase 1, per device concurrently: upload, pack, fused count search, row sum
+        int rc = for_each_group(s, [&](size_t gi) -> int {
+            dev_group *g = s->groups[gi];
+            int r = use_device(g->device);
+            if (r) return r;
+            call_ctx *c = g->pool.acquire();
+            if (!c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+            ctx[gi] = c;
+            const size_t Sg = g->idx.size();
+            const size_t ascii_bytes = (m - 1) * stride + k;
+            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+            if ((r = c->stage(a_ascii + a_pk + a_ok + (Sg + 2) * m * 8)) != RSBWT_OK) return r;
+            uint8_t *d_ascii = (uint8_t *)c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+            uint64_t *d_cnt = (uint64_t *)(d_ok + a_ok);
+            d_sum[gi] = d_cnt + Sg * m;  // followed by m more words: the reduced total on the root
+            hipStream_t st = c->st[0];
+            HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
+            if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+            r = search_launch(*g, g->d_views, (uint32_t)Sg, g->num_cus, d_pk, d_ok, m, k, d_cnt, nullptr, true, st, nullptr);
+            if (r) return r;
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_cnt, (uint32_t)Sg, m, d_sum[gi]);
+            HIP_OK(hipGetLastError());
+            if (!use_rccl) {
+                part[gi].resize(m);
+                HIP_OK(hipMemcpyAsync(part[gi].data(), d_sum[gi], m * 8, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+            }
+            return RSBWT_OK;
+        });
+        // phase 2: one sum over the devices
+        if (rc == RSBWT_OK && use_rccl) {
+            ncclResult_t nr = rccl().GroupStart();
+            for (size_t gi = 0; gi < G && nr == ncclSuccess; ++gi) {
+                (void)hipSetDevice(s->groups[gi]->device);
+                nr = rccl().Reduce(d_sum[gi], d_sum[gi] + m, m, ncclUint64, ncclSum, 0, s->groups[gi]->comm, ctx[gi]->st[0]);
+            }
+            const ncclResult_t ne = rccl().GroupEnd();
+            if (nr == ncclSuccess) nr = ne;
+            if (nr != ncclSuccess) rc = fail(RSBWT_EHIP, "ncclReduce: %s", rccl().GetErrorString(nr));
+            if (rc == RSBWT_OK) {
+                (void)hipSetDevice(s->groups[0]->device);
+                hipError_t e = hipMemcpyAsync(counts + q0, d_sum[0] + m, m * 8, hipMemcpyDeviceToHost, ctx[0]->st[0]);
+                for (size_t gi = 0; gi < G && e == hipSuccess; ++gi) {
+                    (void)hipSetDevice(s->groups[gi]->device);
+                    e = hipStreamSynchronize(ctx[gi]->st[0]);
+                }
+                if (e != hipSuccess) rc = fail_hip(e, "count reduction");
+            }
+        } else if (rc == RSBWT_OK) {
+            for (size_t i = 0; i < m; ++i) {
+                uint64_t t = 0;
+                for (size_t gi = 0; gi < G; ++gi) t += part[gi][i];
+                counts[q0 + i] = t;
+            }
+        }
+        for (size_t gi = 0; gi < G; ++gi)
+            if (ctx[gi]) {
+                (void)hipSetDevice(s->groups[gi]->device);
+                (void)hipStreamSynchronize(ctx[gi]->st[0]);
+                s->groups[gi]->pool.release(ctx[gi]);
+            }
+        if (rc) return rc;
+    }
+    return RSBWT_OK;
+}
+
+// Device-resident, for a set whose shards all sit on one device: one fused launch on `stream`;
+// d_lower/d_upper: [num_shards][Q].  Nothing is synchronised.
+int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                                 void *d_lower, void *d_upper, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    dev_group *g = s->groups[0];
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper,
+                         false, (hipStream_t)stream, nullptr);
+}
+
+int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                        void *d_counts, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    dev_group *g = s->groups[0];
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_counts, nullptr,
+                         true, (hipStream_t)stream, nullptr);
+}
+
+// Gathers per-device interval blocks onto the first device of the set over RCCL (xGMI): d_blocks[g]
+// = device g's [S_g][Q] x {lower, upper} block of `bytes[g]` bytes on that device; d_root on device 0
+// receives them back to back in device order.  One call per batch; nothing is synchronised beyond
+// the streams given (streams[g] on device g).  With one device it is a device-to-device copy.
+int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes, void *d_root,
+                                   void *const *streams) {
+    if (!s || !d_blocks || !bytes || !d_root || !streams) return fail(RSBWT_EINVAL, "null argument");
+    const size_t G = s->groups.size();
+    (void)hipSetDevice(s->groups[0]->device);
+    HIP_OK(hipMemcpyAsync(d_root, d_blocks[0], bytes[0], hipMemcpyDeviceToDevice, (hipStream_t)streams[0]));
+    if (G == 1) return RSBWT_OK;
+    if (!ensure_comms(s)) return fail(RSBWT_ENODEV, "RCCL is not available: cannot gather across devices");
+    size_t off = bytes[0];
+    ncclResult_t nr = rccl().GroupStart();
+    for (size_t g = 1; g < G && nr == ncclSuccess; ++g) {
+        (void)hipSetDevice(s->groups[g]->device);
+        nr = rccl().Send(d_blocks[g], bytes[g], ncclUint8, 0, s->groups[g]->comm, (hipStream_t)streams[g]);
+        if (nr != ncclSuccess) break;
+        (void)hipSetDevice(s->groups[0]->device);
+        nr = rccl().Recv((uint8_t *)d_root + off, bytes[g], ncclUint8, (int)g, s->groups[0]->comm, (hipStream_t)streams[0]);
+        off += bytes[g];
+    }
+    const ncclResult_t ne = rccl().GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return fail(RSBWT_EHIP, "RCCL gather: %s", rccl().GetErrorString(nr));
+    return RSBWT_OK;
+}
+
+int rsbwt_rccl_available(void) { return rccl().ok ? 1 : 0; }
+
+// measurement hooks of the set's first device group (bench.py)
+int rsbwt_set_set_counting(rsbwt_set_t *s, int on) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    for (dev_group *g : s->groups) {
+        std::lock_guard<std::mutex> lock(g->mu);
+        g->counting = on != 0;
+    }
+    return RSBWT_OK;
+}
+
+int rsbwt_set_search_history_ms(rsbwt_set_t *s, float *ms, size_t cap, size_t *count) {
+    if (!s || (!ms && cap) || !count) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(s->groups[0]->device);
+    if (rc) return rc;
+    return meter_history_ms(*s->groups[0], ms, cap, count);
+}
+
+int rsbwt_set_last_search_counters(rsbwt_set_t *s, uint64_t *words16) {
+    if (!s || !words16) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(s->groups[0]->device);
+    if (rc) return rc;
+    return meter_work(*s->groups[0], words16, WORK_WORDS);
+}
+
+}  // extern "C"

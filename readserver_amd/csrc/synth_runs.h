@@ -2,6 +2,9 @@
 // a pure function of (seed, i), so the GPU fill, the host fill and any slice agree bit for bit.
 // Lengths: 20 % full units (31, i.e. pieces of long runs), 20 % 6..21, 60 % 1..4 (mean ~10.4
 // symbols per byte, a population-BWT-like mix); symbols uniform over ACGT with ~1.2 % '$'.
+// Seeds with bit 63 set select the LONG-RUN stream (a deep population BWT, whose units are mostly
+// the 31-symbol pieces of long runs): blocks of 8 consecutive units, 80 % of them one run of
+// 7 x 31 + (1..31) symbols, the rest drawn as above -- mean ~25 symbols per byte.
 #ifndef RSBWT_SYNTH_RUNS_H
 #define RSBWT_SYNTH_RUNS_H
 
@@ -23,6 +26,14 @@ RSBWT_HD uint64_t synth_mix64(uint64_t z) {
 }
 
 RSBWT_HD uint8_t synth_run_byte(uint64_t seed, uint64_t i) {
+    if (seed >> 63) {
+        const uint64_t hb = synth_mix64(seed * 0xD1342543DE82EF95ull + 0x5BD1E9955BD1E995ull + (i >> 3));
+        if ((uint32_t)(hb % 10u) < 8u) {
+            const uint32_t sym = 1u + (uint32_t)((hb >> 8) & 3u);
+            const uint32_t len = (i & 7u) == 7u ? 1u + (uint32_t)((hb >> 16) % 31u) : 31u;
+            return (uint8_t)((sym << 5) | len);
+        }
+    }
     const uint64_t h = synth_mix64(seed * 0xD1342543DE82EF95ull + i);
     const uint32_t a = (uint32_t)(h & 0xFF);
     const uint32_t sym = a < 3u ? 0u : 1u + (uint32_t)((h >> 8) & 3u);

@@ -126,13 +126,13 @@ def test_gpu_one_mismatch_equals_composition_of_exact_searches(rsb, oracle, tmp_
         assert len(rsb.hits_1mm_batch(g, ["N" * k])) == 0
 
 
-@pytest.mark.parametrize("T,slots,k", [(2, True, 31), (6, False, 31), (12, True, 31), (12, False, 40), (9, True, 64),
-                                       (8, True, 9), (None, True, 20)])
-def test_gpu_one_mismatch_resumed_from_the_trace_equals_searching_every_variant(rsb, tmp_path, T, slots, k):
+@pytest.mark.parametrize("T,span,k", [(2, 0, 31), (6, 300, 31), (12, 0, 31), (12, 2944, 40), (9, 0, 64),
+                                      (8, 0, 9), (None, 0, 20)])
+def test_gpu_one_mismatch_resumed_from_the_trace_equals_searching_every_variant(rsb, tmp_path, T, span, k):
     """Variants left of the k-mer table's reach resume from their k-mer's traced search; the result
     must be what the exact search gives for every variant spelled out (itself held to the oracle
-    elsewhere), whatever the table depth (T = 2: wide entries, fallback starts), the layout, and
-    with k-mers that span several packed words."""
+    elsewhere), whatever the table depth (T = 2: wide entries, fallback starts), the window span
+    (2944: most lookups continue in far lines), and with k-mers that span several packed words."""
     bwt, rd = str(tmp_path / "s.bwt"), str(tmp_path / "s.reads")
     rsb.synth_popbwt(bwt, rd, seed=21, genome_len=60000, haplotypes=4, snp_rate=0.005, read_len=80, coverage=4.0)
     reads = open(rd).read().split()
@@ -147,7 +147,7 @@ def test_gpu_one_mismatch_resumed_from_the_trace_equals_searching_every_variant(
             w[p] = "ACGT"[("ACGT".index(w[p]) + 1 + rng.integers(3)) % 4]
         kmers.append("".join(w))
     kmers += ["A" * k, "T" * k, "ACGT" * (k // 4) + "A" * (k % 4), "N" + "A" * (k - 1)]
-    with rsb.GpuBWT(bwt, ktab_depth=T, slots=slots, dir_shift=8) as g:
+    with rsb.GpuBWT(bwt, ktab_depth=T, window_span=span) as g:
         lo, up = rsb.find_intervals_1mm(g, kmers)
         spelled = []
         for w in kmers:
@@ -215,17 +215,19 @@ def test_gpu_single_query_mirrors(rsb, gix, golden):
 
 # ---- oracle parity on seeded random run streams -------------------------------------------------
 
-@pytest.mark.parametrize("R,shift", [(1, 0), (2, 0), (95, 0), (96, 0), (97, 0), (1000, 0), (5000, 8),
-                                     (5000, 10), (70000, 0), (70000, 12), (300000, 9), (300000, 16)])
-def test_gpu_occ_char_vs_oracle(rsb, oracle, R, shift):
-    rng = np.random.default_rng(R + shift)
+@pytest.mark.parametrize("R,span", [(1, 0), (2, 0), (95, 0), (96, 0), (97, 0), (1000, 0), (5000, 2),
+                                    (5000, 37), (70000, 0), (70000, 2944), (300000, 700), (300000, 1800)])
+def test_gpu_occ_char_vs_oracle(rsb, oracle, R, span):
+    """The class BWT mirrors on every position, for windows of 2 symbols up to spans whose windows
+    continue in spill chunks and chains of far lines."""
+    rng = np.random.default_rng(R + span)
     runs = _random_runs(rng, R)
     oix = oracle.from_runs(runs)
-    with rsb.GpuBWT(runs=runs, dir_shift=shift) as g:
+    with rsb.GpuBWT(runs=runs, window_span=span) as g:
         n = g.getBWLen()
         assert n == oix.bwlen()
-        if shift:
-            assert g.dir_shift() == shift
+        if span:
+            assert g.window_span() == span
         assert [g.getPC(c) for c in "$ACGT"] == [oix.pc(c) for c in "$ACGT"]
         pos = np.arange(n, dtype=np.uint64) if n <= 200000 else np.unique(np.concatenate([
             rng.integers(0, n, 100000), np.arange(n - 5000, n), np.arange(5000)])).astype(np.uint64)
@@ -243,28 +245,30 @@ def test_gpu_occ_char_vs_oracle(rsb, oracle, R, shift):
                 assert np.array_equal(g.occ_at_batch(ch, bc), where[bc.astype(np.int64) - 1].astype(np.uint64))
 
 
-def test_gpu_dense_runs_force_directory_hops(rsb, oracle):
-    # all runs of length 1: 96-symbol blocks, so windows of 2^12 symbols hold ~42 block starts
+def test_gpu_dense_runs_force_far_line_chains(rsb, oracle):
+    # all runs of length 1: a window of S symbols has S pieces, so spans of 300 and 2944 put every
+    # window into chains of 3 and 32 far lines, which a lookup follows one line per pass
     rng = np.random.default_rng(9)
     runs = ((rng.integers(1, 5, 200000).astype(np.uint8)) << 5) | 1
     oix = oracle.from_runs(runs)
-    for shift in (8, 12, 16):
-        with rsb.GpuBWT(runs=runs, dir_shift=shift) as g:
+    for span in (0, 300, 2944):
+        with rsb.GpuBWT(runs=runs, window_span=span) as g:
+            assert (g.far_lines() > 0) == (span > 0)
             km = _random_kmers(rng, 20000, 9)
             lo, up = rsb.find_intervals(g, km)
             elo, eup = oix.find_intervals(km)
             assert np.array_equal(lo, elo) and np.array_equal(up, eup)
 
 
-@pytest.mark.parametrize("slots", [True, False])
+@pytest.mark.parametrize("span", [0, 1900])
 @pytest.mark.parametrize("R,with_dollar", [(1, True), (2, False), (17, True), (50, True), (65, False), (3000, False),
                                            (200000, True), (4000000, True)])
-def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar, slots):
+def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar, span):
     rng = np.random.default_rng(77 + R)
     runs = _random_runs(rng, R, with_dollar)
     oix = oracle.from_runs(runs)
-    with rsb.GpuBWT(runs=runs, slots=slots) as g:
-        assert (g.slot_span() > 0) == slots
+    with rsb.GpuBWT(runs=runs, window_span=span) as g:
+        assert g.window_span() == span or span == 0
         for k in (1, 2, 7, 16, 31, 32, 33, 64, 65, 100):
             Q = 3000 if R < 1000000 else 20000
             km = _random_kmers(rng, Q, k)
@@ -276,16 +280,15 @@ def test_gpu_find_intervals_vs_oracle(rsb, oracle, R, with_dollar, slots):
             assert np.array_equal(cnt, np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64))
 
 
-@pytest.mark.parametrize("slots", [True, False])
-@pytest.mark.parametrize("dir_shift", [8, 10])
-def test_gpu_interval_at_the_top_of_a_bwt_without_terminators(rsb, oracle, slots, dir_shift):
+@pytest.mark.parametrize("span", [0, 1000])
+def test_gpu_interval_at_the_top_of_a_bwt_without_terminators(rsb, oracle, span):
     """No '$' => C[A] = 0, so searches can sit at lower == 0, and a step that finds no b there gives
     upper = 0 + 0 - 1 = 2^64 - 1.  The reference does not see that as empty (unsigned compare,
     query.cpp:35) and takes one more step with Occ(b, 2^64 - 1) = 0 (rlebwt.cpp:269); so must we."""
     rng = np.random.default_rng(12)
     runs = (rng.integers(1, 5, 60000).astype(np.uint8) << 5) | 31   # long runs: many such cases
     oix = oracle.from_runs(runs)
-    with rsb.GpuBWT(runs=runs, slots=slots, dir_shift=dir_shift, ktab_depth=None) as g:
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=None) as g:
         km = _random_kmers(rng, 30000, 24)
         km[:, 12:23] = ord("A")      # ...AAAAAAAAAAAX: the poly-A suffix keeps lower at 0
         lo, up, steps = oix.find_intervals(km, want_steps=True)
@@ -436,8 +439,8 @@ def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     torch.cuda.synchronize()
     runs = d_runs.cpu().numpy()
     oix = oracle.from_runs(runs)
-    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None, slots=False)  # every LF step is taken
-    assert g.ktab_depth() == 0 and g.slot_span() == 0
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None)  # every LF step is taken
+    assert g.ktab_depth() == 0
     Q, k = 50000, 31
     km = _random_kmers(rng, Q, k)
     d_km = torch.from_numpy(km).cuda()
@@ -459,10 +462,12 @@ def test_gpu_device_entry_points_and_work_counters(rsb, oracle):
     assert np.array_equal(d_up.cpu().numpy().view(np.uint64), eup)
     assert st.value == int(steps.sum())
     assert oc.value == 2 * st.value and st.value <= bl.value <= oc.value
-    # distinct blocks, independently: lower-1 and upper share a block iff no block starts in between
-    ends = np.cumsum((runs & 31).astype(np.int64))
-    P0 = np.concatenate([[0], ends[95::96]])
-    assert bl.value > st.value  # wide intervals early in a search do span blocks
+    assert bl.value > st.value  # wide intervals early in a search do span windows
+    # distinct window lines, independently: lower-1 and upper share a line iff they share a window
+    w = (C.c_uint64 * 16)()
+    assert L.rsbwt_last_search_counters(g.handle, w) == 0
+    assert (w[0], w[1], w[2]) == (st.value, oc.value, bl.value)
+    assert w[11] <= 0.05 * w[2]  # continuation lines: the few lookups past their window's own pieces
     assert L.rsbwt_set_counting(g.handle, 0) == 0
     d_cnt = torch.empty(Q, dtype=torch.int64, device="cuda:0")
     assert L.rsbwt_count_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_cnt), s) == 0
@@ -500,20 +505,22 @@ def test_gpu_file_open_and_shard_set(rsb, oracle, tmp_path):
         g.close()
 
 
-@pytest.mark.parametrize("style,span", [("synth", 0), ("synth", 256), ("synth", 1536), ("synth", 3968),
-                                        ("dense", 0), ("dense", 3968), ("long", 0), ("long", 256),
+@pytest.mark.parametrize("style,span", [("synth", 0), ("synth", 256), ("synth", 1536), ("synth", 2944),
+                                        ("dense", 0), ("dense", 2944), ("long", 0), ("long", 256),
                                         ("mixed", 0), ("mixed", 768)])
-def test_gpu_slot_layout_is_bit_exact(rsb, oracle, style, span):
-    """The single-request layout: runs split at slot borders, overflow chains for windows with more
-    than 64 pieces (forced by large spans over short runs), half-empty slots (small spans over long
-    runs) -- the same intervals as the oracle and as the classic layout."""
+def test_gpu_window_layout_is_bit_exact(rsb, oracle, style, span):
+    """The window-line layout: runs split at window borders, spill chunks for windows of 97..120
+    pieces, chains of far lines beyond (forced by large spans over short runs), half-empty lines
+    (small spans over long runs) -- the same intervals as the oracle, and the builder on the GPU
+    lays the index out exactly as the same code does on the host (layout self-test)."""
+    import ctypes as C
     L = rsb.lib()
     rng = np.random.default_rng(len(style) * 1000 + span)
     R = 300000
     if style == "synth":
         runs = np.empty(R, np.uint8)
         assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 555) == 0
-    elif style == "dense":   # every run of length 1: 96 symbols per 96 pieces
+    elif style == "dense":   # every run of length 1
         runs = (rng.integers(1, 5, R).astype(np.uint8) << 5) | 1
     elif style == "long":    # every unit full: 31 symbols per piece
         runs = (rng.integers(1, 5, R).astype(np.uint8) << 5) | 31
@@ -521,27 +528,27 @@ def test_gpu_slot_layout_is_bit_exact(rsb, oracle, style, span):
         ln = np.where((np.arange(R) // 5000) % 2 == 0, 1, 31).astype(np.uint8)
         runs = (rng.integers(0, 5, R).astype(np.uint8) << 5) | ln
     oix = oracle.from_runs(runs)
-    with rsb.GpuBWT(runs=runs, slots=True, slot_span=span, ktab_depth=None) as g, \
-            rsb.GpuBWT(runs=runs, slots=False, ktab_depth=None) as classic:
-        S = g.slot_span()
-        assert S > 0 and S % 128 == 0 and S < 4096
-        if span:
-            assert S <= span * 1.04
-        if style == "dense" or (style in ("synth", "mixed") and span >= 1536):
-            assert g.slot_overflow_blocks() > 0
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=None) as g:
+        S = g.window_span()
+        assert 2 <= S <= 2944 and (S == span or span == 0)
+        if (style == "dense" and span) or (style in ("synth", "mixed") and span >= 1536):
+            assert g.far_lines() > 0
         if style == "long":
-            assert g.slot_overflow_blocks() == 0
-        n = g.getBWLen()
+            assert g.far_lines() == 0 and g.spilled_symbols() == 0
+        if span == 0:
+            assert g.spilled_symbols() <= 0.025 * g.getBWLen()
+        # the same layout decisions as the host-side run of the builder's code
+        st = (C.c_uint64 * 6)()
+        bad = C.c_uint64()
+        assert L.rsbwt_layout_selftest_host(runs.ctypes.data, R, S, st, C.byref(bad)) == 0
+        assert (st[0], st[1], st[2], st[5]) == (S, g.num_lines(), g.far_lines(), g.spilled_symbols())
         for k in (1, 2, 9, 31, 40):
             km = _random_kmers(rng, 20000, k)
             km[::11] = km[0]
             lo, up = rsb.find_intervals(g, km)
             elo, eup = oix.find_intervals(km, nthreads=8)
             assert np.array_equal(lo, elo) and np.array_equal(up, eup), (style, span, k)
-            clo, cup = rsb.find_intervals(classic, km)
-            assert np.array_equal(lo, clo) and np.array_equal(up, cup)
-        # k-mers that exist (long matches walk through many slots)
-        import ctypes as C
+        # k-mers that exist (long matches walk through many windows)
         import torch
         d = torch.empty((4000, 31), dtype=torch.uint8, device="cuda:0")
         if L.rsbwt_sample_present_kmers_dev(g.handle, 4000, 31, 31, 5, C.c_void_p(d.data_ptr()), None) == 0:
@@ -565,7 +572,7 @@ def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T):
     rng = np.random.default_rng(T)
     with rsb.GpuBWT(runs=runs, ktab_depth=T) as g, rsb.GpuBWT(runs=runs, ktab_depth=None) as plain:
         assert g.ktab_depth() == T and plain.ktab_depth() == 0
-        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T  # both carry the same slot layout
+        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T  # both carry the same lines
         for k in sorted({1, T - 1, T, T + 1, 12, 31, 32, 33, 32 + T // 2, 64, 65, 97}):
             if k < 1:
                 continue
@@ -618,27 +625,32 @@ def test_gpu_kmer_table_auto_depth_and_counters(rsb, oracle):
 # ---- full-size properties (sizes the oracle cannot sweep exhaustively) --------------------------
 
 def test_gpu_large_index_properties(rsb, oracle):
-    """R = 2^28 run bytes (~2.8e9 symbols, > 2^32 positions is exercised by 40-bit counts in the
-    headers): sum_b Occ(b, p) == p + 1, Occ monotone, BWT[OccAt(b, c)] == b, and a sampled
-    comparison with the oracle built over the same bytes."""
+    """R = 6e8 run bytes = 6.2e9 symbols: positions, counts and intervals beyond 2^32 (the high byte
+    of the 40-bit counts, 64-bit window arithmetic).  sum_b Occ(b, p) == p + 1, Occ monotone,
+    BWT[OccAt(b, c)] == b, and Occ / 31-mer intervals against the oracle built over the same bytes,
+    sampled where p > 2^32."""
     import ctypes as C
     import torch
     L = rsb.lib()
-    R = 1 << 28
+    R = 600_000_000
     d_runs = torch.empty(R, dtype=torch.uint8, device="cuda:0")
     assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, 77, 0, None) == 0
     torch.cuda.synchronize()
     g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
     n = g.getBWLen()
-    assert n > (1 << 31)
+    assert n > (1 << 32) + (1 << 30) and g.ktab_depth() >= 12
     rng = np.random.default_rng(4)
-    pos = np.sort(rng.integers(0, n, 200000)).astype(np.uint64)
+    pos = np.sort(np.concatenate([rng.integers(0, n, 100000), rng.integers(1 << 32, n, 100000),
+                                  [(1 << 32) - 1, 1 << 32, (1 << 32) + 1, n - 1]])).astype(np.uint64)
     tot = np.zeros(pos.size, np.uint64)
+    occ = {}
     for ch in "$ACGT":
         o = g.occ_batch(ch, pos)
         assert (np.diff(o.astype(np.int64)) >= 0).all()
         tot += o
+        occ[ch] = o
     assert np.array_equal(tot, pos + 1)
+    assert occ["A"][-1] > (1 << 30) and g.getPC("T") > (1 << 32)
     for ch in "ACGT":
         last = g.getOcc(ch, n - 1)
         assert g.getPC(ch) + last == (g.getPC("ACGT"["ACGT".index(ch) + 1]) if ch != "T" else n)
@@ -649,8 +661,208 @@ def test_gpu_large_index_properties(rsb, oracle):
     runs = d_runs.cpu().numpy()
     del d_runs
     oix = oracle.from_runs(runs)
-    km = _random_kmers(rng, 200000, 31)
+    hi = pos[pos > (1 << 32)][::400]
+    for ch in "$ACGT":
+        got = occ[ch][pos > (1 << 32)][::400]
+        assert all(int(x) == oix.occ(ch, int(p)) for x, p in zip(got, hi)), ch
+    # 31-mers: random (die early) and drawn from the index (all 30 steps, intervals beyond 2^32)
+    km = _random_kmers(rng, 100000, 31)
+    d = torch.empty((100000, 31), dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_sample_present_kmers_dev(g.handle, 100000, 31, 31, 5, C.c_void_p(d.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    km = np.concatenate([km, d.cpu().numpy()])
     lo, up = rsb.find_intervals(g, km)
     elo, eup = oix.find_intervals(km, nthreads=16)
     assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+    assert (lo[100000:] > (1 << 32)).sum() > 10000 and (up[100000:] >= lo[100000:]).all()
     g.close()
+
+
+# ---- query / query_exactmatch behind the C-ABI (a13), pinned by the compiled reference ------------
+
+def test_gpu_golden_query_and_query_exactmatch(rsb, gix, golden_dir):
+    """rsbwt_query / rsbwt_query_exactmatch against the reference's own answers (query.cpp:87-120;
+    tests/golden/make_query_golden.py): the same reads in the same order, the same booleans."""
+    gq = np.load(os.path.join(golden_dir, "query_v1.npz"))
+    for L_ in (70, 69, 40):
+        got = rsb.query_exactmatch_batch(gix, gq[f"em_w{L_}"])
+        assert np.array_equal(got, gq[f"em_ans{L_}"].astype(bool)), L_
+    assert rsb.query_exactmatch_batch(gix, gq["em_w70"]).sum() > 100
+    for k in (25, 31, 45):
+        want_first, want_reads, want_len = gq[f"q_first{k}"], gq[f"q_reads{k}"], gq[f"q_len{k}"]
+        got = rsb.query_batch(gix, gq[f"q_w{k}"], read_stride=96)
+        assert len(got) == want_first.size - 1
+        for q, reads in enumerate(got):
+            exp = [want_reads[r, :want_len[r]].tobytes().decode() for r in range(int(want_first[q]), int(want_first[q + 1]))]
+            assert reads == exp, (k, q)
+    # single-string mirrors
+    w = gq["q_w31"][0].tobytes().decode()
+    assert rsb.query(gix, w) == rsb.query_batch(gix, [w])[0] and len(rsb.query(gix, w)) > 0
+    assert rsb.query(gix, "ACGN") == [] and not rsb.query_exactmatch(gix, "ACGN")
+
+
+# ---- thread safety (include/rsbwt.h): one handle, concurrent host callers -------------------------
+
+def test_gpu_concurrent_callers_share_one_handle(rsb, oracle):
+    """The reference answers from 8 + 64 pool threads on one shared BWT* (service.cpp:88-89,
+    1532-1569).  Eight host threads hammer one handle with every host entry point at once; each must
+    get exactly what a lone caller gets."""
+    import threading
+    L = rsb.lib()
+    runs = np.empty(1500000, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, runs.size, 404) == 0
+    oix = oracle.from_runs(runs)
+    g = rsb.GpuBWT(runs=runs, ktab_depth=8)
+    n = g.getBWLen()
+    work = []
+    for t in range(8):
+        rng = np.random.default_rng(1000 + t)
+        km = _random_kmers(rng, 30000 + 1000 * t, 31 if t % 2 else 20)
+        pos = rng.integers(0, n, 20000).astype(np.uint64)
+        rows = rng.integers(0, n, 300).astype(np.uint64)
+        work.append((km, pos, rows))
+    expect = []
+    for km, pos, rows in work:  # serial pass
+        expect.append((rsb.find_intervals(g, km), rsb.count_kmers(g, km), g.occ_batch("C", pos), g.char_batch(pos),
+                       rsb.extract_reads(g, rows, stride=4096)[0], rsb.find_intervals_1mm(g, km[:200])))
+    elo, eup = oix.find_intervals(work[0][0], nthreads=8)
+    assert np.array_equal(expect[0][0][0], elo) and np.array_equal(expect[0][0][1], eup)
+    errors = []
+
+    def run(t):
+        try:
+            km, pos, rows = work[t]
+            for _ in range(3):
+                lo, up = rsb.find_intervals(g, km)
+                assert np.array_equal(lo, expect[t][0][0]) and np.array_equal(up, expect[t][0][1])
+                assert np.array_equal(rsb.count_kmers(g, km), expect[t][1])
+                assert np.array_equal(g.occ_batch("C", pos), expect[t][2])
+                assert np.array_equal(g.char_batch(pos), expect[t][3])
+                assert rsb.extract_reads(g, rows, stride=4096)[0] == expect[t][4]
+                l1, u1 = rsb.find_intervals_1mm(g, km[:200])
+                assert np.array_equal(l1, expect[t][5][0]) and np.array_equal(u1, expect[t][5][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    g.close()
+
+
+# ---- shard sets: one fused launch over the shards of a device --------------------------------------
+
+def test_gpu_shard_set_fused_launch_device_resident(rsb, oracle):
+    """rsbwt_set_find_intervals_dev / _count_dev: 5 shards of different sizes and table depths on
+    device 0 searched by ONE launch ((query, shard) pairs drawn from per-shard pools), [S][Q]
+    results against each shard's oracle; the set-level work counters add up."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    sizes = [200000, 1, 70000, 1200000, 333333]
+    shards, oixs = [], []
+    for i, R in enumerate(sizes):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 900 + i) == 0
+        oixs.append(oracle.from_runs(runs))
+        shards.append(rsb.GpuBWT(runs=runs, ktab_depth=[None, None, 5, 9, 0][i], window_span=[0, 0, 300, 0, 1700][i]))
+    ss = rsb.ShardSet(shards)
+    assert L.rsbwt_set_devices(ss._s) == 1
+    rng = np.random.default_rng(6)
+    for k, Q in ((31, 50000), (12, 20000), (40, 7000)):
+        km = _random_kmers(rng, Q, k)
+        km[5, 3] = ord("N")
+        d_km = torch.from_numpy(km).cuda()
+        wpq = (k + 31) // 32
+        d_pk = torch.empty((Q, wpq), dtype=torch.int64, device="cuda:0")
+        d_ok = torch.empty(Q, dtype=torch.uint8, device="cuda:0")
+        d_lo = torch.empty((len(sizes), Q), dtype=torch.int64, device="cuda:0")
+        d_up = torch.empty((len(sizes), Q), dtype=torch.int64, device="cuda:0")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, None) == 0
+        assert L.rsbwt_set_set_counting(ss._s, 1) == 0
+        assert L.rsbwt_set_find_intervals_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(d_lo), p(d_up), None) == 0
+        torch.cuda.synchronize()
+        w = (C.c_uint64 * 16)()
+        assert L.rsbwt_set_last_search_counters(ss._s, w) == 0
+        assert L.rsbwt_set_set_counting(ss._s, 0) == 0
+        lo, up = d_lo.cpu().numpy().view(np.uint64), d_up.cpu().numpy().view(np.uint64)
+        steps = 0
+        for s, oix in enumerate(oixs):
+            elo, eup, st = oix.find_intervals(km, nthreads=8, want_steps=True)
+            assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup), (k, s)
+            T = shards[s].ktab_depth()
+            steps += int(np.maximum(st.astype(np.int64) - (max(T, 1) - 1 if k >= T else 0), 0).sum())
+        assert w[0] == steps and w[2] <= w[1] <= 2 * w[0]
+        d_cnt = torch.empty((len(sizes), Q), dtype=torch.int64, device="cuda:0")
+        assert L.rsbwt_set_count_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(d_cnt), None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d_cnt.cpu().numpy().view(np.uint64), np.where(up >= lo, up - lo + 1, 0).astype(np.uint64))
+        # host entry points of the set: the same intervals, counts summed over the shards
+        hlo, hup = ss.find_intervals(km)
+        assert np.array_equal(hlo, lo) and np.array_equal(hup, up)
+        assert np.array_equal(ss.count(km), np.where(up >= lo, up - lo + 1, 0).sum(0).astype(np.uint64))
+    ms = (C.c_float * 8)()
+    cnt = C.c_size_t()
+    assert L.rsbwt_set_search_history_ms(ss._s, ms, 8, C.byref(cnt)) == 0 and cnt.value == 8 and min(ms) > 0
+    ss.close()
+    for g in shards:
+        g.close()
+
+
+def test_gpu_set_open_sizes_the_tables_per_device(rsb, oracle, tmp_path):
+    kw = dict(seed=14, genome_len=30000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=3.0)
+    import ctypes as C
+    L = rsb.lib()
+    paths = []
+    for s in range(3):
+        p = str(tmp_path / f"s{s}.bwt")
+        rsb.synth_popbwt(p, None, shard=s, num_shards=3, **kw)
+        paths.append(p)
+    arr = (C.c_char_p * 3)(*[p.encode() for p in paths])
+    h = C.c_void_p()
+    assert L.rsbwt_set_open(arr, 3, None, 0, C.byref(h)) == 0
+    depths = [L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, i)) for i in range(3)]
+    assert len(set(depths)) == 1 and depths[0] >= 6  # one depth for the device's shards
+    rng = np.random.default_rng(3)
+    km = _random_kmers(rng, 5000, 31)
+    lo = np.empty((3, 5000), np.uint64)
+    up = np.empty((3, 5000), np.uint64)
+    assert L.rsbwt_set_find_intervals(h, km.ctypes.data, 5000, 31, 31, lo.ctypes.data, up.ctypes.data) == 0
+    for s in range(3):
+        elo, eup = oracle.load(paths[s]).find_intervals(km)
+        assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup)
+    L.rsbwt_set_close(h)
+
+
+def test_gpu_reference_query_cpp_runs_on_the_shim(rsb, oracle, fixture_bwt, golden_dir):
+    """oracle/_ref/shim_demo = the reference's unmodified src/bwt/query.cpp linked with
+    `class GpuBWT : public BWT` (include/rsbwt_gpubwt.hpp), built in the build container.  Here every
+    virtual call of the reference's own findInterval / query / query_exactmatch is one GPU round trip;
+    the answers must be the reference's (golden) ones."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(golden_dir), "..", "oracle", "_ref", "shim_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_demo is built only where the reference tree exists")
+    path, _ = fixture_bwt
+    g31 = np.load(os.path.join(golden_dir, "popbwt_v1.npz"))
+    gq = np.load(os.path.join(golden_dir, "query_v1.npz"))
+    ws = [g31["kmers31"][i].tobytes().decode() for i in (0, 1, 5003, 10005)]
+    ws += [gq["q_w45"][i].tobytes().decode() for i in (0, 1)] + [gq["em_w70"][i].tobytes().decode() for i in (0, 1, 2, 3)]
+    p = subprocess.run([exe, path] + ws, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.strip().split("\n")
+    assert len(lines) == len(ws)
+    for j, i in enumerate((0, 1, 5003, 10005)):
+        f = lines[j].split()
+        assert (int(f[0]), int(f[1])) == (int(g31["lower31"][i]), int(g31["upper31"][i]))
+    for j, i in enumerate((0, 1)):
+        f = lines[4 + j].split()
+        a, b = int(gq["q_first45"][i]), int(gq["q_first45"][i + 1])
+        want = [gq["q_reads45"][r, :gq["q_len45"][r]].tobytes().decode() for r in range(a, b)]
+        assert int(f[3]) == len(want) and f[4:] == want
+    for j, i in enumerate((0, 1, 2, 3)):
+        assert int(lines[6 + j].split()[2]) == int(gq["em_ans70"][i])

@@ -1,0 +1,55 @@
+"""CPU suite: the window-line layout (readserver_amd/csrc/line_format.h).  The builder's code and
+the scalar readers are plain C++ shared by host and kernels; here they are run on the host and held
+to naive ranks at every position.  No query path is involved (rsbwt_layout_selftest_host answers
+none): all searches run on the GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _runs(style, R, rng, L):
+    if style == "synth":
+        r = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(r.ctypes.data, R, 555) == 0
+        return r
+    if style == "dense":
+        return (rng.integers(1, 5, R).astype(np.uint8) << 5) | 1
+    if style == "long":
+        return (rng.integers(1, 5, R).astype(np.uint8) << 5) | 31
+    if style == "mixed":
+        ln = np.where((np.arange(R) // 5000) % 2 == 0, 1, 31).astype(np.uint8)
+        return (rng.integers(0, 5, R).astype(np.uint8) << 5) | ln
+    return (rng.integers(0, 5, R).astype(np.uint8) << 5) | rng.integers(1, 32, R).astype(np.uint8)
+
+
+@pytest.mark.parametrize("style,R,span", [("synth", 60000, 0), ("synth", 60000, 256), ("synth", 60000, 1536),
+                                          ("synth", 60000, 2944), ("dense", 30000, 0), ("dense", 30000, 2944),
+                                          ("dense", 20000, 300), ("long", 30000, 0), ("long", 30000, 256),
+                                          ("mixed", 60000, 0), ("mixed", 60000, 768), ("rand", 40000, 0),
+                                          ("rand", 1, 0), ("rand", 2, 0), ("rand", 97, 0), ("rand", 17, 5),
+                                          ("rand", 3000, 2), ("rand", 3000, 3)])
+def test_layout_is_exact_at_every_position(rsb, style, R, span):
+    L = rsb.lib()
+    rng = np.random.default_rng(R + span)
+    runs = _runs(style, R, rng, L)
+    st = (C.c_uint64 * 6)()
+    bad = C.c_uint64()
+    rc = L.rsbwt_layout_selftest_host(runs.ctypes.data, R, span, st, C.byref(bad))
+    assert rc == 0, f"first disagreement at position {bad.value}"
+    S, nlines, far, chunkw, farw, spilled = list(st)
+    n = int((runs & 31).astype(np.int64).sum())
+    assert 2 <= S <= 2944 and (span == 0 or S == span)
+    assert nlines == ((n + S - 1) // S + 15) // 16 * 17 + far
+    if span == 0 and style != "mixed":  # (the GPU builder also shrinks S when stretches differ: build_lines.hip)
+        assert spilled <= 0.03 * n  # ~90 pieces per window: few positions past their line
+    if style == "dense" and span:
+        assert far > 0 and farw > 0
+    if style == "synth" and span == 0:
+        assert chunkw > 0 and nlines * 128 < 1.62 * R  # ~1.55 bytes per run byte
+
+
+def test_layout_rejects_symbols_above_four(rsb):
+    L = rsb.lib()
+    runs = np.array([(1 << 5) | 3, (6 << 5) | 2], np.uint8)
+    assert L.rsbwt_layout_selftest_host(runs.ctypes.data, 2, 0, None, None) == -3
