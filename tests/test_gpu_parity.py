@@ -535,7 +535,7 @@ def test_gpu_window_layout_is_bit_exact(rsb, oracle, style, span):
             assert g.far_lines() > 0
         if style == "long":
             assert g.far_lines() == 0 and g.spilled_symbols() == 0
-        if span == 0:
+        if span == 0 and style != "mixed":  # (no single span suits stretches of 1- and 31-symbol runs)
             assert g.spilled_symbols() <= 0.025 * g.getBWLen()
         # the same layout decisions as the host-side run of the builder's code
         st = (C.c_uint64 * 6)()
@@ -818,21 +818,21 @@ def test_gpu_set_open_sizes_the_tables_per_device(rsb, oracle, tmp_path):
     import ctypes as C
     L = rsb.lib()
     paths = []
-    for s in range(3):
+    for s in range(4):
         p = str(tmp_path / f"s{s}.bwt")
-        rsb.synth_popbwt(p, None, shard=s, num_shards=3, **kw)
+        rsb.synth_popbwt(p, None, shard=s, num_shards=4, **kw)
         paths.append(p)
-    arr = (C.c_char_p * 3)(*[p.encode() for p in paths])
+    arr = (C.c_char_p * 4)(*[p.encode() for p in paths])
     h = C.c_void_p()
-    assert L.rsbwt_set_open(arr, 3, None, 0, C.byref(h)) == 0
-    depths = [L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, i)) for i in range(3)]
+    assert L.rsbwt_set_open(arr, 4, None, 0, C.byref(h)) == 0
+    depths = [L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, i)) for i in range(4)]
     assert len(set(depths)) == 1 and depths[0] >= 6  # one depth for the device's shards
     rng = np.random.default_rng(3)
     km = _random_kmers(rng, 5000, 31)
-    lo = np.empty((3, 5000), np.uint64)
-    up = np.empty((3, 5000), np.uint64)
+    lo = np.empty((4, 5000), np.uint64)
+    up = np.empty((4, 5000), np.uint64)
     assert L.rsbwt_set_find_intervals(h, km.ctypes.data, 5000, 31, 31, lo.ctypes.data, up.ctypes.data) == 0
-    for s in range(3):
+    for s in range(4):
         elo, eup = oracle.load(paths[s]).find_intervals(km)
         assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup)
     L.rsbwt_set_close(h)
