@@ -232,6 +232,9 @@ int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path);
  * means the file describes this BWT; rsbwt_last_error() names the first difference. */
 int rsbwt_bpi2_check(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
                      uint64_t *mismatches);
+/* Host only: does the file parse as a .bpi2 (what deserialiseFMIndex reads, rlebwt.cpp:163-200)?
+ * RSBWT_OK, RSBWT_EIO or RSBWT_EFORMAT (truncated, trailing bytes, sizes the file cannot back). */
+int rsbwt_bpi2_validate_file(const char *bpi2_path);
 
 /* Shard sets: the shards one process holds on its GPU(s), searched with one call ------
  * Every query goes to every shard (src/service/server.cpp:124,578).  The shards of one device are

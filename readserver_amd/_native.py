@@ -90,6 +90,7 @@ SIGNATURES = {
     "rsbwt_sample_present_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint64, _vp, _vp]),
     "rsbwt_bpi2_write": (C.c_int, [C.c_char_p, C.c_char_p]),
     "rsbwt_bpi2_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rsbwt_bpi2_validate_file": (C.c_int, [C.c_char_p]),
     "rsbwt_synth_popbwt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_uint32, C.c_double, C.c_int, C.c_int]),
     "rsbwt_service_counts": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),

@@ -126,7 +126,10 @@ bool put_narrow(FILE *f, const std::vector<uint64_t> &v, uint64_t width) {
     return true;
 }
 bool get(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
-bool get_wide(FILE *f, std::vector<uint64_t> *v, uint64_t count, uint64_t width) {
+// `left` = bytes the file still holds: nothing is allocated for a count the file cannot back
+bool get_wide(FILE *f, std::vector<uint64_t> *v, uint64_t count, uint64_t width, uint64_t *left) {
+    if (count > *left / width) return false;
+    *left -= count * width;
     v->assign(count, 0);
     std::vector<uint8_t> buf;
     const size_t CH = 1u << 16;
@@ -161,17 +164,27 @@ int bpi2_load(const char *path, bpi2_index *ix, std::string *err) {
     FILE *f = fopen(path, "rb");
     if (!f) return err_set(err, RSBWT_EIO, std::string("cannot open ") + path + ": " + strerror(errno));
     *ix = bpi2_index();
+    // every size field is held against what the file still has to give before anything is
+    // allocated for it: a truncated or malformed file is reported, never a std::bad_alloc
+    uint64_t left = 0;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long end = ftell(f);
+        if (end > 0) left = (uint64_t)end;
+    }
+    rewind(f);
     uint64_t depth = 0;
-    bool ok = get(f, &depth, 8) && depth >= 1 && depth <= 8;
+    bool ok = left >= 8 && get(f, &depth, 8) && depth >= 1 && depth <= 8;
+    left -= ok ? 8 : 0;
     for (uint64_t k = 0; ok && k < depth; ++k) {
         bpi2_level l;
-        ok = get(f, &l.width, 8) && get(f, &l.length, 8) && get(f, &l.block, 8) && get(f, &l.bucket, 8);
+        ok = left >= 32 && get(f, &l.width, 8) && get(f, &l.length, 8) && get(f, &l.block, 8) && get(f, &l.bucket, 8);
+        if (ok) left -= 32;
         ok = ok && (l.width == 2 || l.width == 4 || l.width == 8) && l.length < (1ull << 40) && l.bucket > 0;
-        ok = ok && get_wide(f, &l.counts, l.length * 5, l.width) && get_wide(f, &l.sums, l.length, l.width);
+        ok = ok && get_wide(f, &l.counts, l.length * 5, l.width, &left) && get_wide(f, &l.sums, l.length, l.width, &left);
         if (ok) ix->levels.push_back(std::move(l));
     }
     uint64_t ns = 0;
-    ok = ok && get(f, &ns, 8) && ns < (1ull << 32);
+    ok = ok && left >= 8 && get(f, &ns, 8) && ns < (1ull << 32) && ns * 4 + 40 <= left - 8;
     if (ok) {
         ix->vsum.resize(ns);
         ok = get(f, ix->vsum.data(), ns * 4) && get(f, ix->pc, 40);

@@ -472,6 +472,19 @@ int rsbwt_bpi2_write(const char *bwt_path, const char *bpi2_path) {
     return RSBWT_OK;
 }
 
+int rsbwt_bpi2_validate_file(const char *bpi2_path) {
+    if (!bpi2_path) return fail(RSBWT_EINVAL, "null argument");
+    try {
+        bpi2_index f;
+        std::string err;
+        const int rc = bpi2_load(bpi2_path, &f, &err);
+        if (rc != RSBWT_OK) return fail(rc, "%s", err.c_str());
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed while reading %s", bpi2_path);
+    }
+    return RSBWT_OK;
+}
+
 static int bpi2_check_impl(rsbwt_t *h, const char *bpi2_path, uint64_t max_samples, uint64_t *checked,
                            uint64_t *mismatches) {
     bpi2_index f;

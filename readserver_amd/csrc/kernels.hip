@@ -529,7 +529,9 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
     for (uint64_t base = 0; base < total && e == hipSuccess; base += SL) {
         const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
         hipLaunchKernelGGL(ktab_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base, m, d_pk, d_ok);
-        e = launch_search(d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream);
+        search_extra role;
+        role.table_build = true;
+        e = launch_search(d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream, nullptr, nullptr, &role);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
         e = hipGetLastError();

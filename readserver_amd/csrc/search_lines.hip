@@ -159,7 +159,9 @@ enum { WORK_STEPS = 0, WORK_OCC = 1, WORK_LINES = 2, WORK_KTAB = 3, WORK_PHASE0 
 // LONGK: k > 32, i.e. a query spans several packed words.  A template parameter because with the
 // reload on the path -- however it is guarded at run time -- hipcc waits for vmcnt(0) at the top of
 // every pass, which also waits for the start-up loads just issued by entering lanes.
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK>
+// ROLE changes nothing but the kernel's name: 1 = the launches that fill a k-mer table at open time,
+// so that a profile's per-kernel statistics of the query launches (ROLE 0) are not mixed with them.
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK, int ROLE>
 __global__ void __launch_bounds__(64 * WG_WAVES)
 search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
                     const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
@@ -522,10 +524,10 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
     uint32_t qchunk = 1024;
     while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
     if (wpq > 1)
-        hipLaunchKernelGGL((search_lines_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+        hipLaunchKernelGGL((search_lines_kernel<CW, CO, true, 0>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
                            pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
     else
-        hipLaunchKernelGGL((search_lines_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+        hipLaunchKernelGGL((search_lines_kernel<CW, CO, false, 0>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
                            pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
 }
 
@@ -575,7 +577,12 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
     else
         hipLaunchKernelGGL(search_init_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq, init);
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if (d_work) {
+    if (extra && extra->table_build && !d_work && !counts_only && wpq == 1) {
+        uint32_t qchunk = 1024;
+        while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
+        hipLaunchKernelGGL((search_lines_kernel<false, false, false, 1>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, d_shards,
+                           nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, qchunk);
+    } else if (d_work) {
         if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
         else launch_k<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
     } else {

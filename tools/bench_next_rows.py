@@ -30,7 +30,7 @@ with tempfile.TemporaryDirectory() as td:
     rd = [l.strip() for l in open(reads) if l.strip()]
 rng = np.random.default_rng(3)
 out = {"n_symbols": int(g.getBWLen()), "n_runs": int(g.num_runs()), "reads": len(rd), "read_len": read_len,
-       "synth_s": round(t_synth, 1), "ktab_depth": g.ktab_depth(), "slot_span": g.slot_span()}
+       "synth_s": round(t_synth, 1), "ktab_depth": g.ktab_depth(), "window_span": g.window_span()}
 
 # k-mers: half cut from the reads, half random
 Q = 200000
