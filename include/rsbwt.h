@@ -276,19 +276,62 @@ int rsbwt_set_last_search_counters(rsbwt_set_t *s, uint64_t *words16);
 
 /* Service slice: the CountReads / ExactMatch-Count path of the query service --------
  * rsbwt_service_counts replaces, for a batch of serialised `Request` messages
- * (src/service/readserver.proto:3-14; message i = requests[req_off[i] .. req_off[i+1])), what the
- * recv loop does per message (src/service/service.cpp:1549-1554,1567-1570 -> count_reads
- * :279-315): two serialised `Reply` messages per request, forward strand then reverse complement,
- * each carrying the original query and an int32 count summed over the set's shards (the front-end
- * only adds partition counts: src/service/server.cpp:184-197).  Reply j of request i is
- * replies[rep_off[2i+j] .. rep_off[2i+j+1]); requests of any other type get two empty replies and
+ * (src/service/readserver.proto:3-14; message i = requests[req_off[i] .. req_off[i+1]), offsets
+ * ascending and inside requests_len), what the recv loop does per message
+ * (src/service/service.cpp:1549-1554,1567-1570 -> count_reads :279-315): two serialised `Reply`
+ * messages per request, forward strand then reverse complement, each carrying the original query and
+ * an int32 count summed over the set's shards (the front-end only adds partition counts:
+ * src/service/server.cpp:184-197; the narrowing to int32, readserver.proto:31-33, applies to the sum:
+ * the per-partition form is what rsbwt_service_create(per_partition = 1) sends).  Reply j of request i
+ * is replies[rep_off[2i+j] .. rep_off[2i+j+1]); requests of any other type get two empty replies and
  * stay with the caller.  *needed receives the bytes required; RSBWT_ERANGE if cap is too small. */
-int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, const uint64_t *req_off, size_t n,
-                         uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed);
+int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
+                         size_t n, uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed);
 /* The codec on its own (host only). */
 int rsbwt_proto_decode_request(const uint8_t *msg, size_t len, int *t, int *rt, const char **q, size_t *qlen);
 size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen,
                                       int revcomp, int32_t c);
+
+/* The service's configuration file: the libconfig subset the reference's service.cfg uses
+ * (`key = "value";`, `key = [ "a", ... ];`, comments; demo/TEMPLATE.service.cfg).  Loading fails with
+ * RSBWT_EFORMAT when a setting the reference looks up unconditionally is missing (prefix, suffix,
+ * hashfile, pull, push, push_count, rocksdb_path, rocksdb_ext, rocksdb: service.cpp:1425-1442). */
+typedef struct rsbwt_service_config rsbwt_service_config_t;
+int rsbwt_service_config_load(const char *path, rsbwt_service_config_t **out);
+void rsbwt_service_config_free(rsbwt_service_config_t *cfg);
+const char *rsbwt_service_config_get(const rsbwt_service_config_t *cfg, const char *key); /* NULL: absent */
+size_t rsbwt_service_config_array_len(const rsbwt_service_config_t *cfg, const char *key);
+const char *rsbwt_service_config_array_item(const rsbwt_service_config_t *cfg, const char *key, size_t i);
+
+/* Transports: what the loop needs of ZeroMQ -- a SUB socket connected to `pull` and subscribed to
+ * everything, PUSH sockets connected to `push` (channel 0) and `push_count` (channel 1)
+ * (service.cpp:1493-1502).  In-process: a queue pair for tests and embedding. */
+typedef struct rsbwt_transport rsbwt_transport_t;
+int rsbwt_transport_inproc(rsbwt_transport_t **out);
+int rsbwt_transport_zmq(const char *pull, const char *push, const char *push_count, rsbwt_transport_t **out); /* RSBWT_ENODEV without libzmq */
+void rsbwt_transport_free(rsbwt_transport_t *t);
+int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_t n); /* in-process only */
+int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us);
+void rsbwt_transport_close(rsbwt_transport_t *t); /* the loop ends once what was pushed is answered */
+
+/* The recv loop (service.cpp:1521-1577) with a micro-batch window: the first Request opens a window
+ * that closes after window_us or at max_batch messages; all CountReads / ExactMatch-Count requests of
+ * the window are answered by one batched search per query length over the set; replies go out in
+ * arrival order, forward strand then reverse complement, CountReads on push_count and ExactMatch on
+ * push.  per_partition = 1: two replies per request PER SHARD, each what a reference service holding
+ * that partition sends (front-end `workers` = 2 x shards); 0: two replies with the counts summed
+ * (`workers` = 2).  Requests of other types go to the handler (may be NULL). */
+typedef struct rsbwt_service rsbwt_service_t;
+typedef void (*rsbwt_service_other_fn)(void *arg, const uint8_t *request, size_t len);
+int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch,
+                         int per_partition, rsbwt_service_t **out);
+void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg);
+int rsbwt_service_run(rsbwt_service_t *s);   /* on the calling thread, until the transport closes */
+int rsbwt_service_start(rsbwt_service_t *s); /* on a thread of its own */
+int rsbwt_service_stop(rsbwt_service_t *s);
+void rsbwt_service_free(rsbwt_service_t *s);
+/* {requests, count requests, windows, replies sent, malformed messages, largest window} */
+void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6);
 
 /* Test hook (host only, answers no query): lays `runs` out as window lines with the code the GPU
  * builder runs and holds the layout's scalar readers to naive ranks at every position.  stats6 =

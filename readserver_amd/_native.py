@@ -93,7 +93,25 @@ SIGNATURES = {
     "rsbwt_bpi2_validate_file": (C.c_int, [C.c_char_p]),
     "rsbwt_synth_popbwt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double,
                                      C.c_uint32, C.c_double, C.c_int, C.c_int]),
-    "rsbwt_service_counts": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),
+    "rsbwt_service_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),
+    "rsbwt_service_config_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "rsbwt_service_config_free": (None, [_vp]),
+    "rsbwt_service_config_get": (C.c_char_p, [_vp, C.c_char_p]),
+    "rsbwt_service_config_array_len": (C.c_size_t, [_vp, C.c_char_p]),
+    "rsbwt_service_config_array_item": (C.c_char_p, [_vp, C.c_char_p, C.c_size_t]),
+    "rsbwt_transport_inproc": (C.c_int, [C.POINTER(_vp)]),
+    "rsbwt_transport_zmq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "rsbwt_transport_free": (None, [_vp]),
+    "rsbwt_transport_push_request": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "rsbwt_transport_pop_reply": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int64]),
+    "rsbwt_transport_close": (None, [_vp]),
+    "rsbwt_service_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "rsbwt_service_set_other_handler": (None, [_vp, _vp, _vp]),
+    "rsbwt_service_run": (C.c_int, [_vp]),
+    "rsbwt_service_start": (C.c_int, [_vp]),
+    "rsbwt_service_stop": (C.c_int, [_vp]),
+    "rsbwt_service_free": (None, [_vp]),
+    "rsbwt_service_stats": (None, [_vp, _u64p]),
     "rsbwt_proto_decode_request": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                              C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
     "rsbwt_proto_encode_count_reply": (C.c_size_t, [_vp, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int32]),

@@ -1,0 +1,44 @@
+// service.h -- the query service's CountReads / ExactMatch-Count slice, host side:
+// what service_slice.cpp (codec + batched count_reads) and service_loop.cpp (the recv loop with its
+// micro-batch window, the service.cfg reader, the transport interface) share.
+#ifndef RSBWT_SERVICE_H
+#define RSBWT_SERVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rsbwt.h"
+
+namespace rsb {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+struct service_request {
+    int t = 0, rt = 0;  // Request.RequestType / ReturnType (readserver.proto:4-5)
+    std::string q;
+};
+
+bool service_decode(const uint8_t *msg, size_t len, service_request *out);
+// replies[i] = the Reply messages of request i in sending order (forward, reverse complement; per
+// shard first when per_partition); handled[i] = 0: not a count request, left to the caller
+int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition,
+                        std::vector<std::vector<std::vector<uint8_t>>> *replies, std::vector<char> *handled);
+
+// What the loop needs of ZeroMQ: the SUB socket it receives Requests on (service.cpp:1495-1497) and
+// the two PUSH sockets it answers on (push for ExactMatch, push_count for CountReads: :1499-1502,1568).
+class transport {
+  public:
+    virtual ~transport() {}
+    // next Request message; waits at most timeout_us (< 0: until one arrives or the transport
+    // closes).  false = nothing arrived in time, or closed.
+    virtual bool recv(std::vector<uint8_t> *msg, int64_t timeout_us) = 0;
+    virtual bool closed() = 0;
+    enum channel { PUSH = 0, PUSH_COUNT = 1 };
+    virtual void send(channel c, const uint8_t *data, size_t n) = 0;
+};
+
+}  // namespace rsb
+#endif

@@ -12,10 +12,12 @@
 #include <string.h>
 
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/rsbwt.h"
+#include "service.h"
 
 namespace {
 
@@ -117,57 +119,127 @@ size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type
     return o.size();
 }
 
-int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, const uint64_t *req_off, size_t n,
-                         uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed) {
-    if (!set || (!requests && n) || !req_off || !rep_off) return RSBWT_EINVAL;
-    std::vector<request_view> rq(n);
-    std::vector<char> handled(n, 0);
-    // group the count requests by query length: one batched call per length and strand
-    std::map<size_t, std::vector<size_t>> by_len;
+}  // extern "C"
+
+namespace rsb {
+
+// count_reads (src/service/service.cpp:279-315) for a batch of decoded requests over a shard set.
+// Every request of type CountReads, or ExactMatch with return type Count, gets its replies; the
+// others are left to the caller (handled[i] = 0).  per_partition: one forward and one reverse-
+// complement Reply PER SHARD, each carrying that shard's count narrowed to int32 exactly as a
+// reference service process holding that partition would send it (readserver.proto:31-33,
+// service.cpp:304) -- the front-end adds them up (server.cpp:184-197).  Otherwise two replies per
+// request with the counts summed over the shards first (set the front-end's `workers` to 2): the
+// narrowing then applies to the sum, which differs from the above only beyond 2^31 matches.
+int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition,
+                        std::vector<std::vector<std::vector<uint8_t>>> *replies, std::vector<char> *handled) {
+    const size_t n = rq.size();
+    const size_t S = rsbwt_set_size(set);
+    handled->assign(n, 0);
+    replies->assign(n, {});
+    std::map<size_t, std::vector<size_t>> by_len;  // one batched search per query length
     for (size_t i = 0; i < n; ++i) {
-        const uint8_t *m = requests + req_off[i];
-        if (!decode_request(m, (size_t)(req_off[i + 1] - req_off[i]), rq[i])) continue;
-        const bool count_reads = rq[i].t == 1;                      // Request::CountReads
-        const bool exact_count = rq[i].t == 2 && rq[i].rt == 1;     // ExactMatch + Count
-        if (!count_reads && !exact_count) continue;                  // other paths stay with the caller
-        handled[i] = 1;
-        by_len[rq[i].qlen].push_back(i);
+        const bool count_reads = rq[i].t == 1;                   // Request::CountReads
+        const bool exact_count = rq[i].t == 2 && rq[i].rt == 1;  // ExactMatch + Count
+        if (!count_reads && !exact_count) continue;               // other paths stay with the caller
+        (*handled)[i] = 1;
+        by_len[rq[i].q.size()].push_back(i);
     }
-    std::vector<uint64_t> fwd(n, 0), rev(n, 0);
+    // per request: [strand][shard] counts (one row when summed)
+    const size_t rows = per_partition ? S : 1;
+    std::vector<std::vector<uint64_t>> cnt(n);
     for (auto &g : by_len) {
         const size_t k = g.first, m = g.second.size();
+        for (size_t j = 0; j < m; ++j) cnt[g.second[j]].assign(2 * rows, 0);
         if (k == 0) continue;  // empty query: count 0 (findInterval on "" is undefined in the reference)
-        std::string flat_f(m * k, 'N'), flat_r(m * k, 'N');
+        // both strands of the group in one batch: forward k-mers, then their reverse complements
+        std::string flat(2 * m * k, 'N');
         for (size_t j = 0; j < m; ++j) {
-            const request_view &r = rq[g.second[j]];
-            memcpy(&flat_f[j * k], r.q, k);
-            const std::string rc = rev_comp(r.q, k);
-            memcpy(&flat_r[j * k], rc.data(), k);
+            const std::string &q = rq[g.second[j]].q;
+            memcpy(&flat[j * k], q.data(), k);
+            const std::string rc = rev_comp(q.data(), k);
+            memcpy(&flat[(m + j) * k], rc.data(), k);
         }
-        std::vector<uint64_t> cf(m), cr(m);
-        int rc = rsbwt_set_count(set, flat_f.data(), m, (uint32_t)k, k, cf.data());
-        if (rc == RSBWT_OK) rc = rsbwt_set_count(set, flat_r.data(), m, (uint32_t)k, k, cr.data());
-        if (rc != RSBWT_OK) return rc;
-        for (size_t j = 0; j < m; ++j) { fwd[g.second[j]] = cf[j]; rev[g.second[j]] = cr[j]; }
+        int rc;
+        if (per_partition) {
+            std::vector<uint64_t> lo(S * 2 * m), up(S * 2 * m);
+            rc = rsbwt_set_find_intervals(set, flat.data(), 2 * m, (uint32_t)k, k, lo.data(), up.data());
+            if (rc != RSBWT_OK) return rc;
+            for (size_t s = 0; s < S; ++s)
+                for (size_t j = 0; j < 2 * m; ++j) {
+                    const uint64_t l = lo[s * 2 * m + j], u = up[s * 2 * m + j];
+                    const uint64_t c = u >= l ? u - l + 1 : 0;  // service.cpp:304
+                    cnt[g.second[j % m]][(j / m) * rows + s] = c;
+                }
+        } else {
+            std::vector<uint64_t> c(2 * m);
+            rc = rsbwt_set_count(set, flat.data(), 2 * m, (uint32_t)k, k, c.data());
+            if (rc != RSBWT_OK) return rc;
+            for (size_t j = 0; j < 2 * m; ++j) cnt[g.second[j % m]][j / m] = c[j];
+        }
     }
-    std::vector<uint8_t> o;
-    size_t total = 0;
-    rep_off[0] = 0;
     for (size_t i = 0; i < n; ++i) {
-        for (int strand = 0; strand < 2; ++strand) {
-            if (handled[i]) {
-                o.clear();
+        if (!(*handled)[i]) continue;
+        for (size_t r = 0; r < rows; ++r)
+            for (int strand = 0; strand < 2; ++strand) {
+                std::vector<uint8_t> o;
                 // resultc->set_c(...) narrows the 64-bit count to int32 (readserver.proto:31-33)
-                const int32_t c = (int32_t)(uint32_t)(strand ? rev[i] : fwd[i]);
-                encode_count_reply(o, rq[i].t, rq[i].q, rq[i].qlen, strand == 1, c);
-                if (replies && total + o.size() <= cap) memcpy(replies + total, o.data(), o.size());
-                total += o.size();
+                const int32_t c = (int32_t)(uint32_t)cnt[i][strand * rows + r];
+                encode_count_reply(o, rq[i].t, rq[i].q.data(), rq[i].q.size(), strand == 1, c);
+                (*replies)[i].push_back(std::move(o));
             }
-            rep_off[2 * i + strand + 1] = total;
-        }
     }
-    if (needed) *needed = total;
-    return (replies && total <= cap) || total == 0 ? RSBWT_OK : RSBWT_ERANGE;
+    return RSBWT_OK;
+}
+
+bool service_decode(const uint8_t *msg, size_t len, service_request *out) {
+    request_view r;
+    if (!decode_request(msg, len, r)) return false;
+    out->t = r.t;
+    out->rt = r.rt;
+    out->q.assign(r.q ? r.q : "", r.qlen);
+    return true;
+}
+
+}  // namespace rsb
+
+extern "C" {
+
+int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
+                         size_t n, uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed) {
+    if (!set || (!requests && n) || !req_off || !rep_off) return rsb::fail(RSBWT_EINVAL, "null argument");
+    for (size_t i = 0; i < n; ++i)
+        if (req_off[i] > req_off[i + 1] || req_off[i + 1] > requests_len)
+            return rsb::fail(RSBWT_EINVAL, "request %zu: offsets %llu..%llu are not an ascending range inside the %zu-byte buffer",
+                             i, (unsigned long long)req_off[i], (unsigned long long)req_off[i + 1], requests_len);
+    try {
+        std::vector<rsb::service_request> rq(n);
+        std::vector<char> parsed(n, 0);
+        for (size_t i = 0; i < n; ++i)
+            parsed[i] = rsb::service_decode(requests + req_off[i], (size_t)(req_off[i + 1] - req_off[i]), &rq[i]) ? 1 : 0;
+        for (size_t i = 0; i < n; ++i)
+            if (!parsed[i]) rq[i].t = 0;  // not a Request: no reply
+        std::vector<std::vector<std::vector<uint8_t>>> rep;
+        std::vector<char> handled;
+        const int rc = rsb::service_count_batch(set, rq, false, &rep, &handled);
+        if (rc != RSBWT_OK) return rc;
+        size_t total = 0;
+        rep_off[0] = 0;
+        for (size_t i = 0; i < n; ++i)
+            for (int strand = 0; strand < 2; ++strand) {
+                if (handled[i]) {
+                    const std::vector<uint8_t> &o = rep[i][strand];
+                    if (replies && total + o.size() <= cap) memcpy(replies + total, o.data(), o.size());
+                    total += o.size();
+                }
+                rep_off[2 * i + strand + 1] = total;
+            }
+        if (needed) *needed = total;
+        if ((replies && total <= cap) || total == 0) return RSBWT_OK;
+        return rsb::fail(RSBWT_ERANGE, "%zu reply bytes, room for %zu", total, cap);
+    } catch (const std::bad_alloc &) {
+        return rsb::fail(RSBWT_ENOMEM, "host allocation failed");
+    }
 }
 
 }  // extern "C"

@@ -93,12 +93,20 @@ def test_gpu_service_counts_batch(rsb, oracle, pb, tmp_path):
     ss = rsb.ShardSet(shards)
     rep_off = np.zeros(2 * len(reqs) + 1, np.uint64)
     need = C.c_size_t()
-    rc = L.rsbwt_service_counts(ss._s, blob.ctypes.data, off.ctypes.data, len(reqs), None, 0, rep_off.ctypes.data,
-                                C.byref(need))
+    rc = L.rsbwt_service_counts(ss._s, blob.ctypes.data, blob.size, off.ctypes.data, len(reqs), None, 0,
+                                rep_off.ctypes.data, C.byref(need))
     assert rc == -7 and need.value > 0
     out = np.zeros(need.value, np.uint8)
-    assert L.rsbwt_service_counts(ss._s, blob.ctypes.data, off.ctypes.data, len(reqs), out.ctypes.data, out.size,
-                                  rep_off.ctypes.data, C.byref(need)) == 0
+    assert L.rsbwt_service_counts(ss._s, blob.ctypes.data, blob.size, off.ctypes.data, len(reqs), out.ctypes.data,
+                                  out.size, rep_off.ctypes.data, C.byref(need)) == 0
+    # offsets that are not an ascending range inside the buffer are refused, with a message of their own
+    bad_off = off.copy()
+    bad_off[3], bad_off[4] = bad_off[4], bad_off[3]
+    assert L.rsbwt_service_counts(ss._s, blob.ctypes.data, blob.size, bad_off.ctypes.data, len(reqs), out.ctypes.data,
+                                  out.size, rep_off.ctypes.data, C.byref(need)) == -1
+    assert b"ascending" in L.rsbwt_last_error()
+    assert L.rsbwt_service_counts(ss._s, blob.ctypes.data, blob.size - 1, off.ctypes.data, len(reqs), out.ctypes.data,
+                                  out.size, rep_off.ctypes.data, C.byref(need)) == -1
     for i, r in enumerate(reqs):
         f = out[int(rep_off[2 * i]):int(rep_off[2 * i + 1])].tobytes()
         v = out[int(rep_off[2 * i + 1]):int(rep_off[2 * i + 2])].tobytes()
