@@ -132,3 +132,203 @@ def test_gpu_service_counts_batch(rsb, oracle, pb, tmp_path):
     ss.close()
     for g in shards:
         g.close()
+
+
+# ---- service.cfg reader (CPU) -----------------------------------------------------------------------
+
+CFG = '''// prefix for bwt file (path before .bwt extension)
+prefix = "/data/SERVER/bwt/final"
+# a hash comment
+hashfile = "/data/SERVER/files/list_of_sample_hash";
+pull = "tcp://10.0.0.1:5557";
+push = "tcp://10.0.0.1:5558";
+push_count = "tcp://10.0.0.1:5559";
+/* the common suffix
+   (read from backward) */
+suffix = "";
+size_of_sample = "1";
+has_other_meta_data = "0";
+max_read_length = "100"; min_read_length = "100";
+rocksdb_path = "/data/SERVER/" "rocksdbs/"
+rocksdb_ext = ".rocksdb";
+rocksdb = [
+    "CGA",
+    "CGC", "AAA"
+];
+shards = [ "/data/s0", "/data/s1" ];
+batch_window_us = "350";
+'''
+
+
+def test_service_config_reader(rsb, tmp_path):
+    L = rsb.lib()
+    p = tmp_path / "service.cfg"
+    p.write_text(CFG)
+    h = C.c_void_p()
+    assert L.rsbwt_service_config_load(str(p).encode(), C.byref(h)) == 0
+    get = lambda k: L.rsbwt_service_config_get(h, k.encode())
+    assert get("prefix") == b"/data/SERVER/bwt/final" and get("suffix") == b"" and get("pull") == b"tcp://10.0.0.1:5557"
+    assert get("push_count") == b"tcp://10.0.0.1:5559" and get("max_read_length") == b"100"
+    assert get("rocksdb_path") == b"/data/SERVER/rocksdbs/"  # adjacent strings concatenate, as in libconfig
+    assert get("batch_window_us") == b"350" and get("nope") is None
+    assert L.rsbwt_service_config_array_len(h, b"rocksdb") == 3
+    assert [L.rsbwt_service_config_array_item(h, b"rocksdb", i) for i in range(3)] == [b"CGA", b"CGC", b"AAA"]
+    assert L.rsbwt_service_config_array_item(h, b"shards", 1) == b"/data/s1"
+    assert L.rsbwt_service_config_array_item(h, b"rocksdb", 3) is None
+    L.rsbwt_service_config_free(h)
+    # a setting the reference looks up unconditionally is missing (SettingNotFoundException, service.cpp:1438-1442)
+    q = tmp_path / "short.cfg"
+    q.write_text(CFG.replace('push_count = "tcp://10.0.0.1:5559";', ""))
+    assert L.rsbwt_service_config_load(str(q).encode(), C.byref(h)) == -3 and b"push_count" in L.rsbwt_last_error()
+    q.write_text('prefix = "a"\nsuffix = nope;')
+    assert L.rsbwt_service_config_load(str(q).encode(), C.byref(h)) == -3 and b"line 2" in L.rsbwt_last_error()
+    assert L.rsbwt_service_config_load(str(tmp_path / "missing.cfg").encode(), C.byref(h)) == -2
+    # the reference's own template parses (build container only)
+    import os
+    tpl = "/root/reference/demo/TEMPLATE.service.cfg"
+    if os.path.exists(tpl):
+        assert L.rsbwt_service_config_load(tpl.encode(), C.byref(h)) == 0
+        assert L.rsbwt_service_config_array_len(h, b"rocksdb") == 64 and L.rsbwt_service_config_get(h, b"suffix") == b""
+        L.rsbwt_service_config_free(h)
+
+
+def test_zmq_transport_is_reported_absent_not_faked(rsb):
+    L = rsb.lib()
+    h = C.c_void_p()
+    rc = L.rsbwt_transport_zmq(b"tcp://127.0.0.1:1", b"tcp://127.0.0.1:2", b"tcp://127.0.0.1:3", C.byref(h))
+    assert rc in (0, -5)
+    if rc == -5:
+        assert b"libzmq" in L.rsbwt_last_error()
+    else:
+        L.rsbwt_transport_free(h)
+
+
+# ---- the recv loop with its micro-batch window (GPU) ------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window_us,max_batch", [(5000, 4096), (0, 1), (300, 7)])
+def test_gpu_service_loop_golden_replies(rsb, fixture_bwt, golden_dir, window_us, max_batch):
+    """A mixed stream of serialised Requests pushed through the loop (in-process transport) with one
+    partition = the golden fixture: the replies must be, byte for byte and in order, what a reference
+    service process sends (tests/golden/service_v1.json: bytes from the protobuf runtime, counts from
+    the compiled reference); CountReads on push_count, ExactMatch-Count on push; other request types
+    go to the handler; a malformed message is dropped and counted."""
+    import json
+    import os
+    import threading
+    L = rsb.lib()
+    gold = json.load(open(os.path.join(golden_dir, "service_v1.json")))["items"]
+    path, _ = fixture_bwt
+    g = rsb.GpuBWT(path)
+    ss = rsb.ShardSet([g])
+    tr, svc = C.c_void_p(), C.c_void_p()
+    assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
+    assert L.rsbwt_service_create(ss._s, tr, window_us, max_batch, 1, C.byref(svc)) == 0
+    others = []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+    cb = CB(lambda arg, p, n: others.append(bytes(p[:n])))
+    L.rsbwt_service_set_other_handler(svc, C.cast(cb, C.c_void_p), None)
+    assert L.rsbwt_service_start(svc) == 0
+    wires = [bytes.fromhex(x["request"]) for x in gold]
+
+    def feed():
+        for i, w in enumerate(wires):
+            buf = (C.c_uint8 * max(len(w), 1)).from_buffer_copy(w or b"\\0")
+            assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
+            if i == 100:
+                junk = (C.c_uint8 * 3)(0xFF, 0xFF, 0x01)
+                L.rsbwt_transport_push_request(tr, junk, 3)
+    th = threading.Thread(target=feed)
+    th.start()
+    want = {0: [], 1: []}
+    for x in gold:
+        if x["replies"]:
+            want[x["channel"]] += [bytes.fromhex(r) for r in x["replies"]]
+    got = {0: [], 1: []}
+    buf = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    for ch in (1, 0):
+        for _ in want[ch]:
+            assert L.rsbwt_transport_pop_reply(tr, ch, buf, 4096, C.byref(n), 20_000_000) == 0
+            got[ch].append(bytes(buf[:n.value]))
+    th.join()
+    L.rsbwt_transport_close(tr)
+    assert L.rsbwt_service_stop(svc) == 0
+    assert got[1] == want[1] and got[0] == want[0]
+    assert L.rsbwt_transport_pop_reply(tr, 0, buf, 4096, C.byref(n), 1000) == -2  # exactly two per request, no more
+    st = (C.c_uint64 * 6)()
+    L.rsbwt_service_stats(svc, st)
+    assert st[0] == len(gold) + 1 and st[1] == sum(1 for x in gold if x["replies"]) and st[4] == 1
+    assert st[3] == len(want[0]) + len(want[1]) and 1 <= st[5] <= max_batch
+    if max_batch == 1:
+        assert st[2] == st[0]
+    assert sorted(others) == sorted(bytes.fromhex(x["request"]) for x in gold if not x["replies"])
+    L.rsbwt_service_free(svc)
+    L.rsbwt_transport_free(tr)
+    ss.close()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_service_loop_many_partitions(rsb, oracle, pb, tmp_path):
+    """One process impersonating P partitions: per_partition = 1 sends 2 x P replies per request, reply
+    (s, strand) carrying shard s's own count; per_partition = 0 sends 2 with the counts summed."""
+    Request, Reply = pb
+    L = rsb.lib()
+    kw = dict(seed=29, genome_len=20000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=3.0)
+    shards, oixs = [], []
+    for s in range(4):
+        p = str(tmp_path / f"s{s}.bwt")
+        rsb.synth_popbwt(p, None, shard=s, num_shards=4, **kw)
+        shards.append(rsb.GpuBWT(p))
+        oixs.append(oracle.load(p))
+    rd = str(tmp_path / "w.reads")
+    rsb.synth_popbwt(str(tmp_path / "w.bwt"), rd, **kw)
+    reads = open(rd).read().split()
+    rng = np.random.default_rng(5)
+    reqs = []
+    for i in range(300):
+        r = Request()
+        r.t, r.rt = (1, 1) if i % 2 else (2, 1)
+        rr = reads[rng.integers(len(reads))]
+        k = int(rng.choice([25, 31, 40]))
+        st = int(rng.integers(0, len(rr) - k + 1))
+        r.q = rr[st:st + k]
+        reqs.append(r)
+    ss = rsb.ShardSet(shards)
+
+    def count(ox, w):
+        lo, up = ox.find_interval(w)
+        return up - lo + 1 if up >= lo else 0
+    for per_partition in (1, 0):
+        tr, svc = C.c_void_p(), C.c_void_p()
+        assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
+        assert L.rsbwt_service_create(ss._s, tr, 2000, 128, per_partition, C.byref(svc)) == 0
+        for r in reqs:
+            w = r.SerializeToString()
+            buf = (C.c_uint8 * len(w)).from_buffer_copy(w)
+            assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
+        L.rsbwt_transport_close(tr)
+        assert L.rsbwt_service_run(svc) == 0  # returns once everything pushed is answered
+        buf = (C.c_uint8 * 4096)()
+        n = C.c_size_t()
+        for r in reqs:
+            ch = 1 if r.t == 1 else 0
+            rows = len(shards) if per_partition else 1
+            for s in range(rows):
+                for strand in (0, 1):
+                    assert L.rsbwt_transport_pop_reply(tr, ch, buf, 4096, C.byref(n), 1_000_000) == 0
+                    m = Reply()
+                    m.ParseFromString(bytes(buf[:n.value]))
+                    assert (m.rt, m.t, m.q) == (r.t, 1, r.q)
+                    w = _rc(r.q) if strand else r.q
+                    exp = count(oixs[s], w) if per_partition else sum(count(ox, w) for ox in oixs)
+                    c = m.c.revcomp_matches.c if strand else m.c.forward_matches.c
+                    assert c == exp and m.c.HasField("revcomp_matches" if strand else "forward_matches")
+        assert L.rsbwt_transport_pop_reply(tr, 0, buf, 4096, C.byref(n), 1000) == -2
+        assert L.rsbwt_transport_pop_reply(tr, 1, buf, 4096, C.byref(n), 1000) == -2
+        L.rsbwt_service_free(svc)
+        L.rsbwt_transport_free(tr)
+    ss.close()
+    for g in shards:
+        g.close()
