@@ -176,6 +176,14 @@ int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_val
                              uint32_t k, void *d_lower, void *d_upper, void *stream);
 int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                     void *d_counts, void *stream);
+/* 1-mismatch search of m packed k-mers: d_lower/d_upper [m][3k+1] (rsbwt_find_intervals_1mm's layout);
+ * d_scratch: rsbwt_1mm_scratch_bytes(h, m, k) bytes. */
+size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);
+int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+                                 void *d_lower, void *d_upper, void *d_scratch, void *stream);
+/* Read extraction of n rows (d_rows: u64): d_out [n][stride] bytes, d_len and d_prefix_len [n] u32. */
+int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
+                      void *d_prefix_len, void *stream);
 
 /* Measurement hooks (bench.py): wall time of the last search kernel launched through this
  * handle, from HIP events recorded on the launch stream; synchronises on the stop event. */

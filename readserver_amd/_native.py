@@ -78,6 +78,9 @@ SIGNATURES = {
     "rsbwt_pack_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "rsbwt_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),
+    "rsbwt_find_intervals_1mm_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "rsbwt_extract_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_last_search_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rsbwt_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_counting": (C.c_int, [_vp, C.c_int]),

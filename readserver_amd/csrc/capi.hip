@@ -812,6 +812,31 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
     return RSBWT_OK;
 }
 
+// Device-resident form: m packed k-mers -> d_lower/d_upper [m][3k+1]; d_scratch holds the variants and
+// the trace (rsbwt_1mm_scratch_bytes).  Nothing is synchronised.
+size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
+    if (!h || k == 0) return 0;
+    const size_t V = 3 * (size_t)k + 1, mv = m * V;
+    return mv * words_per_kmer(k) * 8 + ((mv + 15) & ~(size_t)15) + ((variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15);
+}
+
+int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+                                 void *d_lower, void *d_upper, void *d_scratch, void *stream) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (m == 0) return RSBWT_OK;
+    if (!d_packed || !d_valid || !d_lower || !d_upper || !d_scratch) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const size_t V = 3 * (size_t)k + 1, mv = m * V;
+    uint8_t *d_vpk = (uint8_t *)d_scratch, *d_vok = d_vpk + mv * words_per_kmer(k) * 8;
+    uint8_t *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
+    hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+    return search_variants(h, d_packed, d_valid, m, k, d_vpk, d_vok, d_lower, d_upper, d_scr, (hipStream_t)stream);
+}
+
 int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
                    size_t cap, size_t *nhits) {
     if (!h || !nhits) return fail(RSBWT_EINVAL, "null argument");
@@ -926,6 +951,23 @@ int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_
                               HIP_OK(hipStreamSynchronize(st));
                               return RSBWT_OK;
                           });
+}
+
+// Device-resident form: d_rows [n] u64 -> d_out [n][stride] bytes, d_len / d_prefix_len [n] u32 (both
+// required), on `stream`; nothing is synchronised (the select sample table is built on first use).
+int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
+                      void *d_prefix_len, void *stream) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (n == 0) return RSBWT_OK;
+    if (!d_rows || !d_out || !d_len || !d_prefix_len) return fail(RSBWT_EINVAL, "null argument");
+    if (stride == 0) return fail(RSBWT_EINVAL, "stride must be positive");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if ((rc = ensure_select_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    hipError_t e = launch_extract(h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
+    return RSBWT_OK;
 }
 
 // ---- query / query_exactmatch (src/bwt/query.cpp:87-120) ------------------------------------------

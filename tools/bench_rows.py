@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""SURVEY section-8 "next" rows on the bench's 20 GB shard, device-resident (inputs and outputs in
+HBM, as bench.py measures the exact search), with a roofline each:
+  f3  1-mismatch search    rsbwt_find_intervals_1mm_dev   (3k+1 variants per 31-mer, traced + resumed)
+  f2  read extraction      rsbwt_extract_dev              (extractPrefix + extractPostfix per row)
+Algorithmic bytes: 128 B per distinct window line read by an Occ lookup (+ 40 B per search) for f3,
+from the search kernel's own counters; 128 B per LF / select step for f2 (one line holds what a step
+needs), counted from the lengths extracted.  Prints one JSON line.
+usage: tools/bench_rows.py [run_bytes=2e10] [kmers=40000] [rows=2000000]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import readserver_amd as rsb  # noqa: E402
+
+R = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000000
+M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 40000
+NR = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2000000
+k, PEAK = 31, 8000.0
+L = rsb.lib()
+dev = torch.device("cuda", 0)
+p = lambda t: C.c_void_p(t.data_ptr())
+
+
+def ok(rc):
+    if rc != 0:
+        raise RuntimeError(L.rsbwt_last_error().decode())
+
+
+d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
+ok(L.rsbwt_synth_runs_dev(p(d_runs), R, 1000003, 0, None))
+torch.cuda.synchronize()
+g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
+del d_runs
+torch.cuda.empty_cache()
+n = g.getBWLen()
+out = {"run_bytes": R, "symbols": int(n), "ktab_depth": g.ktab_depth(), "window_span": g.window_span()}
+
+# ---- f3: 1-mismatch, half of the k-mers drawn from the index ---------------------------------------
+gen = torch.Generator(device=dev)
+gen.manual_seed(5)
+lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+d_km = lut[torch.randint(0, 4, (M, k), generator=gen, device=dev).long()].contiguous()
+half = torch.empty((M // 2, k), dtype=torch.uint8, device=dev)
+ok(L.rsbwt_sample_present_kmers_dev(g.handle, M // 2, k, k, 8, p(half), None))
+torch.cuda.synchronize()
+d_km[::2][:M // 2] = half
+V = 3 * k + 1
+d_pk = torch.empty(M, dtype=torch.int64, device=dev)
+d_ok = torch.empty(M, dtype=torch.uint8, device=dev)
+d_lo = torch.empty((M, V), dtype=torch.int64, device=dev)
+d_up = torch.empty((M, V), dtype=torch.int64, device=dev)
+d_scr = torch.empty(L.rsbwt_1mm_scratch_bytes(g.handle, M, k), dtype=torch.uint8, device=dev)
+ok(L.rsbwt_pack_kmers_dev(p(d_km), M, k, k, p(d_pk), p(d_ok), 0, None))
+run1 = lambda: ok(L.rsbwt_find_intervals_1mm_dev(g.handle, p(d_pk), p(d_ok), M, k, p(d_lo), p(d_up), p(d_scr), None))
+ok(L.rsbwt_set_counting(g.handle, 1))
+run1()
+torch.cuda.synchronize()
+w = (C.c_uint64 * 16)()
+ok(L.rsbwt_last_search_counters(g.handle, w))  # the resumed search of the m x (3k+1) variants
+ok(L.rsbwt_set_counting(g.handle, 0))
+for _ in range(2):
+    run1()
+torch.cuda.synchronize()
+reps = 10
+t0 = time.perf_counter()
+for _ in range(reps):
+    run1()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+buf = (C.c_float * 64)()
+cnt = C.c_size_t()
+ok(L.rsbwt_search_history_ms(g.handle, buf, 2 * reps, C.byref(cnt)))
+kms = sum(buf[:cnt.value]) / reps  # traced + resumed search kernels of one call
+alg = w[2] * 128 + M * V * 40
+hits = int((d_up >= d_lo).sum().item())
+out["one_mismatch"] = {
+    "kmers": M, "variants_per_kmer": V, "kmers_per_s": M / dt, "variant_searches_per_s": M * V / dt,
+    "ms_per_call": dt * 1e3, "search_kernels_ms_per_call": kms, "hits": hits,
+    "lf_steps_per_variant": w[0] / (M * V), "line_reads": w[2], "continuation_line_reads": w[11],
+    "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
+                 "frac": alg / (kms * 1e-3) / 1e9 / PEAK, "kernel": "search_lines_kernel (variants resumed from the trace)",
+                 "algorithmic_bytes": alg},
+}
+del d_lo, d_up, d_scr
+
+# ---- f2: extraction of random rows (the run stream is not a valid BWT: walks end at the '$' they meet) -
+stride = 512
+rows = torch.randint(0, n, (NR,), generator=gen, device=dev, dtype=torch.int64)
+d_out = torch.empty((NR, stride), dtype=torch.uint8, device=dev)
+d_len = torch.empty(NR, dtype=torch.int32, device=dev)
+d_pl = torch.empty(NR, dtype=torch.int32, device=dev)
+run2 = lambda: ok(L.rsbwt_extract_dev(g.handle, p(rows), NR, p(d_out), stride, p(d_len), p(d_pl), None))
+run2()
+torch.cuda.synchronize()
+ln = d_len.cpu().numpy().view(np.uint32)
+fits = ln != 0xFFFFFFFF
+steps = int(ln[fits].astype(np.int64).sum()) + 2 * int(fits.sum())  # one line per symbol + the two '$' steps
+reps = 3
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(reps):
+    run2()
+ev1.record()
+torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / reps
+out["extract"] = {
+    "rows": NR, "rows_fitting_stride": int(fits.sum()), "mean_read_length": float(ln[fits].mean()),
+    "reads_per_s": NR / (ms * 1e-3), "bases_per_s": float(ln[fits].sum()) / (ms * 1e-3), "ms_per_call": ms,
+    "roofline": {"bound": "hbm", "achieved": steps * 128 / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
+                 "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_kernel + extract_postfix_kernel",
+                 "algorithmic_bytes": steps * 128, "steps": steps},
+}
+g.close()
+print(json.dumps(out))
