@@ -257,7 +257,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     int rc = upload_view(h);
     if (rc) { rsbwt_close(h); return rc; }
     // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries take no more
-    // HBM than the index itself and no more than a quarter of what is still free (HBM is there
+    // HBM than 5/4 of the index itself and no more than a quarter of what is still free (HBM is there
     // to be used: every level replaces one LF step, two Occ lookups, of each query by the same
     // single 8-byte read), and whose T-mers still have ~1 expected occurrence (4^T <= n).
     // 8 B * 4^16 = 34 GB is the ceiling.  (rsbwt_set_open sizes the tables of its shards together.)
@@ -266,7 +266,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     else if (T == 0u) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        const uint64_t budget = std::min<uint64_t>(h->hbm_bytes, free_b / 4);
+        const uint64_t budget = std::min<uint64_t>(h->hbm_bytes + h->hbm_bytes / 4, free_b / 4);
         T = 1;
         while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= h->view.n) ++T;
         if (T < 2u) T = 0;

@@ -218,9 +218,14 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
         // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
         // ds_bpermute reads (selects out of scalar registers cost 15 VALU instructions a pass; a
         // dynamically indexed load would be a dependent global load in every pass)
+        // (read with scalar loads and selected per lane: a vector load here would make hipcc wait for
+        // vmcnt(0) at the table's first use in EVERY pass -- behind the start-up loads just issued for
+        // entering queries, whose latency must overlap the line fetches instead)
         uint32_t ctab_lo, ctab_hi;
         {
-            const uint64_t cv = sv->C[1u + (lane & 3u)];
+            const uint64_t c1 = sv->C[1], c2 = sv->C[2], c3 = sv->C[3], c4 = sv->C[4];
+            const uint32_t l3 = lane & 3u;
+            const uint64_t cv = l3 == 0u ? c1 : l3 == 1u ? c2 : l3 == 2u ? c3 : c4;
             ctab_lo = (uint32_t)cv;
             ctab_hi = (uint32_t)(cv >> 32);
         }
