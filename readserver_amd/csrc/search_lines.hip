@@ -31,6 +31,9 @@ namespace rsb {
 // (20 waves) would fit a CU's 160 KB; 4 are launched.
 constexpr int SLOT_U4 = 8;
 constexpr int WG_WAVES = 4;  // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
+#ifndef RSB_MIN_WGS_PER_CU  // tuning knob (tools/build_variant.sh): register budget = 512 / this many waves per SIMD
+#define RSB_MIN_WGS_PER_CU 4
+#endif
 
 // The stage is written by LDS-DMA and parsed as dwords / 8- / 16-byte pieces: the read types may
 // alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
@@ -162,7 +165,7 @@ enum { WORK_STEPS = 0, WORK_OCC = 1, WORK_LINES = 2, WORK_KTAB = 3, WORK_PHASE0 
 // ROLE changes nothing but the kernel's name: 1 = the launches that fill a k-mer table at open time,
 // so that a profile's per-kernel statistics of the query launches (ROLE 0) are not mixed with them.
 template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK, int ROLE>
-__global__ void __launch_bounds__(64 * WG_WAVES)
+__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
 search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
                     const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
                     size_t Q, uint32_t k, uint32_t wpq,
@@ -405,7 +408,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                         const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(qd));
                         const uint2 x1 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 2u));
                         const uint2 x2 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 4u));
-                        const uint32_t bb = __umul24(b, 0x010101u) | (b << 24);  // b in every byte
+                        const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte (v_perm_b32: byte 0 four times)
                         uint32_t m = dword_matched(x0.x, bb, 0u);
                         m = dword_matched(x0.y, bb, m);
                         m = dword_matched(x1.x, bb, m);
@@ -555,7 +558,7 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
     static const int wgs_per_cu = [] {
         const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 4;
+        return v > 0 ? v : RSB_MIN_WGS_PER_CU;
     }();
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;

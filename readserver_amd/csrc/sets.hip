@@ -239,8 +239,8 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
 }
 
 // Builds the k-mer tables of the shards that have none.  depth 0 = per device, the deepest T whose
-// tables (one per shard of that device) fit a third of the device's free HBM, none larger than its
-// shard's lines, with 4^T <= the smallest shard's length; at most 16.
+// tables (one per shard of that device) fit a third of the device's free HBM, none larger than 5/4 of
+// its shard's lines, with 4^T <= the smallest shard's length; at most 16.
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     for (dev_group *g : s->groups) {
@@ -259,7 +259,7 @@ int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
                 min_bytes = std::min(min_bytes, h->hbm_bytes);
             }
             if (!need) continue;
-            const uint64_t budget = std::min<uint64_t>(min_bytes, free_b / 3 / need);
+            const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, free_b / 3 / need);
             T = 1;
             while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= min_n) ++T;
             if (T < 2u) continue;
