@@ -336,7 +336,7 @@ int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg);
 int rsbwt_service_run(rsbwt_service_t *s);   /* on the calling thread, until the transport closes */
 int rsbwt_service_start(rsbwt_service_t *s); /* on a thread of its own */
-int rsbwt_service_stop(rsbwt_service_t *s);
+int rsbwt_service_stop(rsbwt_service_t *s);  /* at once; after rsbwt_transport_close: once all that was pushed is answered */
 void rsbwt_service_free(rsbwt_service_t *s);
 /* {requests, count requests, windows, replies sent, malformed messages, largest window} */
 void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6);

@@ -923,7 +923,7 @@ static int extract_slices(rsbwt_t *h, call_ctx *c, const uint64_t *rows, size_t 
         uint8_t *base = (uint8_t *)c->d_stage;
         uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
         HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_extract(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, st);
+        hipError_t e = launch_extract_wave(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
         if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
         if ((rc = fn(i0, m, d_out, d_len, d_pl, d_len + a_len)) != RSBWT_OK) return rc;
     }
@@ -965,7 +965,7 @@ int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uin
     int rc = use_device(h->device);
     if (rc) return rc;
     if ((rc = ensure_select_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
-    hipError_t e = launch_extract(h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, (hipStream_t)stream);
+    hipError_t e = launch_extract_wave(h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;
 }

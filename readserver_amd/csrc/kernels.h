@@ -57,8 +57,10 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
 // symbol) and the walk kernel
 uint64_t select_sample_stride(const shard_view &ix);
 hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream);
-hipError_t launch_extract(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
-                          void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream);
+// extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
+hipError_t launch_extract_wave(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n, void *d_out,
+                               uint32_t stride, void *d_plen, void *d_len, int num_cus, hipStream_t stream);
+constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences: the window search spans a few windows
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
                               const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream);

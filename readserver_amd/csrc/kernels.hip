@@ -223,7 +223,6 @@ char_batch_kernel(const shard_view ix, const uint64_t *__restrict__ index, size_
 }
 
 // Sampled select: sel[c][m] = window holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
-constexpr uint32_t SEL_SHIFT = 8;  // one sample per 256 occurrences: the header search spans a few windows
 
 __global__ void __launch_bounds__(256)
 select_sample_kernel(const shard_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
@@ -393,56 +392,6 @@ hits1mm_write_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Read extraction (query.cpp:43-85): the read whose suffix is SA row `row`.
-// ------------------------------------------------------------------------------------------
-// extractPrefix (query.cpp:43-63): LF walk left until '$'.  One thread per row; the characters are
-// produced right to left, so they are written downwards from the end of the row's buffer.
-__global__ void __launch_bounds__(256)
-extract_prefix_kernel(const shard_view ix, const uint64_t *__restrict__ rows, size_t n,
-                      uint8_t *__restrict__ out, uint32_t stride, uint32_t *__restrict__ plen) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t idx = rows[i];
-    uint8_t *buf = out + i * (size_t)stride;
-    uint32_t len = 0;
-    bool fits = idx < ix.n;
-    while (fits) {
-        uint64_t occ = 0;
-        const uint32_t c = thread_char_occ(ix, idx, &occ);
-        if (c == 0u) break;
-        if (len == stride) { fits = false; break; }  // the reference would spin (query.cpp:48)
-        idx = ix.C[c] + occ - 1ull;  // C[b] + Occ(b, idx-1)
-        buf[stride - 1u - len] = (uint8_t)("$ACGT"[c]);
-        ++len;
-    }
-    plen[i] = fits ? len : 0xFFFFFFFFu;
-}
-
-// extractPostfix (query.cpp:65-85): F / select walk right until '$', appended after the prefix.
-__global__ void __launch_bounds__(256)
-extract_postfix_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
-                       const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out,
-                       uint32_t stride, const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint8_t *buf = out + i * (size_t)stride;
-    const uint32_t pl = plen[i];
-    if (pl == 0xFFFFFFFFu || rows[i] >= ix.n) { tlen[i] = 0xFFFFFFFFu; return; }
-    for (uint32_t k = 0; k < pl; ++k) buf[k] = buf[stride - pl + k];  // prefix into place (src >= dst)
-    uint32_t len = pl;
-    uint64_t idx = rows[i];
-    for (;;) {
-        uint32_t f = 0;  // getF, rlebwt.cpp:307-314
-        while (f < 4u && ix.C[f + 1] <= idx) ++f;
-        if (f == 0u) break;
-        if (len == stride) { len = 0xFFFFFFFFu; break; }
-        idx = thread_occ_at_sampled(ix, sel, stride_m, f, idx - ix.C[f] + 1ull);
-        buf[len++] = (uint8_t)("$ACGT"[f]);
-    }
-    tlen[i] = len;
-}
-
 // query / query_exactmatch (query.cpp:87-120) over the extracted rows of a batch of k-mers: row i
 // belongs to k-mer owner[i]; flags[i] = 1 when the read equals the k-mer (exact match: the whole read
 // is the query, query.cpp:112-116).
@@ -604,17 +553,6 @@ hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStrea
     if (ix.nwin == 0) return hipSuccess;
     hipLaunchKernelGGL(select_sample_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix));
-    return hipGetLastError();
-}
-
-hipError_t launch_extract(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n,
-                          void *d_out, uint32_t stride, void *d_plen, void *d_len, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(extract_prefix_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix,
-                       (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen);
-    hipLaunchKernelGGL(extract_postfix_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
-                       select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
-                       (const uint32_t *)d_plen, (uint32_t *)d_len);
     return hipGetLastError();
 }
 

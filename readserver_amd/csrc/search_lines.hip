@@ -24,54 +24,9 @@
 #include "kernels.h"
 #include "line_format.h"
 #include "rank_device.h"
+#include "wave_lines.h"
 
 namespace rsb {
-
-// LDS stage: 128 B per lane, 8 KB per wave, 32 KB per 4-wave workgroup, so 5 workgroups
-// (20 waves) would fit a CU's 160 KB; 4 are launched.
-constexpr int SLOT_U4 = 8;
-constexpr int WG_WAVES = 4;  // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
-#ifndef RSB_MIN_WGS_PER_CU  // tuning knob (tools/build_variant.sh): register budget = 512 / this many waves per SIMD
-#define RSB_MIN_WGS_PER_CU 4
-#endif
-
-// The stage is written by LDS-DMA and parsed as dwords / 8- / 16-byte pieces: the read types may
-// alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
-typedef uint32_t __attribute__((may_alias)) lds_u32;
-typedef uint2 __attribute__((may_alias)) lds_u2;
-typedef uint4 __attribute__((may_alias)) lds_u4;
-typedef __attribute__((address_space(3))) void *lds_void_ptr;
-typedef const __attribute__((address_space(1))) void *global_void_ptr;
-
-// Fetch of up to 64 lines into the wave's LDS stage, direct to LDS (global_load_lds_dwordx4,
-// gfx950): no register round trip, no ds_write pass.  One instruction writes 1 KB of LDS in lane
-// order, so the work is split the way that makes this the stage layout itself: instruction k
-// (0..7) serves lanes T = 8o + k, the eight lanes of octet o each bringing 16 B of the line
-// lane T wants (a full 128-B line per octet: the request shape tools/gather_bench.hip measures
-// fastest).  Lane T's line then sits at k * 1 KB + o * 128 B, chunk c at position c ^ k -- the
-// swizzle is applied on the SOURCE side (lane l of the octet loads chunk (l & 7) ^ k).
-// want == ~0u: that lane needs nothing (its octet's lanes are masked off for that instruction and
-// the row keeps what it held).
-__device__ __forceinline__ void glds_fetch(const char *lines, uint32_t want, uint32_t lane, uint32_t stage_lds) {
-    uint32_t tb[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        tb[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~7u) + k) << 2), (int)want);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (tb[k] != ~0u) {
-            const char *src = lines + (uint64_t)tb[k] * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
-            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, 0);
-        }
-    }
-}
-// the lines are in LDS once every outstanding load has returned
-// (the builtin, not inline asm: hipcc's wait-count bookkeeping then knows nothing is outstanding and
-// does not add its own vmcnt(0) at the head of the next pass, in front of that pass's loads)
-__device__ __forceinline__ void glds_wait() {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding)
-    asm volatile("" ::: "memory");
-}
 
 // Start state of every (query, shard) search, computed ahead of the search so that a search
 // entering the wave costs one independent 16-byte load instead of a chain (validity byte + packed

@@ -35,7 +35,8 @@ class transport {
     // next Request message; waits at most timeout_us (< 0: until one arrives or the transport
     // closes).  false = nothing arrived in time, or closed.
     virtual bool recv(std::vector<uint8_t> *msg, int64_t timeout_us) = 0;
-    virtual bool closed() = 0;
+    virtual bool closed() = 0;   // closed AND nothing left to receive
+    virtual bool closing() = 0;  // close was asked for: what is queued is still answered
     enum channel { PUSH = 0, PUSH_COUNT = 1 };
     virtual void send(channel c, const uint8_t *data, size_t n) = 0;
 };

@@ -159,6 +159,10 @@ class inproc_transport : public transport {
         std::lock_guard<std::mutex> lock(mu_);
         return closed_ && in_.empty();
     }
+    bool closing() override {
+        std::lock_guard<std::mutex> lock(mu_);
+        return closed_;
+    }
     void send(channel c, const uint8_t *data, size_t n) override {
         {
             std::lock_guard<std::mutex> lock(mu_);
@@ -227,6 +231,7 @@ class zmq_transport : public transport {
         return n >= 0;
     }
     bool closed() override { return stop_.load(); }
+    bool closing() override { return stop_.load(); }
     void send(channel c, const uint8_t *data, size_t n) override {
         std::lock_guard<std::mutex> lock(mu_);  // the reference guards sender->send the same way (service.cpp:311-313)
         zmq_send(out_[c], data, n, 0);
@@ -485,7 +490,8 @@ int rsbwt_service_start(rsbwt_service_t *s) {
 
 int rsbwt_service_stop(rsbwt_service_t *s) {
     if (!s) return fail(RSBWT_EINVAL, "null service");
-    s->stop.store(true);
+    // a transport that is closing drains: the loop ends by itself once what was received is answered
+    if (!s->tr->closing()) s->stop.store(true);
     if (s->worker.joinable()) s->worker.join();
     return s->last_rc == RSBWT_OK ? RSBWT_OK : fail(s->last_rc, "%s", s->last_err.c_str());
 }

@@ -1,0 +1,97 @@
+// wave_lines.h -- what the wave-cooperative kernels share (search_lines.hip, extract_lines.hip): the
+// wave's LDS stage, the direct-to-LDS fetch of one window line per lane, and accessors into a lane's
+// staged line.
+#ifndef RSBWT_WAVE_LINES_H
+#define RSBWT_WAVE_LINES_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "line_format.h"
+#include "rank_device.h"
+
+namespace rsb {
+
+// LDS stage: 128 B per lane, 8 KB per wave, 32 KB per 4-wave workgroup, so 5 workgroups
+// (20 waves) would fit a CU's 160 KB; 4 are launched.
+constexpr int SLOT_U4 = 8;
+constexpr int WG_WAVES = 4;  // waves per workgroup (one-wave groups would pack 17 per CU but measured 1.4x slower)
+#ifndef RSB_MIN_WGS_PER_CU  // tuning knob (tools/build_variant.sh): register budget = 512 / this many waves per SIMD
+#define RSB_MIN_WGS_PER_CU 4
+#endif
+
+// The stage is written by LDS-DMA and parsed as dwords / 8- / 16-byte pieces: the read types may
+// alias anything, or type-based alias analysis lets hipcc reuse values read before a re-fetch.
+typedef uint32_t __attribute__((may_alias)) lds_u32;
+typedef uint2 __attribute__((may_alias)) lds_u2;
+typedef uint4 __attribute__((may_alias)) lds_u4;
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
+
+// Fetch of up to 64 lines into the wave's LDS stage, direct to LDS (global_load_lds_dwordx4,
+// gfx950): no register round trip, no ds_write pass.  One instruction writes 1 KB of LDS in lane
+// order, so the work is split the way that makes this the stage layout itself: instruction k
+// (0..7) serves lanes T = 8o + k, the eight lanes of octet o each bringing 16 B of the line
+// lane T wants (a full 128-B line per octet: the request shape tools/gather_bench.hip measures
+// fastest).  Lane T's line then sits at k * 1 KB + o * 128 B, chunk c at position c ^ k -- the
+// swizzle is applied on the SOURCE side (lane l of the octet loads chunk (l & 7) ^ k).
+// want == ~0u: that lane needs nothing (its octet's lanes are masked off for that instruction and
+// the row keeps what it held).
+__device__ __forceinline__ void glds_fetch(const char *lines, uint32_t want, uint32_t lane, uint32_t stage_lds) {
+    uint32_t tb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        tb[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~7u) + k) << 2), (int)want);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (tb[k] != ~0u) {
+            const char *src = lines + (uint64_t)tb[k] * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
+            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, 0);
+        }
+    }
+}
+// the lines are in LDS once every outstanding load has returned
+// (the builtin, not inline asm: hipcc's wait-count bookkeeping then knows nothing is outstanding and
+// does not add its own vmcnt(0) at the head of the next pass, in front of that pass's loads)
+__device__ __forceinline__ void glds_wait() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
+
+
+// A lane's staged line: dword d of the line lane T asked for sits at chunk (d >> 2) ^ (T & 7) of the
+// row (T & 7) * 1 KB + (T >> 3) * 128 B of its wave's stage (glds_fetch); lanes l and l + 32 share
+// the swizzle, so the upper side of a pair can read the lower side's row (row - 512 B).
+struct staged_line {
+    const lds_u32 *row;
+    uint32_t swz;
+    __device__ __forceinline__ const lds_u32 *at(uint32_t d) const { return row + ((((d) >> 2) ^ swz) << 2) + ((d) & 3u); }
+    __device__ __forceinline__ uint32_t dword(uint32_t d) const { return *at(d); }
+    __device__ __forceinline__ uint2 u2(uint32_t d) const { return *reinterpret_cast<const lds_u2 *>(at(d)); }  // d even
+    __device__ __forceinline__ uint4 u4(uint32_t d) const { return *reinterpret_cast<const lds_u4 *>(at(d)); }  // d % 4 == 0
+};
+
+__device__ __forceinline__ const lds_u32 *own_stage_row(const uint4 *stage, uint32_t lane) {
+    return reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
+}
+
+// what the 24 pieces at dwords qd .. qd+5 hold of symbol b, 4 runs per v_dot4_u32_u8
+__device__ __forceinline__ uint32_t matched24(const staged_line &L, uint32_t qd, uint32_t b) {
+    const uint2 x0 = L.u2(qd & 31u), x1 = L.u2((qd + 2u) & 31u), x2 = L.u2((qd + 4u) & 31u);
+    const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte
+    uint32_t m = dword_matched(x0.x, bb, 0u);
+    m = dword_matched(x0.y, bb, m);
+    m = dword_matched(x1.x, bb, m);
+    m = dword_matched(x1.y, bb, m);
+    m = dword_matched(x2.x, bb, m);
+    return dword_matched(x2.y, bb, m);
+}
+
+// the 24 pieces at dword dw into registers
+__device__ __forceinline__ void load24(const staged_line &L, uint32_t dw, uint32_t r6[6]) {
+    const uint2 y0 = L.u2(dw & 31u), y1 = L.u2((dw + 2u) & 31u), y2 = L.u2((dw + 4u) & 31u);
+    r6[0] = y0.x; r6[1] = y0.y; r6[2] = y1.x; r6[3] = y1.y; r6[4] = y2.x; r6[5] = y2.y;
+}
+
+}  // namespace rsb
+#endif
