@@ -132,19 +132,33 @@ def main():
         torch.cuda.empty_cache()
         shards.append(g)
     sset = rsb.ShardSet(shards)
-    if a.ktab_depth == 0:
-        ok(L.rsbwt_set_attach_ktabs(sset._s, 0))
-    t_build = time.time() - t_build0
     n_sym = shards[0].getBWLen()
+    # the batch's buffers first (rank 0 also holds the gathered intervals of all ranks), then the k-mer
+    # tables out of what HBM is left: one depth for every shard of the job
+    wpq = (k + 31) // 32
+    from readserver_amd import sharded
+    d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
+    d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
+    d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
+    gat = sharded.IntervalGatherer(S, Q, dev, depth=2)
+    if a.ktab_depth == 0:
+        T = L.rsbwt_set_auto_ktab_depth(sset._s)
+        if world > 1:
+            tt = torch.tensor([T], dtype=torch.int64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            T = int(tt.item())
+        if T >= 2:
+            ok(L.rsbwt_set_attach_ktabs(sset._s, T))
+    t_build = time.time() - t_build0
 
     # ---- the query batch (identical on every rank) ----------------------------------------------
     n_present = int(Q * a.present_frac)
     gen = torch.Generator(device=dev)
     gen.manual_seed(a.seed + 12345)
-    codes = torch.randint(0, 4, (Q, k), generator=gen, device=dev, dtype=torch.uint8)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    d_kmers = _lut_chunks(lut, codes)
-    del codes
+    for i in range(0, Q, 1 << 22):
+        j = min(Q, i + (1 << 22))
+        d_kmers[i:j] = lut[torch.randint(0, 4, (j - i, k), generator=gen, device=dev, dtype=torch.uint8).long()]
     # present k-mers: every rank draws its share evenly from its shards; shares are concatenated
     share = n_present // world
     if share:
@@ -167,11 +181,6 @@ def main():
         d_kmers[idx] = mine
         del mine, idx, parts
 
-    wpq = (k + 31) // 32
-    from readserver_amd import sharded
-    d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
-    d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
-    gat = sharded.IntervalGatherer(S, Q, dev, depth=2)
     step_no = [0]
 
     def step():
@@ -311,15 +320,6 @@ def main():
         g.close()
     if world > 1:
         dist.destroy_process_group()
-
-
-def _lut_chunks(lut, codes):
-    import torch
-    out = torch.empty_like(codes)
-    step = 1 << 22
-    for i in range(0, codes.shape[0], step):
-        out[i:i + step] = lut[codes[i:i + step].long()]
-    return out
 
 
 def _pmc_traffic(R, Q, S, k, stream):

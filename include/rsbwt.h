@@ -256,8 +256,10 @@ void rsbwt_set_close(rsbwt_set_t *s); /* closes the shards it opened itself */
 size_t rsbwt_set_size(const rsbwt_set_t *s);
 size_t rsbwt_set_devices(const rsbwt_set_t *s);
 rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
-/* k-mer tables for the shards that have none; depth 0 = sized per device from its free HBM */
+/* k-mer tables for the shards that have none; depth 0 = sized per device from its free HBM (the depth
+ * that gives, over all devices: rsbwt_set_auto_ktab_depth) */
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth);
+uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s);
 /* lower/upper: [num_shards][Q]; counts: [Q] summed over shards, the way the front-end sums
  * per-partition replies (src/service/server.cpp:184-197).  With several devices the per-device sums
  * are reduced onto the first device over RCCL (ncclReduce) and cross PCIe once. */

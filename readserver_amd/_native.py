@@ -124,6 +124,7 @@ SIGNATURES = {
     "rsbwt_set_size": (C.c_size_t, [_vp]),
     "rsbwt_set_devices": (C.c_size_t, [_vp]),
     "rsbwt_set_attach_ktabs": (C.c_int, [_vp, C.c_uint32]),
+    "rsbwt_set_auto_ktab_depth": (C.c_uint32, [_vp]),
     "rsbwt_set_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_set_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "rsbwt_set_gather_intervals_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), _vp, C.POINTER(_vp)]),

@@ -238,34 +238,43 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
     return RSBWT_OK;
 }
 
-// Builds the k-mer tables of the shards that have none.  depth 0 = per device, the deepest T whose
-// tables (one per shard of that device) fit a third of the device's free HBM, none larger than 5/4 of
-// its shard's lines, with 4^T <= the smallest shard's length; at most 16.
+// The depth rsbwt_set_attach_ktabs(s, 0) would give the shards of device group g: the deepest T whose
+// tables (one per shard of that device without one) fit a third of the device's free HBM, none larger
+// than 5/4 of its shard's lines, with 4^T <= the smallest shard's length; at most 16; 0 = none.
+static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g) {
+    if (use_device(g->device)) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    uint64_t min_n = ~0ull, min_bytes = ~0ull, need = 0;
+    for (size_t i : g->idx) {
+        const rsbwt_t *h = s->shards[i];
+        if (h->view.ktab || h->view.n == 0) continue;
+        ++need;
+        min_n = std::min(min_n, h->view.n);
+        min_bytes = std::min(min_bytes, h->hbm_bytes);
+    }
+    if (!need) return 0;
+    const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, free_b / 3 / need);
+    uint32_t T = 1;
+    while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= min_n) ++T;
+    return T < 2u ? 0u : T;
+}
+
+uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {
+    if (!s) return 0;
+    uint32_t T = 16;
+    for (dev_group *g : s->groups) T = std::min(T, auto_ktab_depth(s, g));
+    return T;
+}
+
+// Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     for (dev_group *g : s->groups) {
-        int rc = use_device(g->device);
-        if (rc) return rc;
-        uint32_t T = depth;
-        if (T == 0u) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-            uint64_t min_n = ~0ull, min_bytes = ~0ull, need = 0;
-            for (size_t i : g->idx) {
-                const rsbwt_t *h = s->shards[i];
-                if (h->view.ktab || h->view.n == 0) continue;
-                ++need;
-                min_n = std::min(min_n, h->view.n);
-                min_bytes = std::min(min_bytes, h->hbm_bytes);
-            }
-            if (!need) continue;
-            const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, free_b / 3 / need);
-            T = 1;
-            while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= min_n) ++T;
-            if (T < 2u) continue;
-        }
+        const uint32_t T = depth ? depth : auto_ktab_depth(s, g);
+        if (T < 2u) continue;
         for (size_t i : g->idx) {
-            rc = rsbwt_attach_ktab(s->shards[i], T);
+            const int rc = rsbwt_attach_ktab(s->shards[i], T);
             if (rc) return rc;
         }
     }

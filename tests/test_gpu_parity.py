@@ -808,6 +808,17 @@ def test_gpu_shard_set_fused_launch_device_resident(rsb, oracle):
     ms = (C.c_float * 8)()
     cnt = C.c_size_t()
     assert L.rsbwt_set_search_history_ms(ss._s, ms, 8, C.byref(cnt)) == 0 and cnt.value == 8 and min(ms) > 0
+    # the gather entry of the C++ host: with one device it is a device-to-device copy of the [S][Q] block
+    # (several devices: ncclSend / ncclRecv in one group -- no multi-GPU box here)
+    assert L.rsbwt_rccl_available() in (0, 1)
+    blk = torch.stack([d_lo, d_up]).contiguous()
+    root = torch.zeros_like(blk)
+    blocks = (C.c_void_p * 1)(blk.data_ptr())
+    sizes = (C.c_size_t * 1)(blk.numel() * 8)
+    streams = (C.c_void_p * 1)(None)
+    assert L.rsbwt_set_gather_intervals_dev(ss._s, blocks, sizes, C.c_void_p(root.data_ptr()), streams) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(root, blk)
     ss.close()
     for g in shards:
         g.close()

@@ -114,7 +114,7 @@ out["extract"] = {
     "rows": NR, "rows_fitting_stride": int(fits.sum()), "mean_read_length": float(ln[fits].mean()),
     "reads_per_s": NR / (ms * 1e-3), "bases_per_s": float(ln[fits].sum()) / (ms * 1e-3), "ms_per_call": ms,
     "roofline": {"bound": "hbm", "achieved": steps * 128 / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
-                 "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_kernel + extract_postfix_kernel",
+                 "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel",
                  "algorithmic_bytes": steps * 128, "steps": steps},
 }
 g.close()
