@@ -176,6 +176,10 @@ int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_val
                              uint32_t k, void *d_lower, void *d_upper, void *stream);
 int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                     void *d_counts, void *stream);
+/* The same intervals as BWTInterval pairs (include/bwt/query.h:8-11): d_pairs[q] = {lower, upper}, 16
+ * bytes per k-mer, written by one store per search (the separate arrays cost two scattered stores). */
+int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                                  void *d_pairs, void *stream);
 /* 1-mismatch search of m packed k-mers: d_lower/d_upper [m][3k+1] (rsbwt_find_intervals_1mm's layout);
  * d_scratch: rsbwt_1mm_scratch_bytes(h, m, k) bytes. */
 size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);
@@ -273,6 +277,9 @@ int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const voi
                                  uint32_t k, void *d_lower, void *d_upper, void *stream);
 int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                         void *d_counts, void *stream);
+/* d_pairs: [num_shards][Q] x {lower, upper} */
+int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q,
+                                      uint32_t k, void *d_pairs, void *stream);
 /* Gathers per-device result blocks onto the set's first device over RCCL / xGMI (ncclSend/ncclRecv in
  * one group): d_blocks[g], bytes[g], streams[g] belong to device g of the set; d_root (first device)
  * receives the blocks back to back.  For GPU-resident consumers of all shards' intervals. */

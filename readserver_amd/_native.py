@@ -78,6 +78,7 @@ SIGNATURES = {
     "rsbwt_pack_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "rsbwt_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_find_interval_pairs_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "rsbwt_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),
     "rsbwt_find_intervals_1mm_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp, _vp]),
     "rsbwt_extract_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, _vp]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     "rsbwt_set_auto_ktab_depth": (C.c_uint32, [_vp]),
     "rsbwt_set_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_set_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_set_find_interval_pairs_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "rsbwt_set_gather_intervals_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), _vp, C.POINTER(_vp)]),
     "rsbwt_rccl_available": (C.c_int, []),
     "rsbwt_set_set_counting": (C.c_int, [_vp, C.c_int]),

@@ -614,7 +614,8 @@ namespace rsb {
 int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                   const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                   hipStream_t stream, const search_extra *extra) {
-    if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
+    const bool pairs = extra && extra->pairs;
+    if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !pairs && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
     if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1 for device-resident searches");
     if (k > 65535u) return fail(RSBWT_ERANGE, "k %u: at most 65535 symbols per k-mer", k);
     std::lock_guard<std::mutex> lock(m.mu);
@@ -733,6 +734,13 @@ int rsbwt_find_intervals_dev(rsbwt_t *h, const void *d_packed, const void *d_val
 int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                     void *d_counts, void *stream) {
     return search_dev(h, d_packed, d_valid, Q, k, d_counts, nullptr, true, (hipStream_t)stream);
+}
+
+int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                                  void *d_pairs, void *stream) {
+    search_extra ex;
+    ex.pairs = true;
+    return search_dev(h, d_packed, d_valid, Q, k, d_pairs, nullptr, false, (hipStream_t)stream, &ex);
 }
 
 int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,

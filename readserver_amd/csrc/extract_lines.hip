@@ -183,6 +183,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
                 } else if (h.kind == KIND_CHUNK && cont == 0u) {
                     cdw = read_chunk_dword(L);
                     cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                    if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
                     co = oe - h.span;
                 } else {
@@ -243,6 +244,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
                     acc = cnt;
                     cdw = read_chunk_dword(L);
                     cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                    if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
                     co = oe - h.span;
                 } else {
@@ -410,6 +412,7 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 } else if (h.kind == KIND_CHUNK && cont == 0u) {
                     cdw = read_chunk_dword(L);
                     cblk = (wlo >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                    if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
                     posbase += h.span;
                     t = left;  // what the chunk's pieces still have to provide

@@ -27,6 +27,7 @@ struct search_extra {
     const void *d_trace_in = nullptr;
     uint32_t trace_n = 0, variants = 0;
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
+    bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
 };
 hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
                          size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,

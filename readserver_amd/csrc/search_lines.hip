@@ -126,7 +126,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                     size_t Q, uint32_t k, uint32_t wpq,
                     uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                     unsigned long long *__restrict__ work,
-                    ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk) {
+                    ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -170,8 +170,11 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
         const int j_table = ktab ? (int)(k - sv->ktab_depth) - 1 : (int)k - 2;
         const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
         const ulonglong2 *init_s = init + (size_t)sid * Q;
-        uint64_t *out_lo = out_lower + (size_t)sid * Q;
-        uint64_t *out_up = COUNTS_ONLY ? nullptr : out_upper + (size_t)sid * Q;
+        // results: lower[s][q] and upper[s][q], or (pairs) {lower, upper}[s][q] -- one 16-byte store
+        // instead of two 8-byte ones: the stores of ended searches are scattered, each is a request of
+        // its own, and requests are what this kernel is bound by
+        uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
+        uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;
         // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
         // ds_bpermute reads (selects out of scalar registers cost 15 VALU instructions a pass; a
@@ -370,6 +373,17 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                         m = dword_matched(x1.y, bb, m);
                         m = dword_matched(x2.x, bb, m);
                         m = dword_matched(x2.y, bb, m);
+#ifdef RSB_EXPERIMENT_EXTRA_DOT4  // timing experiment (answers unchanged): the quarter sum done twice
+                        {
+                            uint32_t m2 = dword_matched(x0.x ^ 1u, bb, 1u);
+                            m2 = dword_matched(x0.y ^ 1u, bb, m2);
+                            m2 = dword_matched(x1.x ^ 1u, bb, m2);
+                            m2 = dword_matched(x1.y ^ 1u, bb, m2);
+                            m2 = dword_matched(x2.x ^ 1u, bb, m2);
+                            m2 = dword_matched(x2.y ^ 1u, bb, m2);
+                            asm volatile("" ::"v"(m2));
+                        }
+#endif
                         base = cnt + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
                         dw = HDR_DWORDS + 6u * cq;
                         rem = oe - start;
@@ -384,6 +398,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                         cacc = cnt;
                         cdw = 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
                         cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                        if (cblk >= nlines) cblk = 0;  // never for p < n
                         cont = KIND_CHUNK;
                         co = oe - span;
                     } else {  // a position beyond what the index holds: never for p < n
@@ -412,6 +427,12 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 const uint2 y2 = *reinterpret_cast<const lds_u2 *>(MINE((dw + 4u) & 31u));
                 const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
                 const uint32_t sc = runs_scan<6>(r6, b, rem);
+#ifdef RSB_EXPERIMENT_EXTRA_SCAN2  // timing experiment (answers unchanged): 8 more pieces scanned
+                {
+                    const uint32_t sc2 = runs_scan<2>(r6 + 2, b, rem + 1u);
+                    asm volatile("" ::"v"(sc2));
+                }
+#endif
                 if (do_scan) {
                     occ_hold = base + sc;
                     ready = true;
@@ -451,6 +472,8 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 if (side == 0u) {
                     if (COUNTS_ONLY) {
                         out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                    } else if (pairs) {
+                        reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
                     } else {
                         out_lo[q] = lo;
                         out_up[q] = hi;
@@ -480,7 +503,8 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
 template <bool CW, bool CO>
 static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uint32_t nshards, const uint64_t *pk,
                      const ulonglong2 *init, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
-                     uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n) {
+                     uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n,
+                     uint32_t pairs) {
     // queries per draw from the pool: at least ~4 draws per wave, so that a batch of a few
     // thousand queries (a service micro-batch, the k-mers of a 1-mismatch slice) still occupies
     // every wave launched instead of the first few
@@ -488,10 +512,10 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
     while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
     if (wpq > 1)
         hipLaunchKernelGGL((search_lines_kernel<CW, CO, true, 0>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
     else
         hipLaunchKernelGGL((search_lines_kernel<CW, CO, false, 0>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk);
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
 }
 
 hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
@@ -499,7 +523,9 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                          const search_extra *extra) {
     if (Q == 0 || nshards == 0) return hipSuccess;
-    if (extra && nshards != 1) return hipErrorInvalidValue;  // traced / resumed searches: one shard
+    if (extra && (extra->d_trace_out || extra->d_trace_in || extra->table_build) && nshards != 1)
+        return hipErrorInvalidValue;  // traced / resumed searches: one shard
+    const uint32_t pairs = (extra && extra->pairs && !counts_only) ? 1u : 0u;
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
     const uint32_t trace_n = extra ? extra->trace_n : 0u;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
@@ -544,13 +570,13 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
         uint32_t qchunk = 1024;
         while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
         hipLaunchKernelGGL((search_lines_kernel<false, false, false, 1>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, d_shards,
-                           nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, qchunk);
+                           nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, qchunk, 0u);
     } else if (d_work) {
-        if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
-        else launch_k<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+        else launch_k<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
     } else {
-        if (counts_only) launch_k<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
-        else launch_k<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n);
+        if (counts_only) launch_k<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+        else launch_k<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
     }
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);

@@ -425,6 +425,19 @@ int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const voi
                          false, (hipStream_t)stream, nullptr);
 }
 
+int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
+                                      void *d_pairs, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    dev_group *g = s->groups[0];
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    search_extra ex;
+    ex.pairs = true;
+    return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_pairs, nullptr,
+                         false, (hipStream_t)stream, &ex);
+}
+
 int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                         void *d_counts, void *stream) {
     if (!s) return fail(RSBWT_EINVAL, "null set");

@@ -65,14 +65,17 @@ class IntervalGatherer:
     On rank `dst`, `result(i)` is the list of `world` tensors [2, S_local, Q] of batch i.
     """
 
-    def __init__(self, s_local, q, device, depth=2, dst=0, group=None, dtype=torch.int64):
+    def __init__(self, s_local, q, device, depth=2, dst=0, group=None, dtype=torch.int64, interleaved=False):
+        """interleaved: buffers are [S_local, Q, 2] = {lower, upper} pairs (what rsbwt_*_interval_pairs_dev
+        writes) instead of [2, S_local, Q]."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.dst, self.group, self.depth = dst, group, depth
-        self._pairs = [torch.empty((2, s_local, q), dtype=dtype, device=device) for _ in range(depth)]
+        shape = (s_local, q, 2) if interleaved else (2, s_local, q)
+        self._pairs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
         self._out = None
         if self.world > 1 and self.rank == dst:
-            self._out = [[torch.empty((2, s_local, q), dtype=dtype, device=device) for _ in range(self.world)]
+            self._out = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)]
                          for _ in range(depth)]
         self._work = [None] * depth
 

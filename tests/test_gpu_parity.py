@@ -797,6 +797,15 @@ def test_gpu_shard_set_fused_launch_device_resident(rsb, oracle):
             T = shards[s].ktab_depth()
             steps += int(np.maximum(st.astype(np.int64) - (max(T, 1) - 1 if k >= T else 0), 0).sum())
         assert w[0] == steps and w[2] <= w[1] <= 2 * w[0]
+        # the same intervals as {lower, upper} pairs (one 16-byte store per search), set and single handle
+        d_pr = torch.empty((len(sizes), Q, 2), dtype=torch.int64, device="cuda:0")
+        assert L.rsbwt_set_find_interval_pairs_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(d_pr), None) == 0
+        d_p3 = torch.empty((Q, 2), dtype=torch.int64, device="cuda:0")
+        assert L.rsbwt_find_interval_pairs_dev(shards[3].handle, p(d_pk), p(d_ok), Q, k, p(d_p3), None) == 0
+        torch.cuda.synchronize()
+        pr = d_pr.cpu().numpy().view(np.uint64)
+        assert np.array_equal(pr[:, :, 0], lo) and np.array_equal(pr[:, :, 1], up)
+        assert np.array_equal(d_p3.cpu().numpy().view(np.uint64), pr[3])
         d_cnt = torch.empty((len(sizes), Q), dtype=torch.int64, device="cuda:0")
         assert L.rsbwt_set_count_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(d_cnt), None) == 0
         torch.cuda.synchronize()
