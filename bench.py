@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--separate-arrays", action="store_true",
                     help="results as lower[S][Q] and upper[S][Q] (two scattered 8-byte stores per search) instead of "
                          "{lower, upper}[S][Q] pairs (one 16-byte store)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal where only one GPU exists: every rank uses GPU 0 and the collectives run over "
+                         "gloo through host copies (RCCL refuses two ranks on one device).  Exercises this script's "
+                         "multi-rank logic, not xGMI: its numbers mean nothing")
     ap.add_argument("--no-single-check", action="store_true",
                     help="skip the single-shard (configs[1]) launches after the timed region: profile passes want "
                          "only the fused launches under the kernel's name")
@@ -101,11 +105,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(1)
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if a.rehearse_on_one_gpu else dev  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     L = rsb.lib()
     R, Q, k, S = int(a.runs), int(a.queries), a.k, a.shards_per_gpu
@@ -143,11 +153,12 @@ def main():
     d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
     d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
-    gat = sharded.IntervalGatherer(S, Q, dev, depth=2, interleaved=not a.separate_arrays)
+    gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays)
+    d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
     if a.ktab_depth == 0:
         T = L.rsbwt_set_auto_ktab_depth(sset._s)
         if world > 1:
-            tt = torch.tensor([T], dtype=torch.int64, device=dev)
+            tt = torch.tensor([T], dtype=torch.int64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             T = int(tt.item())
         if T >= 2:
@@ -176,9 +187,10 @@ def main():
         mine = torch.cat(parts, 0)
         mine = mine[torch.randperm(mine.shape[0], device=dev, generator=gen)]  # the shards' k-mers interleaved
         if world > 1:
-            allp = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allp, mine)
-            mine = torch.cat(allp, 0)
+            mine_c = mine.to(cdev)
+            allp = [torch.empty_like(mine_c) for _ in range(world)]
+            dist.all_gather(allp, mine_c)
+            mine = torch.cat(allp, 0).to(dev)
         # interleave present and random k-mers so every wave sees the mix
         idx = torch.arange(mine.shape[0], device=dev) * (Q // mine.shape[0])
         d_kmers[idx] = mine
@@ -190,11 +202,16 @@ def main():
         i = step_no[0]
         step_no[0] += 1
         pair = gat.acquire(i)
+        host_pair = None
+        if d_res is not None:  # rehearsal: search into HBM, gather from a host copy
+            host_pair, pair = pair, d_res[i % 2]
         ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
         if a.separate_arrays:
             ok(L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
         else:
             ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair), sp))
+        if host_pair is not None:
+            host_pair.copy_(pair)
         gat.submit(i)
 
     def barrier():
@@ -230,9 +247,20 @@ def main():
     ok(L.rsbwt_set_search_history_ms(sset._s, buf, min(a.steps, 64), C.byref(cnt)))
     k_ms = list(buf[:cnt.value])
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # the gathered blocks are what the ranks sent: checksums of the last batch, rank by rank
+    gather_verified = None
+    if world > 1:
+        last = step_no[0] - 1
+        mine_sum = gat.pair(last).sum().reshape(1).to(cdev)
+        sums = [torch.empty_like(mine_sum) for _ in range(world)]
+        dist.all_gather(sums, mine_sum)
+        if rank == 0:
+            got = gat.result(last)
+            gather_verified = all(int(got[r].sum().item()) == int(sums[r].item()) for r in range(world))
 
     searches = world * S * Q * a.steps
     value = searches / dt
@@ -302,8 +330,9 @@ def main():
             "spilled_position_fraction": shards[0].spilled_symbols() / max(int(n_sym), 1),
             "index_hbm_bytes_per_gpu": hbm, "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
             "index_build_s": round(t_build, 2),
+            "gather_verified": gather_verified,
             "results": ("lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
-            "multi_gpu": ("measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
+            "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
             "single_shard_check": single,
         },
         "roofline": {
@@ -318,7 +347,7 @@ def main():
     }
 
     if rank == 0 and host_runs is not None:
-        pair = gat.pair(step_no[0] - 1)
+        pair = gat.pair(step_no[0] - 1).to(dev)
         lo0, up0 = (pair[0][0], pair[1][0]) if a.separate_arrays else (pair[0, :, 0], pair[0, :, 1])
         out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, lo0, up0, Q, k)
     if rank == 0:

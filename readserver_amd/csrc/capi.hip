@@ -177,6 +177,42 @@ const char *rsbwt_strerror(int code) {
 
 // ---- lifetime -------------------------------------------------------------------------------
 
+}  // extern "C"
+
+namespace rsb {
+
+int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride) {
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipError_t e = build_ktable(h->view, T, d_table, stride, h->num_cus, g.c->st[0]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_hip(e, "building the k-mer table");
+    }
+    h->view.ktab = d_table;
+    h->view.ktab_depth = T;
+    h->view.ktab_stride = stride;
+    h->hbm_bytes += 8ull << (2u * T);
+    return upload_view(h);
+}
+
+int detach_ktab(rsbwt *h) {
+    if (h->ktab_owned || !h->view.ktab) return RSBWT_OK;
+    h->hbm_bytes -= 8ull << (2u * h->view.ktab_depth);
+    h->view.ktab = nullptr;
+    h->view.ktab_depth = 0;
+    h->view.ktab_stride = 1;
+    h->ktab_owned = true;
+    const int rc = use_device(h->device);
+    return rc ? rc : upload_view(h);
+}
+
+}  // namespace rsb
+
+extern "C" {
+
 // Builds the k-mer table of depth T (2..16) for an open handle that has none.
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
@@ -185,23 +221,13 @@ int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) {
     if (T > 16u) T = 16;  // 8 B * 4^16 = 34 GB
     int rc = use_device(h->device);
     if (rc) return rc;
-    ctx_guard g(h->pool);
-    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
     uint64_t *d_tab = nullptr;
-    const uint64_t bytes = 8ull << (2u * T);
-    hipError_t e = hipMalloc(&d_tab, bytes);
-    if (e == hipSuccess) {
-        e = build_ktable(h->view, T, d_tab, h->num_cus, g.c->st[0]);
-        if (e != hipSuccess) (void)hipFree(d_tab);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail_hip(e, "building the k-mer table");
-    }
-    h->view.ktab = d_tab;
-    h->view.ktab_depth = T;
-    h->hbm_bytes += bytes;
-    return upload_view(h);
+    hipError_t e = hipMalloc(&d_tab, 8ull << (2u * T));
+    if (e != hipSuccess) return fail_hip(e, "allocating the k-mer table");
+    rc = attach_ktab_into(h, T, d_tab, 1);
+    if (rc) (void)hipFree(d_tab);
+    else h->ktab_owned = true;
+    return rc;
 }
 
 static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
@@ -248,6 +274,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         return fail(RSBWT_EFORMAT, "run byte with a symbol code above 4 ($ACGT = 0..4, include/bwt/alphabet.h:8-9)");
     }
     h->view = br.view;
+    h->view.ktab_stride = 1;
     h->num_runs = br.num_runs;
     h->hbm_bytes = br.hbm_bytes;
     h->far_lines = br.far_lines;
@@ -360,7 +387,7 @@ void rsbwt_close(rsbwt_t *h) {
     (void)hipSetDevice(h->device);
     h->pool.destroy();
     if (h->view.lines) (void)hipFree((void *)h->view.lines);
-    if (h->view.ktab) (void)hipFree((void *)h->view.ktab);
+    if (h->view.ktab && h->ktab_owned) (void)hipFree((void *)h->view.ktab);
     if (h->d_view) (void)hipFree(h->d_view);
     if (h->d_sel) (void)hipFree(h->d_sel);
     if (h->d_work) (void)hipFree(h->d_work);

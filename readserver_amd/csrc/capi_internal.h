@@ -70,6 +70,13 @@ struct rsbwt : rsb::search_meter {
     uint64_t far_lines = 0, chunk_windows = 0, far_windows = 0, spilled_symbols = 0;
     rsb::ctx_pool pool;
     uint32_t *d_sel = nullptr;  // sampled select table, built on first use
+    bool ktab_owned = true;     // false: view.ktab points into a shard set's interleaved table
 };
+
+namespace rsb {
+// Builds h's k-mer table of depth T into d_table[c * stride] (memory owned by the caller).
+int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride);
+int detach_ktab(rsbwt *h);  // forgets a table it does not own
+}  // namespace rsb
 
 #endif

@@ -36,9 +36,10 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
 uint32_t trace_entries(const shard_view &ix, uint32_t k);
 constexpr int WORK_WORDS = 16;  // counters of a counting launch (search_lines.hip, WORK_*)
 
-// k-mer table: fills d_entries (4^T entries) by searching every T-mer.  `view` is the host copy of
-// the shard's view (no table yet), d_view a device copy the searches may use.
-hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, int num_cus, hipStream_t stream);
+// k-mer table: fills d_entries[c * stride], c < 4^T, by searching every T-mer.  `view` is the host copy
+// of the shard's view (no table yet).
+hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, uint32_t stride, int num_cus,
+                        hipStream_t stream);
 
 // class BWT mirrors, batched
 hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void *d_index, size_t n,

@@ -112,14 +112,14 @@ __global__ void ktab_codes_kernel(uint64_t base, size_t m, uint64_t *__restrict_
 }
 
 __global__ void ktab_encode_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper,
-                                   size_t m, uint64_t *__restrict__ entries) {
+                                   size_t m, uint64_t *__restrict__ entries, uint32_t stride) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) {
         const uint64_t lo = lower[i], up = upper[i];
         uint64_t width = up + 1ull - lo;  // 0 when empty: an empty result always has upper = lower - 1
         if (lo > up && up + 1ull != lo) width = KTAB_WIDE;  // never produced; stay safe
         if (width >= KTAB_WIDE) width = KTAB_WIDE;
-        entries[i] = (lo & COUNT_MASK) | (width << COUNT_BITS);
+        entries[i * stride] = (lo & COUNT_MASK) | (width << COUNT_BITS);
     }
 }
 
@@ -433,9 +433,10 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
     return hipGetLastError();
 }
 
-// Fills `d_entries` (4^T entries) by searching every T-mer, in slices that bound the temporary
-// memory.  `view` must not have a table yet.
-hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, int num_cus, hipStream_t stream) {
+// Fills `d_entries` (4^T entries, `stride` apart) by searching every T-mer, in slices that bound the
+// temporary memory.  `view` must not have a table yet.
+hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, uint32_t stride, int num_cus,
+                        hipStream_t stream) {
     const uint64_t total = 1ull << (2u * T);
     const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 24);
     uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr, *d_half = nullptr;
@@ -444,6 +445,7 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
     shard_view plain = view;
     plain.ktab = nullptr;
     plain.ktab_depth = 0;
+    plain.ktab_stride = 1;
     hipError_t e = hipSuccess;
     auto cleanup = [&] {
         if (d_pk) (void)hipFree(d_pk);
@@ -463,7 +465,7 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
     // the 4^T searches starts from its last T/2 symbols' entry and takes half the LF steps
     if (T >= 10u) {
         const uint32_t T0 = T / 2u;
-        if ((e = hipMalloc(&d_half, 8ull << (2u * T0))) == hipSuccess) e = build_ktable(view, T0, d_half, num_cus, stream);
+        if ((e = hipMalloc(&d_half, 8ull << (2u * T0))) == hipSuccess) e = build_ktable(view, T0, d_half, 1, num_cus, stream);
         if (e != hipSuccess) {
             cleanup();
             return e;
@@ -482,7 +484,8 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
         role.table_build = true;
         e = launch_search(d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream, nullptr, nullptr, &role);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m, d_entries + base);
+        hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m,
+                           d_entries + base * stride, stride);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);

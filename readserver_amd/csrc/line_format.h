@@ -42,7 +42,10 @@
 //
 // K-MER TABLE (8 B per T-mer, 4^T entries): the interval findInterval returns for every string of
 // T symbols over ACGT: bits 0..39 lower, bits 40..63 width = upper - lower + 1 (0 = empty, upper =
-// lower - 1; RSBWT_KTAB_WIDE = not tabulated).  Code of a T-mer = its 2-bit packing.
+// lower - 1; RSBWT_KTAB_WIDE = not tabulated).  Code of a T-mer = its 2-bit packing.  The tables of
+// the shards a set holds on one GPU are INTERLEAVED (entry of shard s for code c at [c * S + s]): a
+// query's start records for all S shards then come out of one 8S-byte stretch -- one request
+// instead of S random ones.
 //
 // Everything below is plain C++ usable on the host and in kernels: the layout logic (what the
 // builder writes, what a scalar reader finds) is one piece of code for both, so tests can hold it
@@ -93,6 +96,8 @@ struct shard_view {
     uint64_t first_far;     // = ngroups * 17
     span_params sp;
     uint32_t ktab_depth;    // T (0 = no table)
+    uint32_t ktab_stride;   // entries between consecutive T-mers: 1, or the number of shards whose tables are
+                            // interleaved (a shard set's shards on one GPU: entry(code) = ktab[code * stride])
     const uint64_t *ktab;
     uint64_t C[5];          // C[c] = # symbols with rank < c   (getPC)
     uint64_t total[5];      // occurrences of each symbol in the whole BWT

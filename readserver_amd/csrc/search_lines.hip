@@ -48,7 +48,7 @@ __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const u
         const uint32_t w0 = off >> 6, sh = off & 63u;
         uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
         if (sh + 2u * T > 64u) bits |= last << (64u - sh);
-        const uint64_t e = ix.ktab[bits & ((1ull << (2u * T)) - 1ull)];
+        const uint64_t e = ix.ktab[(bits & ((1ull << (2u * T)) - 1ull)) * ix.ktab_stride];
         const uint32_t width = (uint32_t)(e >> COUNT_BITS);
         if (width != KTAB_WIDE) {
             rec.x = e & COUNT_MASK;
@@ -63,14 +63,15 @@ __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const u
     return rec;
 }
 
-// one thread per (shard, query): init[s * Q + q]
+// one thread per (query, shard): init[s * Q + q].  Adjacent lanes = the shards of one query, so that
+// interleaved k-mer tables are read one stretch per query.
 __global__ void __launch_bounds__(256)
 search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
                    const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
                    ulonglong2 *__restrict__ init) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q * nshards) return;
-    const size_t s = i / Q, q = i - s * Q;
+    const size_t q = i / nshards, s = i - q * nshards;
     ulonglong2 rec;
     if (valid[q] == 0) {
         rec.x = INIT_INVALID;
@@ -78,7 +79,7 @@ search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
     } else {
         rec = start_record(shards[s], packed + q * wpq, k);
     }
-    init[i] = rec;
+    init[s * Q + q] = rec;
 }
 
 // Start records of the 3k+1 variants of m k-mers (1-mismatch search, variants_kernel's order).  A

@@ -88,6 +88,7 @@ struct dev_group : search_meter {
     int num_cus = 256;
     std::vector<size_t> idx;         // positions in the set, ascending
     shard_view *d_views = nullptr;   // [idx.size()] in HBM
+    uint64_t *d_ktab = nullptr;      // the interleaved k-mer tables of the shards this set gave one
     ctx_pool pool;
     ncclComm_t comm = nullptr;
 };
@@ -186,6 +187,11 @@ void rsbwt_set_close(rsbwt_set_t *s) {
         (void)hipSetDevice(g->device);
         g->pool.destroy();
         if (g->comm && rccl().ok) (void)rccl().CommDestroy(g->comm);
+        if (g->d_ktab) {  // shards that outlive the set lose the table that lived in it
+            for (size_t i : g->idx)
+                if (!s->owns && s->shards[i]) (void)detach_ktab(s->shards[i]);
+            (void)hipFree(g->d_ktab);
+        }
         if (g->d_views) (void)hipFree(g->d_views);
         if (g->d_work) (void)hipFree(g->d_work);
         for (int i = 0; i < search_meter::RING; ++i) {
@@ -267,15 +273,28 @@ uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {
     return T;
 }
 
-// Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.
+// Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.  The
+// tables of one device are interleaved in one allocation of the set (line_format.h): the start
+// records of a query for all shards come out of one stretch of 8 x shards bytes.
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     for (dev_group *g : s->groups) {
-        const uint32_t T = depth ? depth : auto_ktab_depth(s, g);
-        if (T < 2u) continue;
-        for (size_t i : g->idx) {
-            const int rc = rsbwt_attach_ktab(s->shards[i], T);
+        uint32_t T = depth ? depth : auto_ktab_depth(s, g);
+        if (T < 2u || g->d_ktab) continue;
+        if (T > 16u) T = 16;
+        std::vector<size_t> need;
+        for (size_t i : g->idx)
+            if (!s->shards[i]->view.ktab && s->shards[i]->view.n) need.push_back(i);
+        if (need.empty()) continue;
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        hipError_t e = hipMalloc(&g->d_ktab, (8ull << (2u * T)) * need.size());
+        if (e != hipSuccess) return fail_hip(e, "allocating the k-mer tables");
+        for (size_t j = 0; j < need.size(); ++j) {
+            rsbwt_t *h = s->shards[need[j]];
+            rc = attach_ktab_into(h, T, g->d_ktab + j, (uint32_t)need.size());
             if (rc) return rc;
+            h->ktab_owned = false;
         }
     }
     return publish_views(s);

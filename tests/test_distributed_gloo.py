@@ -90,7 +90,7 @@ def test_world2_gather_and_reduce(rsb, tmp_path):
     assert q.get() == "ok"
 
 
-def _pipeline_worker(rank, world, port, q):
+def _pipeline_worker(rank, world, port, q, interleaved=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -98,12 +98,15 @@ def _pipeline_worker(rank, world, port, q):
     try:
         from readserver_amd import sharded
         S, Q, steps = 2, 1000, 7
-        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2)
+        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2, interleaved=interleaved)
+        lo_of = (lambda t: t[..., 0]) if interleaved else (lambda t: t[0])  # {lower, upper} pairs / two arrays
+        up_of = (lambda t: t[..., 1]) if interleaved else (lambda t: t[1])
         seen = {}
         for i in range(steps):
             buf = g.acquire(i)  # waits for batch i - 2's gather before the buffer is rewritten
-            buf[0] = 1000 * i + 10 * rank + torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
-            buf[1] = buf[0] + 7
+            assert buf.shape == ((S, Q, 2) if interleaved else (2, S, Q))
+            lo_of(buf)[:] = 1000 * i + 10 * rank + torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
+            up_of(buf)[:] = lo_of(buf) + 7
             g.submit(i)
             if rank == 0 and i >= 1:
                 # batch i - 1 is complete once its handle has been waited for; acquire(i + 1) does
@@ -116,8 +119,8 @@ def _pipeline_worker(rank, world, port, q):
             base = torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
             for i in range(steps):
                 for r in range(world):
-                    assert torch.equal(seen[i][r][0], 1000 * i + 10 * r + base), (i, r)
-                    assert torch.equal(seen[i][r][1], 1000 * i + 10 * r + base + 7), (i, r)
+                    assert torch.equal(lo_of(seen[i][r]), 1000 * i + 10 * r + base), (i, r)
+                    assert torch.equal(up_of(seen[i][r]), 1000 * i + 10 * r + base + 7), (i, r)
             q.put("ok")
         else:
             assert g.result(0) is None
@@ -125,11 +128,15 @@ def _pipeline_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_pipelined_interval_gather():
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_world2_pipelined_interval_gather(interleaved):
+    """bench.py's N > 1 data path: searches write into one of two resident buffers while the other one's
+    gather to rank 0 is in flight ({lower, upper} pairs as rsbwt_set_find_interval_pairs_dev writes them,
+    or two arrays)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + 3) % 2000
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + 3 + int(interleaved)) % 2000
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, interleaved)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
