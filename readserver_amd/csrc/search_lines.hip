@@ -280,8 +280,14 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
             ulonglong2 rec = {0, 0};
             uint64_t first_word = 0;
             if (got_n) {
+#ifdef RSB_NT_RECORDS  // tuning knob: start records and packed words are read once
+                rec.x = __builtin_nontemporal_load(&init_s[nq].x);
+                rec.y = __builtin_nontemporal_load(&init_s[nq].y);
+                first_word = __builtin_nontemporal_load(&packed[nq * wpq + w_table]);
+#else
                 rec = init_s[nq];
                 first_word = packed[nq * wpq + w_table];
+#endif
             }
             const bool alive = has_q;
             const bool stepping = alive && !done;
@@ -474,7 +480,12 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                     if (COUNTS_ONLY) {
                         out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
                     } else if (pairs) {
+#ifdef RSB_NT_RESULTS  // tuning knob: results are written once and read by another kernel / the host
+                        __builtin_nontemporal_store(lo, &out_lo[2 * q]);
+                        __builtin_nontemporal_store(hi, &out_lo[2 * q + 1]);
+#else
                         reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
+#endif
                     } else {
                         out_lo[q] = lo;
                         out_up[q] = hi;

@@ -12,6 +12,14 @@
 
 namespace rsb {
 
+// Cache policy of the line fetch: nt (aux = 2).  A fetched line is parsed once and not asked for
+// again, and with the default policy the stream of random lines churns the vector L1 and the L2: same
+// box, same batch, 8 x 20 GB shards: 5.33-5.40 ms per launch with nt against 5.67-5.78 ms with the
+// default policy (4 shards; sc1 and sc0 variants in between; nt on the result stores is slower).
+#ifndef RSB_LINE_LOAD_AUX  // tuning knob (tools/build_variant.sh): 0 default, 1 sc0, 2 nt, 16 sc1
+#define RSB_LINE_LOAD_AUX 2
+#endif
+
 // LDS stage: 128 B per lane, 8 KB per wave, 32 KB per 4-wave workgroup, so 5 workgroups
 // (20 waves) would fit a CU's 160 KB; 4 are launched.
 constexpr int SLOT_U4 = 8;
@@ -46,7 +54,7 @@ __device__ __forceinline__ void glds_fetch(const char *lines, uint32_t want, uin
     for (int k = 0; k < 8; ++k) {
         if (tb[k] != ~0u) {
             const char *src = lines + (uint64_t)tb[k] * 128u + (((lane & 7u) ^ (uint32_t)k) << 4);
-            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(uintptr_t)(stage_lds + k * 1024u), 16, 0, RSB_LINE_LOAD_AUX);
         }
     }
 }
