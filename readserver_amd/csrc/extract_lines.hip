@@ -83,22 +83,36 @@ __device__ __forceinline__ uint32_t select24(const uint32_t r6[6], uint32_t b, u
     return pos;
 }
 
-// hands rows to the lanes that have none: one atomic per wave and pass in which any lane asks
-__device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, size_t n, uint32_t lane, size_t *row,
-                                         bool *drained) {
+// Hands rows to the lanes that have none.  A wave draws chunks of ROW_CHUNK consecutive rows from the
+// global counter (one atomic per chunk, not per pass: the atomic's round trip would otherwise sit in
+// front of every pass's line fetch) and gives the next one to whichever lane is free.
+constexpr uint32_t ROW_CHUNK = 256;
+struct row_pool {
+    uint64_t next = 0, end = 0;  // wave-uniform
+    bool drained = false;
+};
+__device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, size_t n, uint32_t lane, row_pool &rp,
+                                         size_t *row) {
     const uint64_t mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0ull || *drained) return false;
-    unsigned long long base = 0;
-    if (lane == 0u) base = atomicAdd(pool, (unsigned long long)__builtin_popcountll(mask));
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-           __builtin_amdgcn_readfirstlane((uint32_t)base);
-    if (base >= n) *drained = true;
-    const uint64_t mine = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    if (want && mine < n) {
-        *row = (size_t)mine;
-        return true;
+    if (mask == 0ull) return false;
+    if (rp.next >= rp.end && !rp.drained) {
+        unsigned long long c = 0;
+        if (lane == 0u) c = atomicAdd(pool, (unsigned long long)ROW_CHUNK);
+        c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+            __builtin_amdgcn_readfirstlane((uint32_t)c);
+        rp.next = c;
+        rp.end = c + ROW_CHUNK < n ? c + ROW_CHUNK : n;
+        if (c >= n) {
+            rp.drained = true;
+            rp.next = rp.end = 0;
+        }
     }
-    return false;
+    const uint64_t mine = rp.next + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    const bool got = want && mine < rp.end;
+    if (got) *row = (size_t)mine;
+    const uint64_t taken = rp.next + __builtin_popcountll(mask);
+    rp.next = taken < rp.end ? taken : rp.end;
+    return got;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -124,19 +138,25 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
         ctab_lo = (uint32_t)cv;
         ctab_hi = (uint32_t)(cv >> 32);
     }
-    bool have = false, drained = false;
+    bool have = false;
+    row_pool rp;
     size_t r = 0;
     uint64_t idx = 0, acc = 0;
     uint32_t len = 0, c = 0, phase = 0;  // phase 0: symbol at idx; 1: rank of symbol c at idx
     uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0, w = 0;
+    // characters are produced right to left: four at a time go out as one aligned dword when the row
+    // buffers allow it (a byte store per character is a request per character)
+    const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
+    uint32_t chars = 0;
     for (;;) {
         size_t nr = 0;
-        if (draw_row(!have, pool, n, lane, &nr, &drained)) {
+        if (draw_row(!have, pool, n, lane, rp, &nr)) {
             r = nr;
             idx = rows[r];
             len = 0;
             phase = 0;
             cont = 0;
+            chars = 0;
             have = true;
             if (idx >= ix.n) {
                 plen[r] = 0xFFFFFFFFu;
@@ -144,7 +164,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
             }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
-            if (drained) break;
+            if (rp.drained) break;
             continue;
         }
         // ---- this lane's line
@@ -204,6 +224,9 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
         }
         if (got_char) {
             if (c == 0u || c > 4u) {  // '$': the read starts here (query.cpp:52)
+                if (packed_out)  // the characters not yet written: the (len & 3) most recent ones
+                    for (uint32_t t = 0; t < (len & 3u); ++t)
+                        out[r * (size_t)stride + (stride - len + t)] = (uint8_t)(chars >> (8u * t));
                 plen[r] = len;
                 have = false;
             } else if (len == stride) {  // the reference would spin (query.cpp:48)
@@ -272,7 +295,17 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
         const uint64_t pc = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_hi) << 32) |
                             (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_lo);
         if (done) {
-            out[r * (size_t)stride + (stride - 1u - len)] = (uint8_t)(0x54474341u >> (8u * (c - 1u)));  // "ACGT"[c-1]
+            const uint32_t ch = (0x54474341u >> (8u * (c - 1u))) & 0xFFu;  // "ACGT"[c-1]
+            if (packed_out) {
+                chars = (chars << 8) | ch;  // most recent character in the low byte = lowest address
+                if ((len & 3u) == 3u) {
+                    // chars = [c(len-3) c(len-2) c(len-1) c(len)] high to low; memory order is the reverse of
+                    // production order: address stride-1-len holds c(len)
+                    *reinterpret_cast<uint32_t *>(out + r * (size_t)stride + (stride - 1u - len)) = chars;
+                }
+            } else {
+                out[r * (size_t)stride + (stride - 1u - len)] = (uint8_t)ch;
+            }
             ++len;
             idx = pc + occ - 1ull;  // C[b] + Occ(b, idx-1) of the reference = this row's LF target
             phase = 0;
@@ -299,7 +332,8 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
     const uint32_t S = ix.sp.S, nlines = (uint32_t)ix.nlines;
     const uint64_t C1 = ix.C[1], C2 = ix.C[2], C3 = ix.C[3], C4 = ix.C[4];
     const uint64_t T1 = ix.total[1], T2 = ix.total[2], T3 = ix.total[3], T4 = ix.total[4];
-    bool have = false, drained = false;
+    bool have = false;
+    row_pool rp;
     size_t r = 0;
     uint64_t idx = 0, bc = 0, posbase = 0;
     uint32_t len = 0, f = 0;
@@ -309,9 +343,13 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
     uint2 probe_word = {0, 0};
     uint32_t cont = 0, cblk = 0, cdw = 0;
     uint64_t t = 0;  // occurrences of f still to pass (select's running argument)
+    // characters go out four at a time as aligned dwords when the row buffers allow it; `word` holds the
+    // bytes of the dword being filled (low byte = lowest address), seeded with the prefix's last bytes
+    const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
+    uint32_t word = 0;
     for (;;) {
         size_t nr = 0;
-        if (draw_row(!have, pool, n, lane, &nr, &drained)) {
+        if (draw_row(!have, pool, n, lane, rp, &nr)) {
             r = nr;
             idx = rows[r];
             const uint32_t pl = plen[r];
@@ -321,13 +359,15 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 tlen[r] = 0xFFFFFFFFu;
                 have = false;
             } else {
-                uint8_t *buf = out + r * (size_t)stride;
-                for (uint32_t k = 0; k < pl; ++k) buf[k] = buf[stride - pl + k];  // prefix into place (src >= dst)
+                // (the prefix was moved to the head of the row's buffer by move_prefix_kernel)
+                const uint8_t *buf = out + r * (size_t)stride;
+                word = 0;
+                if (packed_out && (pl & 3u)) word = *reinterpret_cast<const uint32_t *>(buf + (pl & ~3u)) & ((1u << (8u * (pl & 3u))) - 1u);
                 len = pl;
             }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
-            if (drained) break;
+            if (rp.drained) break;
             continue;
         }
         // ---- phase 1 (second half): the probe issued in the last pass has landed
@@ -337,25 +377,7 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
             else wlo = probe;
             probe = 0;
         }
-        // ---- phase 0: getF (rlebwt.cpp:307-314) and the select samples around the bc-th f
-        if (have && phase == 0u) {
-            f = (idx >= C1 ? 1u : 0u) + (idx >= C2 ? 1u : 0u) + (idx >= C3 ? 1u : 0u) + (idx >= C4 ? 1u : 0u);
-            if (f == 0u) {  // '$': the read ends here (query.cpp:76)
-                tlen[r] = len;
-                have = false;
-            } else if (len == stride) {
-                tlen[r] = 0xFFFFFFFFu;
-                have = false;
-            } else {
-                const uint64_t cf = f == 1u ? C1 : f == 2u ? C2 : f == 3u ? C3 : C4;
-                const uint64_t tf = f == 1u ? T1 : f == 2u ? T2 : f == 3u ? T3 : T4;
-                bc = idx - cf + 1ull;
-                const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
-                samp_lo = sel[f * stride_m + m];
-                samp_hi = ((m + 1ull) << SEL_SHIFT) < tf ? sel[f * stride_m + m + 1ull] : (uint32_t)(ix.nwin - 1ull);
-                phase = 3;  // the samples are used from the next pass on (their loads fly with this pass's fetches)
-            }
-        } else if (have && phase == 3u) {
+        if (have && phase == 3u) {
             wlo = samp_lo;
             whi = samp_hi < samp_lo ? samp_lo : samp_hi;
             phase = 1;
@@ -436,7 +458,16 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                     tlen[r] = len;
                     have = false;
                 } else {
-                    out[r * (size_t)stride + len] = (uint8_t)(0x54474341u >> (8u * (f - 1u)));  // "ACGT"[f-1]
+                    const uint32_t ch = (0x54474341u >> (8u * (f - 1u))) & 0xFFu;  // "ACGT"[f-1]
+                    if (packed_out) {
+                        word |= ch << (8u * (len & 3u));
+                        if ((len & 3u) == 3u) {
+                            *reinterpret_cast<uint32_t *>(out + r * (size_t)stride + (len - 3u)) = word;
+                            word = 0;
+                        }
+                    } else {
+                        out[r * (size_t)stride + len] = (uint8_t)ch;
+                    }
                     ++len;
                     idx = pos;
                     phase = 0;
@@ -444,6 +475,50 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 }
             }
         }
+        // ---- phase 0 (rows that just arrived or just stepped): getF (rlebwt.cpp:307-314) and the select
+        // samples around the bc-th f; the sample loads fly with the next pass's fetches
+        if (have && phase == 0u) {
+            f = (idx >= C1 ? 1u : 0u) + (idx >= C2 ? 1u : 0u) + (idx >= C3 ? 1u : 0u) + (idx >= C4 ? 1u : 0u);
+            if (f == 0u) {  // '$': the read ends here (query.cpp:76)
+                if (packed_out)  // the bytes of the dword still being filled
+                    for (uint32_t k = len & ~3u; k < len; ++k) out[r * (size_t)stride + k] = (uint8_t)(word >> (8u * (k & 3u)));
+                tlen[r] = len;
+                have = false;
+            } else if (len == stride) {
+                tlen[r] = 0xFFFFFFFFu;
+                have = false;
+            } else {
+                const uint64_t cf = f == 1u ? C1 : f == 2u ? C2 : f == 3u ? C3 : C4;
+                const uint64_t tf = f == 1u ? T1 : f == 2u ? T2 : f == 3u ? T3 : T4;
+                bc = idx - cf + 1ull;
+                const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
+                samp_lo = sel[f * stride_m + m];
+                samp_hi = ((m + 1ull) << SEL_SHIFT) < tf ? sel[f * stride_m + m + 1ull] : (uint32_t)(ix.nwin - 1ull);
+                phase = 3;  // the samples are used from the next pass on
+            }
+        }
+    }
+}
+
+// The prefix, written right to left from the end of the row's buffer, moved to its head: one wave per
+// row, 64 bytes per step, low addresses first (source >= destination, so a step never overwrites a later
+// step's source, and within a step every lane has loaded before any lane stores).
+__global__ void __launch_bounds__(256)
+move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *__restrict__ plen, size_t n) {
+    const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (r >= n) return;
+    const uint32_t pl = plen[r];
+    if (pl == 0xFFFFFFFFu || pl == 0u || pl >= stride) return;
+    uint8_t *buf = out + r * (size_t)stride;
+    const uint32_t off = stride - pl;
+    for (uint32_t k0 = 0; k0 < pl; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        uint8_t ch = 0;
+        if (k < pl) ch = buf[off + k];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every lane's byte is in before any store of this step
+        __builtin_amdgcn_wave_barrier();
+        if (k < pl) buf[k] = ch;
     }
 }
 
@@ -463,6 +538,8 @@ hipError_t launch_extract_wave(const shard_view &ix, const uint32_t *d_sel, cons
     if (g > cap) g = cap;
     hipLaunchKernelGGL(extract_prefix_wave_kernel, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
                        (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool);
+    hipLaunchKernelGGL(move_prefix_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
+                       (const uint32_t *)d_plen, n);
     hipLaunchKernelGGL(extract_postfix_wave_kernel, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
                        select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
                        (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1);
