@@ -62,6 +62,10 @@ def parse():
                     help="N > 1 rehearsal where only one GPU exists: every rank uses GPU 0 and the collectives run over "
                          "gloo through host copies (RCCL refuses two ranks on one device).  Exercises this script's "
                          "multi-rank logic, not xGMI: its numbers mean nothing")
+    ap.add_argument("--verify-all-shards", action="store_true",
+                    help="after the timed region, hold EVERY resident shard's answers to the oracle on a sample of the "
+                         "batch (default: shard 0 only, inside cpu_baseline): regenerates each shard's run bytes, copies "
+                         "them to the host and builds the oracle's index over them, ~30 s per 20 GB shard")
     ap.add_argument("--no-single-check", action="store_true",
                     help="skip the single-shard (configs[1]) launches after the timed region: profile passes want "
                          "only the fused launches under the kernel's name")
@@ -350,6 +354,9 @@ def main():
         pair = gat.pair(step_no[0] - 1).to(dev)
         lo0, up0 = (pair[0][0], pair[1][0]) if a.separate_arrays else (pair[0, :, 0], pair[0, :, 1])
         out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, lo0, up0, Q, k)
+    if rank == 0 and a.verify_all_shards:
+        out["config"]["shards_matching_oracle"] = verify_shards(a, L, gat.pair(step_no[0] - 1).to(dev), d_kmers, S, R, Q, k, style,
+                                                              rank, local, dev, sp)
     if rank == 0:
         print(json.dumps(out), flush=True)
     sset.close()
@@ -373,6 +380,37 @@ def _pmc_traffic(R, Q, S, k, stream):
     except Exception:
         pass
     return None
+
+
+def verify_shards(a, L, pair, d_kmers, S, R, Q, k, style, rank, local, dev, sp):
+    """Every resident shard against the oracle: [true/false per shard] on 1e5 evenly spaced k-mers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_binding
+    import torch
+    orc = oracle_binding.load()
+    m = min(100000, Q)
+    sel_t = torch.from_numpy(np.linspace(0, Q - 1, m).astype(np.int64)).to(dev)
+    km = d_kmers[sel_t].cpu().numpy()
+    res = []
+    for s in range(S):
+        seed = style | (a.seed * 1000003 + (rank * S + (0 if a.same_shards else s)))
+        d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
+        assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, seed, local, sp) == 0
+        torch.cuda.synchronize()
+        runs = d_runs.cpu().numpy()
+        del d_runs
+        torch.cuda.empty_cache()
+        ix = orc.from_runs(runs)
+        lo, up = ix.find_intervals(km, nthreads=a.cpu_threads or usable_cpus())
+        if a.separate_arrays:
+            glo, gup = pair[0][s][sel_t], pair[1][s][sel_t]
+        else:
+            glo, gup = pair[s, :, 0][sel_t], pair[s, :, 1][sel_t]
+        res.append(bool(np.array_equal(lo, glo.cpu().numpy().view(np.uint64)) and
+                        np.array_equal(up, gup.cpu().numpy().view(np.uint64))))
+        del ix, runs
+    return res
 
 
 def cpu_baseline(a, host_runs, d_kmers, d_lower, d_upper, Q, k):

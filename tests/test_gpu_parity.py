@@ -886,3 +886,44 @@ def test_gpu_reference_query_cpp_runs_on_the_shim(rsb, oracle, fixture_bwt, gold
         assert int(f[3]) == len(want) and f[4:] == want
     for j, i in enumerate((0, 1, 2, 3)):
         assert int(lines[6 + j].split()[2]) == int(gq["em_ans70"][i])
+
+
+def test_gpu_set_interleaved_tables_and_detach(rsb, oracle):
+    """rsbwt_set_attach_ktabs gives the shards of a device ONE interleaved k-mer table (entry of shard s
+    for T-mer c at [c * S + s]); searches through the set and through each handle use it; when the set
+    goes while the handles live on, they lose the table that lived in the set and still answer right."""
+    import ctypes as C
+    L = rsb.lib()
+    shards, oixs = [], []
+    for i, R in enumerate([150000, 400000, 90000]):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 700 + i) == 0
+        oixs.append(oracle.from_runs(runs))
+        shards.append(rsb.GpuBWT(runs=runs, ktab_depth=None))
+    ss = rsb.ShardSet(shards)
+    T = L.rsbwt_set_auto_ktab_depth(ss._s)
+    assert 2 <= T <= 16
+    base = [g.hbm_bytes() for g in shards]
+    assert L.rsbwt_set_attach_ktabs(ss._s, 7) == 0
+    assert [g.ktab_depth() for g in shards] == [7, 7, 7]
+    assert [g.hbm_bytes() - b for g, b in zip(shards, base)] == [8 * 4 ** 7] * 3
+    rng = np.random.default_rng(12)
+    for k in (5, 7, 8, 31, 40):
+        km = _random_kmers(rng, 6000, k)
+        km[::7] = ord("C")
+        lo, up = ss.find_intervals(km)
+        for s, oix in enumerate(oixs):
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup), (k, s)
+            hlo, hup = rsb.find_intervals(shards[s], km)  # the handle alone, through its stride-3 table
+            assert np.array_equal(hlo, elo) and np.array_equal(hup, eup), (k, s)
+    lo1, up1 = rsb.find_intervals_1mm(shards[1], km[:100])  # traced / resumed searches on a strided table
+    ss.close()
+    assert [g.ktab_depth() for g in shards] == [0, 0, 0] and [g.hbm_bytes() for g in shards] == base
+    lo, up = rsb.find_intervals(shards[1], km)
+    elo, eup = oixs[1].find_intervals(km, nthreads=8)
+    assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+    lo2, up2 = rsb.find_intervals_1mm(shards[1], km[:100])
+    assert np.array_equal(lo1, lo2) and np.array_equal(up1, up2)
+    for g in shards:
+        g.close()
