@@ -409,6 +409,7 @@ def verify_shards(a, L, pair, d_kmers, S, R, Q, k, style, rank, local, dev, sp):
             glo, gup = pair[s, :, 0][sel_t], pair[s, :, 1][sel_t]
         res.append(bool(np.array_equal(lo, glo.cpu().numpy().view(np.uint64)) and
                         np.array_equal(up, gup.cpu().numpy().view(np.uint64))))
+        print(f"bench.py: shard {s} {'matches' if res[-1] else 'DIFFERS FROM'} the oracle on {m} k-mers", file=sys.stderr, flush=True)
         del ix, runs
     return res
 

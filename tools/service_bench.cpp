@@ -1,0 +1,96 @@
+// service_bench.cpp -- throughput of the f1 service loop (csrc/service_loop.cpp) end to end inside one
+// process: a producer thread pushes serialised CountReads Requests into the in-process transport, the
+// loop batches them (window / max batch), searches all shards of the set on the GPU and sends 2 x P
+// Replies per request, a consumer thread pops them.  What a ZeroMQ deployment adds is the sockets.
+//   tools/bin/service_bench [requests=200000] [shards=1] [run_bytes=2e8] [window_us=200] [max_batch=4096]
+// build: g++ -O2 -std=c++17 -Iinclude tools/service_bench.cpp -Lreadserver_amd/lib -lrsbwt -lpthread
+//            -Wl,-rpath,'$ORIGIN/../../readserver_amd/lib' -Wl,-rpath,/opt/rocm/lib -o tools/bin/service_bench
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rsbwt.h"
+
+static uint64_t mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv) {
+    const size_t N = argc > 1 ? (size_t)atof(argv[1]) : 200000;
+    const size_t P = argc > 2 ? (size_t)atoi(argv[2]) : 1;
+    const uint64_t R = argc > 3 ? (uint64_t)atof(argv[3]) : 200000000ull;
+    const int64_t window = argc > 4 ? atoll(argv[4]) : 200;
+    const size_t max_batch = argc > 5 ? (size_t)atoll(argv[5]) : 4096;
+    const uint32_t k = 31;
+    std::vector<rsbwt_t *> shards;
+    {
+        std::vector<uint8_t> runs(R);
+        for (size_t s = 0; s < P; ++s) {
+            rsbwt_synth_runs_host(runs.data(), R, 4242 + s);
+            rsbwt_t *h = nullptr;
+            if (rsbwt_open_runs(runs.data(), R, 0, 0, 0, &h) != RSBWT_OK) {
+                fprintf(stderr, "%s\n", rsbwt_last_error());
+                return 1;
+            }
+            shards.push_back(h);
+        }
+    }
+    rsbwt_set_t *set = nullptr;
+    rsbwt_transport_t *tr = nullptr;
+    rsbwt_service_t *svc = nullptr;
+    if (rsbwt_set_from_handles(shards.data(), P, &set) || rsbwt_transport_inproc(&tr) ||
+        rsbwt_service_create(set, tr, window, max_batch, 1, &svc) || rsbwt_service_start(svc)) {
+        fprintf(stderr, "%s\n", rsbwt_last_error());
+        return 1;
+    }
+    // Request{t = CountReads, rt = Count, q = 31-mer}: 08 01 10 01 1A 1F <31 bytes>
+    std::vector<std::string> msgs(N);
+    for (size_t i = 0; i < N; ++i) {
+        std::string m("\x08\x01\x10\x01\x1A\x1F", 6);
+        uint64_t h = mix(i);
+        for (uint32_t j = 0; j < k; ++j) {
+            if ((j & 31) == 31) h = mix(h);
+            m.push_back("ACGT"[(h >> (2 * (j & 31))) & 3]);
+        }
+        msgs[i] = m;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::thread producer([&] {
+        for (size_t i = 0; i < N; ++i) rsbwt_transport_push_request(tr, (const uint8_t *)msgs[i].data(), msgs[i].size());
+    });
+    size_t got = 0, bytes = 0;
+    std::thread consumer([&] {
+        uint8_t buf[512];
+        size_t n = 0;
+        while (got < 2 * P * N) {
+            if (rsbwt_transport_pop_reply(tr, 1, buf, sizeof buf, &n, 30000000) != RSBWT_OK) break;
+            ++got;
+            bytes += n;
+        }
+    });
+    producer.join();
+    consumer.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    rsbwt_transport_close(tr);
+    rsbwt_service_stop(svc);
+    uint64_t st[6];
+    rsbwt_service_stats(svc, st);
+    printf("{\"requests\": %zu, \"partitions\": %zu, \"replies\": %zu, \"reply_bytes\": %zu, \"seconds\": %.4f, "
+           "\"requests_per_s\": %.1f, \"searches_per_s\": %.1f, \"windows\": %llu, \"mean_requests_per_window\": %.1f, "
+           "\"largest_window\": %llu, \"window_us\": %lld, \"max_batch\": %zu, \"run_bytes_per_shard\": %llu}\n",
+           N, P, got, bytes, dt, N / dt, 2.0 * P * N / dt, (unsigned long long)st[2], (double)st[0] / (double)(st[2] ? st[2] : 1),
+           (unsigned long long)st[5], (long long)window, max_batch, (unsigned long long)R);
+    rsbwt_service_free(svc);
+    rsbwt_transport_free(tr);
+    rsbwt_set_close(set);
+    for (rsbwt_t *h : shards) rsbwt_close(h);
+    return got == 2 * P * N ? 0 : 2;
+}
