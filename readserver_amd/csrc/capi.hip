@@ -125,8 +125,25 @@ int call_ctx::stage(size_t bytes) {
 
 namespace {
 
+#ifdef RSB_TIME_HIP_CALLS  // diagnostic build: names any runtime call that takes longer than 20 ms
+#include <chrono>
+struct slow_call_timer {
+    const char *what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit slow_call_timer(const char *w) : what(w) {}
+    ~slow_call_timer() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 20.0) fprintf(stderr, "rsbwt: %.1f ms in %s\n", ms, what);
+    }
+};
+#define RSB_TIMED(x) slow_call_timer _timer(#x)
+#else
+#define RSB_TIMED(x) (void)0
+#endif
+
 #define HIP_OK(x)                                              \
     do {                                                       \
+        RSB_TIMED(x);                                          \
         hipError_t _e = (x);                                   \
         if (_e != hipSuccess) return fail_hip(_e, #x);         \
     } while (0)
@@ -391,6 +408,7 @@ void rsbwt_close(rsbwt_t *h) {
     if (h->d_view) (void)hipFree(h->d_view);
     if (h->d_sel) (void)hipFree(h->d_sel);
     if (h->d_work) (void)hipFree(h->d_work);
+    h->scratch.destroy();
     for (int i = 0; i < rsbwt::RING; ++i) {
         if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
         if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
@@ -652,7 +670,7 @@ int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, 
         HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), stream));
     }
     const int slot = (int)(m.launches % search_meter::RING);
-    hipError_t e = launch_search(d_views, nshards, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, num_cus,
+    hipError_t e = launch_search(m.scratch, d_views, nshards, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, work, num_cus,
                                  stream, m.ev_start[slot], m.ev_stop[slot], extra);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -700,6 +718,12 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
         hipStream_t st = nullptr;
     } prev;
     auto collect = [&](const slice_t &sl) -> int {  // results of a slice whose search is under way
+        if (sl.m == Q) {  // the only slice: [nshards][Q] in HBM is the caller's layout, one copy per array
+            HIP_OK(hipMemcpyAsync(lower, sl.d_lo, (size_t)nshards * Q * 8, hipMemcpyDeviceToHost, sl.st));
+            if (!counts_only) HIP_OK(hipMemcpyAsync(upper, sl.d_up, (size_t)nshards * Q * 8, hipMemcpyDeviceToHost, sl.st));
+            HIP_OK(hipStreamSynchronize(sl.st));
+            return RSBWT_OK;
+        }
         for (uint32_t s = 0; s < nshards; ++s) {
             HIP_OK(hipMemcpyAsync(lower + s * Q + sl.q0, sl.d_lo + (size_t)s * sl.m * 8, sl.m * 8, hipMemcpyDeviceToHost, sl.st));
             if (!counts_only)
@@ -720,9 +744,15 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
         cur.d_up = cur.d_lo + a_res;
         const size_t ascii_bytes = (cur.m - 1) * stride + k;  // the last k-mer needs only k bytes
         HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, cur.st));
-        hipError_t e = launch_pack(d_ascii, cur.m, k, stride, d_packed, d_valid, cur.st);
-        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
-        rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st, nullptr);
+        {
+            RSB_TIMED(launch_pack);
+            hipError_t e = launch_pack(d_ascii, cur.m, k, stride, d_packed, d_valid, cur.st);
+            if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+        }
+        {
+            RSB_TIMED(search_launch);
+            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st, nullptr);
+        }
         if (rc) return rc;
         if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
         prev = cur;
@@ -958,7 +988,7 @@ static int extract_slices(rsbwt_t *h, call_ctx *c, const uint64_t *rows, size_t 
         uint8_t *base = (uint8_t *)c->d_stage;
         uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
         HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_extract_wave(h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
+        hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
         if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
         if ((rc = fn(i0, m, d_out, d_len, d_pl, d_len + a_len)) != RSBWT_OK) return rc;
     }
@@ -1000,7 +1030,7 @@ int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uin
     int rc = use_device(h->device);
     if (rc) return rc;
     if ((rc = ensure_select_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
-    hipError_t e = launch_extract_wave(h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus, (hipStream_t)stream);
+    hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;
 }

@@ -47,6 +47,7 @@ struct search_meter {
     uint64_t launches = 0;  // search launches so far; launch i uses pair i % RING
     bool counting = false;
     unsigned long long *d_work = nullptr;  // WORK_WORDS counters (search_lines.hip)
+    scratch_cache scratch;                 // start records / row counters of the launches in flight
     std::mutex mu;
 };
 

@@ -522,15 +522,17 @@ move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *_
     }
 }
 
-hipError_t launch_extract_wave(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n, void *d_out,
-                               uint32_t stride, void *d_plen, void *d_len, int num_cus, hipStream_t stream) {
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
+                               size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
+                               hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    unsigned long long *pool = nullptr;
-    hipError_t e = hipMallocAsync((void **)&pool, 2 * sizeof(unsigned long long), stream);
+    scratch_cache::lease mem;
+    hipError_t e = scratch.take(2 * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
+    unsigned long long *pool = (unsigned long long *)mem.p;
     e = hipMemsetAsync(pool, 0, 2 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(pool, stream);
+        scratch.give(mem, stream);
         return e;
     }
     size_t g = (n + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
@@ -544,8 +546,8 @@ hipError_t launch_extract_wave(const shard_view &ix, const uint32_t *d_sel, cons
                        select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
                        (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1);
     e = hipGetLastError();
-    const hipError_t e2 = hipFreeAsync(pool, stream);
-    return e != hipSuccess ? e : e2;
+    scratch.give(mem, stream);
+    return e;
 }
 
 }  // namespace rsb

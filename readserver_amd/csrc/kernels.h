@@ -7,9 +7,41 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "line_format.h"
 
 namespace rsb {
+
+// Scratch in HBM for the duration of one launch sequence on a stream (the search's start records,
+// a walk's row counters).  A few buffers are kept and handed out again: to the stream that used one
+// last (stream order makes that safe at once), or to any stream once the event recorded at the last
+// give() has completed.  Nothing here calls the runtime's stream-ordered allocator: on this stack a
+// hipMallocAsync / hipFreeAsync pair per call stalls for seconds once in a few thousand calls
+// (profiles/r02d_latency.md).
+class scratch_cache {
+  public:
+    struct lease {
+        void *p = nullptr;
+        int slot = -1;
+    };
+    hipError_t take(size_t bytes, hipStream_t stream, lease *out);
+    void give(const lease &l, hipStream_t stream);  // after the last launch that uses l.p was enqueued
+    void destroy();                                 // with no launch in flight
+    size_t held_bytes();
+
+  private:
+    static constexpr int SLOTS = 16;
+    struct slot_t {
+        void *p = nullptr;
+        size_t bytes = 0;
+        hipStream_t last = nullptr;
+        hipEvent_t done = nullptr;
+        bool recorded = false, busy = false;
+    };
+    slot_t slots_[SLOTS];
+    std::mutex mu_;
+};
 
 hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride, void *d_packed,
                        void *d_valid, hipStream_t stream);
@@ -29,8 +61,8 @@ struct search_extra {
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
     bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
 };
-hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
-                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                         const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr, const search_extra *extra = nullptr);
 uint32_t trace_entries(const shard_view &ix, uint32_t k);
@@ -60,8 +92,9 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
 uint64_t select_sample_stride(const shard_view &ix);
 hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream);
 // extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
-hipError_t launch_extract_wave(const shard_view &ix, const uint32_t *d_sel, const void *d_rows, size_t n, void *d_out,
-                               uint32_t stride, void *d_plen, void *d_len, int num_cus, hipStream_t stream);
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
+                               size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
+                               hipStream_t stream);
 constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences: the window search spans a few windows
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,

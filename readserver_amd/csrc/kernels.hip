@@ -433,6 +433,89 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
     return hipGetLastError();
 }
 
+// ---- scratch_cache (kernels.h) ------------------------------------------------------------------------
+hipError_t scratch_cache::take(size_t bytes, hipStream_t stream, lease *out) {
+    // sizes step by an eighth of a power of two: batches of varying size settle on a few buffers
+    size_t unit = 4096;
+    while (unit * 8 < bytes) unit <<= 1;
+    const size_t want = (bytes + unit - 1) / unit * unit;
+    std::lock_guard<std::mutex> lock(mu_);
+    auto idle = [&](slot_t &s) {  // no launch uses it any more, as far as `stream` can tell
+        if (s.busy) return false;
+        if (!s.recorded || s.last == stream) return true;
+        return hipEventQuery(s.done) == hipSuccess;
+    };
+    int pick = -1, grow = -1, fresh = -1, wait = -1;
+    for (int i = 0; i < SLOTS; ++i) {
+        slot_t &s = slots_[i];
+        if (!s.p) { if (fresh < 0 && !s.busy) fresh = i; continue; }
+        if (s.busy) continue;
+        if (idle(s)) {
+            if (s.bytes >= want) { if (pick < 0 || s.bytes < slots_[pick].bytes) pick = i; }
+            else if (grow < 0) grow = i;
+        } else if (s.bytes >= want && wait < 0) {
+            wait = i;
+        }
+    }
+    if (pick < 0 && fresh >= 0) {
+        slot_t &s = slots_[fresh];
+        hipError_t e = hipSuccess;
+        if (!s.done) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&s.p, want);
+        if (e != hipSuccess) { s.p = nullptr; return e; }
+        s.bytes = want;
+        s.recorded = false;
+        pick = fresh;
+    }
+    if (pick < 0 && grow >= 0) {  // an idle buffer that is too small is replaced
+        slot_t &s = slots_[grow];
+        (void)hipFree(s.p);
+        s.p = nullptr;
+        s.bytes = 0;
+        const hipError_t e = hipMalloc(&s.p, want);
+        if (e != hipSuccess) { s.p = nullptr; return e; }
+        s.bytes = want;
+        s.recorded = false;
+        pick = grow;
+    }
+    if (pick < 0 && wait >= 0) {  // every buffer is in some stream's queue: line up behind one
+        const hipError_t e = hipStreamWaitEvent(stream, slots_[wait].done, 0);
+        if (e != hipSuccess) return e;
+        pick = wait;
+    }
+    if (pick < 0) return hipErrorOutOfMemory;  // 16 launch sequences being enqueued at once, none fitting
+    slots_[pick].busy = true;
+    out->p = slots_[pick].p;
+    out->slot = pick;
+    return hipSuccess;
+}
+
+void scratch_cache::give(const lease &l, hipStream_t stream) {
+    if (l.slot < 0) return;
+    std::lock_guard<std::mutex> lock(mu_);
+    slot_t &s = slots_[l.slot];
+    s.recorded = hipEventRecord(s.done, stream) == hipSuccess;
+    if (!s.recorded) (void)hipStreamSynchronize(stream);  // no event: the buffer is idle only once the stream is
+    s.last = stream;
+    s.busy = false;
+}
+
+void scratch_cache::destroy() {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (slot_t &s : slots_) {
+        if (s.p) (void)hipFree(s.p);
+        if (s.done) (void)hipEventDestroy(s.done);
+        s = slot_t();
+    }
+}
+
+size_t scratch_cache::held_bytes() {
+    std::lock_guard<std::mutex> lock(mu_);
+    size_t b = 0;
+    for (slot_t &s : slots_) b += s.bytes;
+    return b;
+}
+
 // Fills `d_entries` (4^T entries, `stride` apart) by searching every T-mer, in slices that bound the
 // temporary memory.  `view` must not have a table yet.
 hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, uint32_t stride, int num_cus,
@@ -447,7 +530,9 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
     plain.ktab_depth = 0;
     plain.ktab_stride = 1;
     hipError_t e = hipSuccess;
+    scratch_cache scratch;
     auto cleanup = [&] {
+        scratch.destroy();
         if (d_pk) (void)hipFree(d_pk);
         if (d_lo) (void)hipFree(d_lo);
         if (d_up) (void)hipFree(d_up);
@@ -482,7 +567,7 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
         hipLaunchKernelGGL(ktab_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base, m, d_pk, d_ok);
         search_extra role;
         role.table_build = true;
-        e = launch_search(d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream, nullptr, nullptr, &role);
+        e = launch_search(scratch, d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream, nullptr, nullptr, &role);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m,
                            d_entries + base * stride, stride);

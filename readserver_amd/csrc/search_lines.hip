@@ -530,8 +530,8 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
                            pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
 }
 
-hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
-                         size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
+hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                         const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                          const search_extra *extra) {
     if (Q == 0 || nshards == 0) return hipSuccess;
@@ -559,16 +559,17 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
     const uint64_t *pk = (const uint64_t *)d_packed;
     const uint8_t *vd = (const uint8_t *)d_valid;
     uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
-    // start records of this batch + the shards' query counters: stream-ordered scratch, so
-    // concurrent calls do not share state
+    // start records of this batch + the shards' query counters: scratch of this launch sequence
+    // alone, so concurrent calls do not share state
     const size_t nrec = Q * nshards;
-    ulonglong2 *init = nullptr;
-    hipError_t e = hipMallocAsync((void **)&init, nrec * sizeof(ulonglong2) + nshards * sizeof(unsigned long long), stream);
+    scratch_cache::lease mem;
+    hipError_t e = scratch.take(nrec * sizeof(ulonglong2) + nshards * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
+    ulonglong2 *init = (ulonglong2 *)mem.p;
     unsigned long long *ctr = (unsigned long long *)(init + nrec);
     e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(init, stream);
+        scratch.give(mem, stream);
         return e;
     }
     const unsigned ig = (unsigned)((nrec + 255) / 256);
@@ -592,8 +593,8 @@ hipError_t launch_search(const shard_view *d_shards, uint32_t nshards, const voi
     }
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);
-    const hipError_t e2 = hipFreeAsync(init, stream);
-    return e != hipSuccess ? e : e2;
+    scratch.give(mem, stream);
+    return e;
 }
 
 // Entries per k-mer of a traced search = the positions left of the k-mer table's reach (0: the

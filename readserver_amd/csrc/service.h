@@ -22,10 +22,18 @@ struct service_request {
 };
 
 bool service_decode(const uint8_t *msg, size_t len, service_request *out);
-// replies[i] = the Reply messages of request i in sending order (forward, reverse complement; per
-// shard first when per_partition); handled[i] = 0: not a count request, left to the caller
+
+// The serialised Reply messages of one batch, back to back: message j is bytes[off[j] .. off[j+1]);
+// request i's messages are first[i] .. first[i+1], in sending order (forward, reverse complement; per
+// shard first when per_partition).
+struct reply_arena {
+    std::vector<uint8_t> bytes;
+    std::vector<size_t> off, first;
+    size_t messages() const { return off.empty() ? 0 : off.size() - 1; }
+};
+// handled[i] = 0: not a count request, left to the caller (no messages)
 int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition,
-                        std::vector<std::vector<std::vector<uint8_t>>> *replies, std::vector<char> *handled);
+                        reply_arena *replies, std::vector<char> *handled);
 
 // What the loop needs of ZeroMQ: the SUB socket it receives Requests on (service.cpp:1495-1497) and
 // the two PUSH sockets it answers on (push for ExactMatch, push_count for CountReads: :1499-1502,1568).
@@ -39,6 +47,10 @@ class transport {
     virtual bool closing() = 0;  // close was asked for: what is queued is still answered
     enum channel { PUSH = 0, PUSH_COUNT = 1 };
     virtual void send(channel c, const uint8_t *data, size_t n) = 0;
+    // messages [off[0], off[1]), ..., [off[count-1], off[count]) of `base`, in order
+    virtual void send_many(channel c, const uint8_t *base, const size_t *off, size_t count) {
+        for (size_t j = 0; j < count; ++j) send(c, base + off[j], off[j + 1] - off[j]);
+    }
 };
 
 }  // namespace rsb

@@ -165,8 +165,15 @@ class inproc_transport : public transport {
     }
     void send(channel c, const uint8_t *data, size_t n) override {
         {
-            std::lock_guard<std::mutex> lock(mu_);
+            std::lock_guard<std::mutex> lock(mu_out_);
             out_[c].emplace_back(data, data + n);
+        }
+        cv_out_.notify_all();
+    }
+    void send_many(channel c, const uint8_t *base, const size_t *off, size_t count) override {
+        {
+            std::lock_guard<std::mutex> lock(mu_out_);
+            for (size_t j = 0; j < count; ++j) out_[c].emplace_back(base + off[j], base + off[j + 1]);
         }
         cv_out_.notify_all();
     }
@@ -178,7 +185,7 @@ class inproc_transport : public transport {
         cv_.notify_all();
     }
     bool pop_reply(int c, std::vector<uint8_t> *msg, int64_t timeout_us) {
-        std::unique_lock<std::mutex> lock(mu_);
+        std::unique_lock<std::mutex> lock(mu_out_);
         if (!cv_out_.wait_for(lock, std::chrono::microseconds(timeout_us), [&] { return !out_[c].empty(); })) return false;
         *msg = std::move(out_[c].front());
         out_[c].pop_front();
@@ -193,7 +200,7 @@ class inproc_transport : public transport {
     }
 
   private:
-    std::mutex mu_;
+    std::mutex mu_, mu_out_;  // requests in / replies out
     std::condition_variable cv_, cv_out_;
     std::deque<std::vector<uint8_t>> in_, out_[2];
     bool closed_ = false;
@@ -288,7 +295,7 @@ struct rsbwt_service {
             parsed[i] = service_decode(msgs[i].data(), msgs[i].size(), &rq[i]) ? 1 : 0;
             if (!parsed[i]) { rq[i].t = 0; malformed++; }
         }
-        std::vector<std::vector<std::vector<uint8_t>>> rep;
+        reply_arena rep;
         std::vector<char> handled;
         const int rc = service_count_batch(set, rq, per_partition, &rep, &handled);
         if (rc != RSBWT_OK) {
@@ -317,19 +324,28 @@ struct rsbwt_service {
                     }
             }
         } else {
+            // in arrival order; consecutive messages for the same socket go out in one call.
+            // CountReads answers on push_count, ExactMatch-Count on push (service.cpp:1549-1554,1567-1570)
+            size_t run0 = 0, run1 = 0;
+            transport::channel run_ch = transport::PUSH_COUNT;
+            auto flush = [&] {
+                if (run1 > run0) tr->send_many(run_ch, rep.bytes.data(), rep.off.data() + run0, run1 - run0);
+                replies += run1 - run0;
+                run0 = run1;
+            };
             for (size_t i = 0; i < n; ++i) {
                 if (handled[i]) {
                     count_requests++;
-                    // CountReads answers on push_count, ExactMatch-Count on push (service.cpp:1549-1554,1567-1570)
                     const transport::channel ch = rq[i].t == 1 ? transport::PUSH_COUNT : transport::PUSH;
-                    for (const std::vector<uint8_t> &o : rep[i]) {
-                        tr->send(ch, o.data(), o.size());
-                        replies++;
-                    }
+                    if (ch != run_ch) { flush(); run_ch = ch; }
+                    run0 = run1 > run0 ? run0 : rep.first[i];
+                    run1 = rep.first[i + 1];
                 } else if (parsed[i] && other) {
+                    flush();
                     other(other_arg, msgs[i].data(), msgs[i].size());  // KmerMatch, SiteMatch, ExactMatch with reads: the caller's
                 }
             }
+            flush();
         }
         requests += n;
         batches++;

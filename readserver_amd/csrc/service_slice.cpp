@@ -67,25 +67,37 @@ bool decode_request(const uint8_t *p, size_t n, request_view &r) {
     return r.has_t && r.has_rt && r.has_q;  // all three are `required`
 }
 
-void put_varint(std::vector<uint8_t> &o, uint64_t v) {
-    while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; }
-    o.push_back((uint8_t)v);
+inline size_t varint_len(uint64_t v) {
+    size_t n = 1;
+    while (v >= 0x80) { v >>= 7; ++n; }
+    return n;
+}
+
+inline uint8_t *put_varint(uint8_t *p, uint64_t v) {
+    while (v >= 0x80) { *p++ = (uint8_t)(v | 0x80); v >>= 7; }
+    *p++ = (uint8_t)v;
+    return p;
 }
 
 // Reply{rt, t = ReplyCount, q, c = ReplyCount{forward_matches | revcomp_matches = ResultCount{c}}}
-void encode_count_reply(std::vector<uint8_t> &o, int request_type, const char *q, size_t qlen, bool revcomp,
-                        int32_t c) {
-    std::vector<uint8_t> rc;  // ResultCount
-    rc.push_back(0x08);
-    put_varint(rc, (uint64_t)(int64_t)c);  // int32: negative values are sign-extended to 10 bytes
-    std::vector<uint8_t> rcount;  // ReplyCount
-    rcount.push_back(revcomp ? 0x12 : 0x0A);
-    put_varint(rcount, rc.size());
-    rcount.insert(rcount.end(), rc.begin(), rc.end());
-    o.push_back(0x08); put_varint(o, (uint64_t)request_type);  // rt
-    o.push_back(0x10); put_varint(o, 1);                        // t = ReplyCount
-    o.push_back(0x1A); put_varint(o, qlen); o.insert(o.end(), q, q + qlen);
-    o.push_back(0x22); put_varint(o, rcount.size()); o.insert(o.end(), rcount.begin(), rcount.end());
+size_t count_reply_len(int request_type, size_t qlen, int32_t c) {
+    const size_t result_count = 1 + varint_len((uint64_t)(int64_t)c);  // int32: negative values are sign-extended to 10 bytes
+    const size_t reply_count = 1 + varint_len(result_count) + result_count;
+    return 1 + varint_len((uint64_t)request_type) + 2 + 1 + varint_len(qlen) + qlen + 1 + varint_len(reply_count) + reply_count;
+}
+
+uint8_t *encode_count_reply(uint8_t *p, int request_type, const char *q, size_t qlen, bool revcomp, int32_t c) {
+    const size_t result_count = 1 + varint_len((uint64_t)(int64_t)c);
+    const size_t reply_count = 1 + varint_len(result_count) + result_count;
+    *p++ = 0x08; p = put_varint(p, (uint64_t)request_type);  // rt
+    *p++ = 0x10; *p++ = 1;                                    // t = ReplyCount
+    *p++ = 0x1A; p = put_varint(p, qlen);
+    if (qlen) memcpy(p, q, qlen);
+    p += qlen;
+    *p++ = 0x22; p = put_varint(p, reply_count);
+    *p++ = revcomp ? 0x12 : 0x0A; p = put_varint(p, result_count);
+    *p++ = 0x08; p = put_varint(p, (uint64_t)(int64_t)c);
+    return p;
 }
 
 std::string rev_comp(const char *q, size_t n) {  // service.cpp:251-276
@@ -113,10 +125,10 @@ int rsbwt_proto_decode_request(const uint8_t *msg, size_t len, int *t, int *rt, 
 
 size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen,
                                       int revcomp, int32_t c) {
-    std::vector<uint8_t> o;
-    encode_count_reply(o, request_type, q, qlen, revcomp != 0, c);
-    if (out && o.size() <= cap) memcpy(out, o.data(), o.size());
-    return o.size();
+    if (!q && qlen) return 0;
+    const size_t len = count_reply_len(request_type, qlen, c);
+    if (out && len <= cap) encode_count_reply(out, request_type, q, qlen, revcomp != 0, c);
+    return len;
 }
 
 }  // extern "C"
@@ -132,11 +144,13 @@ namespace rsb {
 // request with the counts summed over the shards first (set the front-end's `workers` to 2): the
 // narrowing then applies to the sum, which differs from the above only beyond 2^31 matches.
 int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition,
-                        std::vector<std::vector<std::vector<uint8_t>>> *replies, std::vector<char> *handled) {
+                        reply_arena *replies, std::vector<char> *handled) {
     const size_t n = rq.size();
     const size_t S = rsbwt_set_size(set);
     handled->assign(n, 0);
-    replies->assign(n, {});
+    replies->bytes.clear();
+    replies->off.assign(1, 0);
+    replies->first.assign(n + 1, 0);
     std::map<size_t, std::vector<size_t>> by_len;  // one batched search per query length
     for (size_t i = 0; i < n; ++i) {
         const bool count_reads = rq[i].t == 1;                   // Request::CountReads
@@ -178,17 +192,28 @@ int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
             for (size_t j = 0; j < 2 * m; ++j) cnt[g.second[j % m]][j / m] = c[j];
         }
     }
+    // resultc->set_c(...) narrows the 64-bit count to int32 (readserver.proto:31-33)
+    auto narrowed = [&](size_t i, size_t r, int strand) { return (int32_t)(uint32_t)cnt[i][strand * rows + r]; };
+    size_t total = 0, messages = 0;
     for (size_t i = 0; i < n; ++i) {
         if (!(*handled)[i]) continue;
         for (size_t r = 0; r < rows; ++r)
+            for (int strand = 0; strand < 2; ++strand) total += count_reply_len(rq[i].t, rq[i].q.size(), narrowed(i, r, strand));
+        messages += 2 * rows;
+    }
+    replies->bytes.resize(total);
+    replies->off.reserve(messages + 1);
+    uint8_t *p = replies->bytes.data();
+    for (size_t i = 0; i < n; ++i) {
+        replies->first[i] = replies->off.size() - 1;
+        if (!(*handled)[i]) continue;
+        for (size_t r = 0; r < rows; ++r)
             for (int strand = 0; strand < 2; ++strand) {
-                std::vector<uint8_t> o;
-                // resultc->set_c(...) narrows the 64-bit count to int32 (readserver.proto:31-33)
-                const int32_t c = (int32_t)(uint32_t)cnt[i][strand * rows + r];
-                encode_count_reply(o, rq[i].t, rq[i].q.data(), rq[i].q.size(), strand == 1, c);
-                (*replies)[i].push_back(std::move(o));
+                p = encode_count_reply(p, rq[i].t, rq[i].q.data(), rq[i].q.size(), strand == 1, narrowed(i, r, strand));
+                replies->off.push_back((size_t)(p - replies->bytes.data()));
             }
     }
+    replies->first[n] = replies->off.size() - 1;
     return RSBWT_OK;
 }
 
@@ -219,21 +244,16 @@ int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t reque
             parsed[i] = rsb::service_decode(requests + req_off[i], (size_t)(req_off[i + 1] - req_off[i]), &rq[i]) ? 1 : 0;
         for (size_t i = 0; i < n; ++i)
             if (!parsed[i]) rq[i].t = 0;  // not a Request: no reply
-        std::vector<std::vector<std::vector<uint8_t>>> rep;
+        rsb::reply_arena rep;
         std::vector<char> handled;
         const int rc = rsb::service_count_batch(set, rq, false, &rep, &handled);
         if (rc != RSBWT_OK) return rc;
-        size_t total = 0;
+        const size_t total = rep.bytes.size();
         rep_off[0] = 0;
         for (size_t i = 0; i < n; ++i)
-            for (int strand = 0; strand < 2; ++strand) {
-                if (handled[i]) {
-                    const std::vector<uint8_t> &o = rep[i][strand];
-                    if (replies && total + o.size() <= cap) memcpy(replies + total, o.data(), o.size());
-                    total += o.size();
-                }
-                rep_off[2 * i + strand + 1] = total;
-            }
+            for (int strand = 0; strand < 2; ++strand)
+                rep_off[2 * i + strand + 1] = handled[i] ? rep.off[rep.first[i] + strand + 1] : rep.off[rep.first[i]];
+        if (replies && total <= cap && total) memcpy(replies, rep.bytes.data(), total);
         if (needed) *needed = total;
         if ((replies && total <= cap) || total == 0) return RSBWT_OK;
         return rsb::fail(RSBWT_ERANGE, "%zu reply bytes, room for %zu", total, cap);

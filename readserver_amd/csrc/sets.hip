@@ -194,6 +194,7 @@ void rsbwt_set_close(rsbwt_set_t *s) {
         }
         if (g->d_views) (void)hipFree(g->d_views);
         if (g->d_work) (void)hipFree(g->d_work);
+        g->scratch.destroy();
         for (int i = 0; i < search_meter::RING; ++i) {
             if (g->ev_start[i]) (void)hipEventDestroy(g->ev_start[i]);
             if (g->ev_stop[i]) (void)hipEventDestroy(g->ev_stop[i]);

@@ -2,13 +2,18 @@
 // process: a producer thread pushes serialised CountReads Requests into the in-process transport, the
 // loop batches them (window / max batch), searches all shards of the set on the GPU and sends 2 x P
 // Replies per request, a consumer thread pops them.  What a ZeroMQ deployment adds is the sockets.
-//   tools/bin/service_bench [requests=200000] [shards=1] [run_bytes=2e8] [window_us=200] [max_batch=4096]
+//   tools/bin/service_bench [requests=200000] [shards=1] [run_bytes=2e8] [window_us=200] [max_batch=4096] [closed=0]
+// closed=1: one request in flight at a time (push, wait for its 2 x P replies): the latency of a lone
+// request, printed beside the latency of the library calls under it (rsbwt_set_find_intervals and
+// rsbwt_find_intervals with one k-mer).
 // build: g++ -O2 -std=c++17 -Iinclude tools/service_bench.cpp -Lreadserver_amd/lib -lrsbwt -lpthread
 //            -Wl,-rpath,'$ORIGIN/../../readserver_amd/lib' -Wl,-rpath,/opt/rocm/lib -o tools/bin/service_bench
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -29,6 +34,7 @@ int main(int argc, char **argv) {
     const uint64_t R = argc > 3 ? (uint64_t)atof(argv[3]) : 200000000ull;
     const int64_t window = argc > 4 ? atoll(argv[4]) : 200;
     const size_t max_batch = argc > 5 ? (size_t)atoll(argv[5]) : 4096;
+    const bool closed_loop = argc > 6 && atoi(argv[6]) != 0;
     const uint32_t k = 31;
     std::vector<rsbwt_t *> shards;
     {
@@ -61,6 +67,77 @@ int main(int argc, char **argv) {
             m.push_back("ACGT"[(h >> (2 * (j & 31))) & 3]);
         }
         msgs[i] = m;
+    }
+    if (closed_loop) {
+        auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        auto summary = [](std::vector<double> &v, double *mean, double *p50, double *p99) {
+            size_t slow = 0, worst = 0;
+            for (size_t i = 0; i < v.size(); ++i) {
+                slow += v[i] > 1000.0;
+                if (v[i] > v[worst]) worst = i;
+            }
+            fprintf(stderr, "  %zu samples, %zu over 1 ms, worst %.0f us at sample %zu\n", v.size(), slow, v[worst], worst);
+            std::sort(v.begin(), v.end());
+            double s = 0;
+            for (double x : v) s += x;
+            *mean = s / v.size();
+            *p50 = v[v.size() / 2];
+            *p99 = v[std::min(v.size() - 1, v.size() * 99 / 100)];
+        };
+        // a clock watcher: if it sees the same gap as a slow call, the process was not running at all
+        std::atomic<bool> watch_stop{false};
+        double watch_worst = 0;
+        std::thread watcher([&] {
+            double last = now_us();
+            while (!watch_stop.load()) {
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+                const double t = now_us();
+                if (t - last > watch_worst) watch_worst = t - last;
+                last = t;
+            }
+        });
+        std::vector<double> svc_us, set_us, one_us;
+        uint8_t buf[512];
+        size_t n = 0;
+        for (size_t i = 0; i < N; ++i) {
+            const double t = now_us();
+            rsbwt_transport_push_request(tr, (const uint8_t *)msgs[i].data(), msgs[i].size());
+            for (size_t r = 0; r < 2 * P; ++r)
+                if (rsbwt_transport_pop_reply(tr, 1, buf, sizeof buf, &n, 30000000) != RSBWT_OK) return 2;
+            if (i >= 16) svc_us.push_back(now_us() - t);
+        }
+        std::vector<uint64_t> lo(2 * P), up(2 * P);
+        for (size_t i = 0; i < N; ++i) {  // each entry by itself, so that neither sees the other's stream
+            const char *q = msgs[i].data() + 6;
+            const double t = now_us();
+            if (rsbwt_find_intervals(shards[0], q, 1, k, k, lo.data(), up.data()) != RSBWT_OK) return 2;
+            if (i >= 16) one_us.push_back(now_us() - t);
+        }
+        for (size_t i = 0; i < N; ++i) {
+            const char *q = msgs[i].data() + 6;
+            const double t = now_us();
+            if (rsbwt_set_find_intervals(set, q, 1, k, k, lo.data(), up.data()) != RSBWT_OK) return 2;
+            if (i >= 16) set_us.push_back(now_us() - t);
+        }
+        watch_stop.store(true);
+        watcher.join();
+        fprintf(stderr, "  clock watcher's longest gap between 200 us sleeps: %.0f us\n", watch_worst);
+        double a[3], b[3], c[3];
+        summary(svc_us, &a[0], &a[1], &a[2]);
+        summary(set_us, &b[0], &b[1], &b[2]);
+        summary(one_us, &c[0], &c[1], &c[2]);
+        printf("{\"closed_loop_requests\": %zu, \"partitions\": %zu, \"window_us\": %lld, \"max_batch\": %zu, "
+               "\"service_us\": {\"mean\": %.1f, \"p50\": %.1f, \"p99\": %.1f}, "
+               "\"set_find_intervals_1_us\": {\"mean\": %.1f, \"p50\": %.1f, \"p99\": %.1f}, "
+               "\"find_intervals_1_us\": {\"mean\": %.1f, \"p50\": %.1f, \"p99\": %.1f}}\n",
+               N, P, (long long)window, max_batch, a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]);
+        rsbwt_transport_close(tr);
+        rsbwt_service_stop(svc);
+        rsbwt_service_free(svc);
+        rsbwt_transport_free(tr);
+        rsbwt_set_close(set);
+        for (rsbwt_t *h : shards) rsbwt_close(h);
+        return 0;
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::thread producer([&] {
