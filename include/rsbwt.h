@@ -277,6 +277,12 @@ int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const voi
                                  uint32_t k, void *d_lower, void *d_upper, void *stream);
 int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                         void *d_counts, void *stream);
+/* 1-mismatch search (SURVEY 8 f3 / BASELINE configs[3]) of m packed k-mers in every shard of a one-device
+ * set: d_lower/d_upper [num_shards][m][3k+1]; d_scratch: rsbwt_set_1mm_scratch_bytes(s, m, k) bytes, shared
+ * by the shards' searches, which run one after the other on `stream`. */
+size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k);
+int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+                                     void *d_lower, void *d_upper, void *d_scratch, void *stream);
 /* d_pairs: [num_shards][Q] x {lower, upper} */
 int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q,
                                       uint32_t k, void *d_pairs, void *stream);

@@ -469,6 +469,31 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
                          true, (hipStream_t)stream, nullptr);
 }
 
+// 1-mismatch search over the shards of a one-device set.  A traced / resumed search belongs to one
+// shard (the trace is that shard's), so the shards take turns on the stream; each turn is m x (3k+1)
+// searches, large enough to fill the GPU by itself.
+size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
+    size_t need = 0;
+    if (s)
+        for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_1mm_scratch_bytes(h, m, k));
+    return need;
+}
+
+int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+                                     void *d_lower, void *d_upper, void *d_scratch, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    if (m == 0) return RSBWT_OK;
+    if (!d_lower || !d_upper) return fail(RSBWT_EINVAL, "null argument");
+    const size_t row = m * (3 * (size_t)k + 1) * 8;
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        const int rc = rsbwt_find_intervals_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_lower + i * row,
+                                                    (uint8_t *)d_upper + i * row, d_scratch, stream);
+        if (rc) return rc;
+    }
+    return RSBWT_OK;
+}
+
 // Gathers per-device interval blocks onto the first device of the set over RCCL (xGMI): d_blocks[g]
 // = device g's [S_g][Q] x {lower, upper} block of `bytes[g]` bytes on that device; d_root on device 0
 // receives them back to back in device order.  One call per batch; nothing is synchronised beyond

@@ -927,3 +927,70 @@ def test_gpu_set_interleaved_tables_and_detach(rsb, oracle):
     assert np.array_equal(lo1, lo2) and np.array_equal(up1, up2)
     for g in shards:
         g.close()
+
+
+def _spell_variants(km):
+    """[m][3k+1][k]: every k-mer followed by its single substitutions, position by position, the
+    alternatives in ACGT order (variants_kernel's order)."""
+    m, k = km.shape
+    out = np.repeat(km[:, None, :], 3 * k + 1, axis=1)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for pos in range(k):
+        for q in range(m):
+            alts = [c for c in acgt if c != km[q, pos]][:3]
+            out[q, 1 + 3 * pos:4 + 3 * pos, pos] = alts
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_set_one_mismatch_over_the_shards(rsb, oracle):
+    """rsbwt_set_find_intervals_1mm_dev: the [S][m][3k+1] variant intervals of a one-device set =
+    the oracle's exact search of every spelled-out variant in every shard (tables of different
+    depths, so the shards' traces differ in length; one shard without a table)."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    sizes = [300000, 40000, 900000]
+    shards, oixs = [], []
+    for i, R in enumerate(sizes):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 1700 + i) == 0
+        oixs.append(oracle.from_runs(runs))
+        shards.append(rsb.GpuBWT(runs=runs, ktab_depth=[6, 0, 9][i]))
+    ss = rsb.ShardSet(shards)
+    rng = np.random.default_rng(16)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for k, m in ((31, 300), (12, 500), (33, 100)):
+        km = _random_kmers(rng, m, k)
+        d_half = torch.empty((m // 2, k), dtype=torch.uint8, device="cuda:0")
+        assert L.rsbwt_sample_present_kmers_dev(shards[2].handle, m // 2, k, k, 5, p(d_half), None) == 0
+        torch.cuda.synchronize()
+        km[: m // 2] = d_half.cpu().numpy()
+        km[7, k // 2] = ord("N")
+        V = 3 * k + 1
+        wpq = (k + 31) // 32
+        d_km = torch.from_numpy(km).cuda()
+        d_pk = torch.empty((m, wpq), dtype=torch.int64, device="cuda:0")
+        d_ok = torch.empty(m, dtype=torch.uint8, device="cuda:0")
+        d_lo = torch.empty((len(sizes), m, V), dtype=torch.int64, device="cuda:0")
+        d_up = torch.empty((len(sizes), m, V), dtype=torch.int64, device="cuda:0")
+        need = L.rsbwt_set_1mm_scratch_bytes(ss._s, m, k)
+        assert need >= max(L.rsbwt_1mm_scratch_bytes(g.handle, m, k) for g in shards)
+        d_scr = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+        assert L.rsbwt_set_find_intervals_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_lo), p(d_up), p(d_scr), None) == 0
+        torch.cuda.synchronize()
+        lo, up = d_lo.cpu().numpy().view(np.uint64), d_up.cpu().numpy().view(np.uint64)
+        variants = _spell_variants(km)
+        assert variants.shape == (m, V, k)
+        for s, oix in enumerate(oixs):
+            elo, eup = oix.find_intervals(variants.reshape(m * V, k), nthreads=8)
+            elo, eup = elo.reshape(m, V), eup.reshape(m, V)
+            elo[7], eup[7] = 1, 0  # a k-mer with a foreign symbol is invalid as a whole
+            assert np.array_equal(lo[s], elo) and np.array_equal(up[s], eup), (k, s)
+    ss.close()
+    for g in shards:
+        g.close()
+
+
+

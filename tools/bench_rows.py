@@ -6,7 +6,10 @@ HBM, as bench.py measures the exact search), with a roofline each:
 Algorithmic bytes: 128 B per distinct window line read by an Occ lookup (+ 40 B per search) for f3,
 from the search kernel's own counters; 128 B per LF / select step for f2 (one line holds what a step
 needs), counted from the lengths extracted.  Prints one JSON line.
-usage: tools/bench_rows.py [run_bytes=2e10] [kmers=40000] [rows=2000000]"""
+With shards > 1 (BASELINE configs[3]/[4]: the 8 shards of one GPU) the 1-mismatch search runs over a
+shard set (rsbwt_set_find_intervals_1mm_dev, tables sized for the set) and rows are extracted from every
+shard in turn.
+usage: tools/bench_rows.py [run_bytes=2e10] [kmers=40000] [rows=2000000] [shards=1]"""
 import ctypes as C
 import json
 import os
@@ -22,6 +25,7 @@ import readserver_amd as rsb  # noqa: E402
 R = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000000
 M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 40000
 NR = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2000000
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 k, PEAK = 31, 8000.0
 L = rsb.lib()
 dev = torch.device("cuda", 0)
@@ -33,14 +37,30 @@ def ok(rc):
         raise RuntimeError(L.rsbwt_last_error().decode())
 
 
-d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
-ok(L.rsbwt_synth_runs_dev(p(d_runs), R, 1000003, 0, None))
-torch.cuda.synchronize()
-g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R))
-del d_runs
-torch.cuda.empty_cache()
-n = g.getBWLen()
-out = {"run_bytes": R, "symbols": int(n), "ktab_depth": g.ktab_depth(), "window_span": g.window_span()}
+shards = []
+for s in range(S):
+    d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
+    ok(L.rsbwt_synth_runs_dev(p(d_runs), R, 1000003 + s, 0, None))
+    torch.cuda.synchronize()
+    shards.append(rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=(0 if S == 1 else None)))
+    del d_runs
+    torch.cuda.empty_cache()
+g = shards[0]
+sset = rsb.ShardSet(shards)
+if S > 1:
+    # the select samples of every shard first (built by a shard's first extraction), then one k-mer
+    # table depth for the GPU's shards out of the HBM that is left, interleaved (as bench.py)
+    one = torch.zeros(1, dtype=torch.int64, device=dev)
+    o1 = torch.empty((1, 512), dtype=torch.uint8, device=dev)
+    l1 = torch.empty(2, dtype=torch.int32, device=dev)
+    for h in shards:
+        ok(L.rsbwt_extract_dev(h.handle, p(one), 1, p(o1), 512, p(l1), p(l1[1:]), None))
+    torch.cuda.synchronize()
+    T = L.rsbwt_set_auto_ktab_depth(sset._s)
+    if T >= 2:
+        ok(L.rsbwt_set_attach_ktabs(sset._s, T))
+n = min(h.getBWLen() for h in shards)
+out = {"run_bytes": R, "shards": S, "symbols": int(n), "ktab_depth": g.ktab_depth(), "window_span": g.window_span()}
 
 # ---- f3: 1-mismatch, half of the k-mers drawn from the index ---------------------------------------
 gen = torch.Generator(device=dev)
@@ -54,17 +74,21 @@ d_km[::2][:M // 2] = half
 V = 3 * k + 1
 d_pk = torch.empty(M, dtype=torch.int64, device=dev)
 d_ok = torch.empty(M, dtype=torch.uint8, device=dev)
-d_lo = torch.empty((M, V), dtype=torch.int64, device=dev)
-d_up = torch.empty((M, V), dtype=torch.int64, device=dev)
-d_scr = torch.empty(L.rsbwt_1mm_scratch_bytes(g.handle, M, k), dtype=torch.uint8, device=dev)
+d_lo = torch.empty((S, M, V), dtype=torch.int64, device=dev)
+d_up = torch.empty((S, M, V), dtype=torch.int64, device=dev)
+d_scr = torch.empty(L.rsbwt_set_1mm_scratch_bytes(sset._s, M, k), dtype=torch.uint8, device=dev)
 ok(L.rsbwt_pack_kmers_dev(p(d_km), M, k, k, p(d_pk), p(d_ok), 0, None))
-run1 = lambda: ok(L.rsbwt_find_intervals_1mm_dev(g.handle, p(d_pk), p(d_ok), M, k, p(d_lo), p(d_up), p(d_scr), None))
-ok(L.rsbwt_set_counting(g.handle, 1))
+run1 = lambda: ok(L.rsbwt_set_find_intervals_1mm_dev(sset._s, p(d_pk), p(d_ok), M, k, p(d_lo), p(d_up), p(d_scr), None))
+w = [0] * 16
+for h in shards:  # counters of every shard's resumed search of the m x (3k+1) variants
+    ok(L.rsbwt_set_counting(h.handle, 1))
 run1()
 torch.cuda.synchronize()
-w = (C.c_uint64 * 16)()
-ok(L.rsbwt_last_search_counters(g.handle, w))  # the resumed search of the m x (3k+1) variants
-ok(L.rsbwt_set_counting(g.handle, 0))
+for h in shards:
+    wi = (C.c_uint64 * 16)()
+    ok(L.rsbwt_last_search_counters(h.handle, wi))
+    ok(L.rsbwt_set_counting(h.handle, 0))
+    w = [a + int(b) for a, b in zip(w, wi)]
 for _ in range(2):
     run1()
 torch.cuda.synchronize()
@@ -74,16 +98,18 @@ for _ in range(reps):
     run1()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-buf = (C.c_float * 64)()
-cnt = C.c_size_t()
-ok(L.rsbwt_search_history_ms(g.handle, buf, 2 * reps, C.byref(cnt)))
-kms = sum(buf[:cnt.value]) / reps  # traced + resumed search kernels of one call
-alg = w[2] * 128 + M * V * 40
+kms = 0.0
+for h in shards:
+    buf = (C.c_float * 64)()
+    cnt = C.c_size_t()
+    ok(L.rsbwt_search_history_ms(h.handle, buf, 2 * reps, C.byref(cnt)))
+    kms += sum(buf[:cnt.value]) / reps  # traced + resumed search kernels of one call, every shard
+alg = w[2] * 128 + S * M * V * 40
 hits = int((d_up >= d_lo).sum().item())
 out["one_mismatch"] = {
-    "kmers": M, "variants_per_kmer": V, "kmers_per_s": M / dt, "variant_searches_per_s": M * V / dt,
+    "kmers": M, "variants_per_kmer": V, "kmers_per_s": M / dt, "variant_searches_per_s": S * M * V / dt,
     "ms_per_call": dt * 1e3, "search_kernels_ms_per_call": kms, "hits": hits,
-    "lf_steps_per_variant": w[0] / (M * V), "line_reads": w[2], "continuation_line_reads": w[11],
+    "lf_steps_per_variant": w[0] / (S * M * V), "line_reads": w[2], "continuation_line_reads": w[11],
     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                  "frac": alg / (kms * 1e-3) / 1e9 / PEAK, "kernel": "search_lines_kernel (variants resumed from the trace)",
                  "algorithmic_bytes": alg},
@@ -96,26 +122,33 @@ rows = torch.randint(0, n, (NR,), generator=gen, device=dev, dtype=torch.int64)
 d_out = torch.empty((NR, stride), dtype=torch.uint8, device=dev)
 d_len = torch.empty(NR, dtype=torch.int32, device=dev)
 d_pl = torch.empty(NR, dtype=torch.int32, device=dev)
-run2 = lambda: ok(L.rsbwt_extract_dev(g.handle, p(rows), NR, p(d_out), stride, p(d_len), p(d_pl), None))
-run2()
-torch.cuda.synchronize()
-ln = d_len.cpu().numpy().view(np.uint32)
-fits = ln != 0xFFFFFFFF
-steps = int(ln[fits].astype(np.int64).sum()) + 2 * int(fits.sum())  # one line per symbol + the two '$' steps
+run2 = lambda h: ok(L.rsbwt_extract_dev(h.handle, p(rows), NR, p(d_out), stride, p(d_len), p(d_pl), None))
+steps, nfit, bases = 0, 0, 0
+for h in shards:  # NR rows of every shard (row numbers are per shard: one call per shard)
+    run2(h)
+    torch.cuda.synchronize()
+    ln = d_len.cpu().numpy().view(np.uint32)
+    fits = ln != 0xFFFFFFFF
+    steps += int(ln[fits].astype(np.int64).sum()) + 2 * int(fits.sum())  # one line per symbol + the two '$' steps
+    nfit += int(fits.sum())
+    bases += int(ln[fits].astype(np.int64).sum())
 reps = 3
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
 for _ in range(reps):
-    run2()
+    for h in shards:
+        run2(h)
 ev1.record()
 torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1) / reps
 out["extract"] = {
-    "rows": NR, "rows_fitting_stride": int(fits.sum()), "mean_read_length": float(ln[fits].mean()),
-    "reads_per_s": NR / (ms * 1e-3), "bases_per_s": float(ln[fits].sum()) / (ms * 1e-3), "ms_per_call": ms,
+    "rows": S * NR, "rows_fitting_stride": nfit, "mean_read_length": bases / max(nfit, 1),
+    "reads_per_s": S * NR / (ms * 1e-3), "bases_per_s": bases / (ms * 1e-3), "ms_per_call": ms,
     "roofline": {"bound": "hbm", "achieved": steps * 128 / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                  "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel",
                  "algorithmic_bytes": steps * 128, "steps": steps},
 }
-g.close()
+sset.close()
+for h in shards:
+    h.close()
 print(json.dumps(out))
