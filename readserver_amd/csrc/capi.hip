@@ -1030,7 +1030,13 @@ int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uin
     int rc = use_device(h->device);
     if (rc) return rc;
     if ((rc = ensure_select_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
-    hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus, (hipStream_t)stream);
+    unsigned long long *work = nullptr;
+    if (h->counting) {  // rsbwt_set_counting: the walk kernels' counters, read with rsbwt_last_search_counters
+        work = h->d_work;
+        HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
+    }
+    hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus,
+                                       (hipStream_t)stream, work);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;
 }

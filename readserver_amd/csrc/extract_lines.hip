@@ -9,11 +9,16 @@
 //     128-byte line per octet of lanes, direct to LDS) and parsed lane-privately: the header names the
 //     quarter, 24 pieces are scanned; a position past its line's own pieces continues lazily (spill
 //     chunk / far line) in the lane's next pass;
-//   * LF step (prefix): one line gives the symbol at the position AND its rank (usually one pass);
+//   * LF step (prefix): one line gives the symbol at the position AND its rank in one pass, off one
+//     look at the quarter's 24 pieces (rank_device.h, char_rank24: dword totals by v_dot4, only the
+//     dword holding the position is taken apart); a spilled position takes one more pass, the window
+//     line's four counts travelling with the lane;
 //   * psi step (postfix): sampled select (one sample per 256 occurrences) bounds the window; the
-//     window is found by probing count words (8-byte loads that fly with the other lanes' line
-//     fetches), then selected in: count words of three quarter boundaries from the header and two
-//     v_dot4 sums, one quarter scanned.
+//     window tried first is interpolated between the two samples and its line is fetched together
+//     with the next window's count word (8 bytes), which says at once whether the guess was right
+//     (count(w) < bc <= count(w + 1)) -- a wrong guess costs one more pass; then selected in: three
+//     quarter boundaries from the header and two v_dot4 sums, one quarter taken apart
+//     (rank_device.h, select_in24).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,36 +58,6 @@ __device__ __forceinline__ uint32_t read_chunk_dword(const staged_line &L) {
     return 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
 }
 
-// rank (0..4) of the symbol of the piece holding the rem-th symbol (rem >= 1) of the 24 pieces r6
-__device__ __forceinline__ uint32_t char_at24(const uint32_t r6[6], uint32_t rem) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        const uint32_t u = __builtin_amdgcn_ubfe(r6[i >> 2], 8 * (i & 3), 8), len = u & 31u;
-        const bool hit = (rem - 1u) < len;  // rem == 0 (already found) wraps to "no"
-        c = hit ? (u >> 5) : c;
-        rem = rem > len ? rem - len : 0u;
-    }
-    return c;
-}
-
-// position (symbols from the first of the 24 pieces r6) of the t-th b (t >= 1) among them; *left =
-// what remains of t when they hold fewer (0: found)
-__device__ __forceinline__ uint32_t select24(const uint32_t r6[6], uint32_t b, uint32_t t, uint32_t *left) {
-    uint32_t pos = 0, prefix = 0;
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        const uint32_t u = __builtin_amdgcn_ubfe(r6[i >> 2], 8 * (i & 3), 8), len = u & 31u;
-        const bool act = (u >> 5) == b && t != 0u;  // t == 0: found already
-        const bool hit = act && t <= len;
-        pos = hit ? prefix + t - 1u : pos;
-        t = hit ? 0u : (act ? t - len : t);
-        prefix += len;
-    }
-    *left = t;
-    return pos;
-}
-
 // Hands rows to the lanes that have none.  A wave draws chunks of ROW_CHUNK consecutive rows from the
 // global counter (one atomic per chunk, not per pass: the atomic's round trip would otherwise sit in
 // front of every pass's line fetch) and gives the next one to whichever lane is free.
@@ -120,9 +95,17 @@ __device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, si
 // left, so they are written downwards from the end of the row's buffer; plen = their number
 // (UINT32_MAX: the walk does not fit `stride`, or the row is out of range).
 // ---------------------------------------------------------------------------------------------------
+// COUNT_WORK (both walk kernels): work[] receives, summed over the waves, 0 passes, 1 lanes holding a
+// row over those passes, 2 steps completed, 3 lanes on a continuation line, 4 lanes that fetched a line,
+// 5 cycles in all, 6 cycles from issuing the fetches until they have landed, 7 (postfix) lanes whose
+// window guess was wrong (one more pass each).
+enum { XW_PASSES = 0, XW_ACTIVE = 1, XW_STEPS = 2, XW_CONT = 3, XW_FETCHED = 4, XW_CYCLES = 5, XW_WAIT = 6, XW_PROBES = 7, XW_WORDS = 8 };
+
+template <bool COUNT_WORK>
 __global__ void __launch_bounds__(64 * WG_WAVES)
 extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out,
-                           uint32_t stride, uint32_t *__restrict__ plen, unsigned long long *__restrict__ pool) {
+                           uint32_t stride, uint32_t *__restrict__ plen, unsigned long long *__restrict__ pool,
+                           unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
@@ -141,20 +124,22 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
     bool have = false;
     row_pool rp;
     size_t r = 0;
-    uint64_t idx = 0, acc = 0;
-    uint32_t len = 0, c = 0, phase = 0;  // phase 0: symbol at idx; 1: rank of symbol c at idx
+    uint64_t idx = 0;
+    uint32_t len = 0;
     uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0, w = 0;
+    uint32_t acc_lo[4] = {0, 0, 0, 0}, acc_hi = 0;  // the window line's four counts, kept for its spill chunk
     // characters are produced right to left: four at a time go out as one aligned dword when the row
     // buffers allow it (a byte store per character is a request per character)
     const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
     uint32_t chars = 0;
+    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         size_t nr = 0;
         if (draw_row(!have, pool, n, lane, rp, &nr)) {
             r = nr;
             idx = rows[r];
             len = 0;
-            phase = 0;
             cont = 0;
             chars = 0;
             have = true;
@@ -167,6 +152,11 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
             if (rp.drained) break;
             continue;
         }
+        if (COUNT_WORK) {
+            ++xw[XW_PASSES];
+            xw[XW_ACTIVE] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
+            xw[XW_CONT] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have && cont != 0u));
+        }
         // ---- this lane's line
         uint32_t line = 0, o = 0;
         if (have && cont == 0u) {
@@ -178,51 +168,80 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
             tries = 0;
         }
         const uint32_t want = have ? (cont ? cblk : line) : ~0u;
+        unsigned long long t_fetch = 0;
+        if (COUNT_WORK) {
+            xw[XW_FETCHED] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(want != ~0u));
+            __builtin_amdgcn_sched_barrier(0);
+            t_fetch = __builtin_amdgcn_s_memtime();
+        }
         glds_fetch(lines_bytes, want, lane, stage_lds);
         glds_wait();
-        // ---- phase 0: the symbol at the position (RLEBWT::getChar, rlebwt.cpp:202-227)
-        bool got_char = false, same_line = false;
-        if (have && phase == 0u) {
-            uint32_t dw = HDR_DWORDS, rem = 0;
-            bool scan = false;
-            if (cont != KIND_CHUNK) {
+        if (COUNT_WORK) {
+            __builtin_amdgcn_sched_barrier(0);
+            xw[XW_WAIT] += __builtin_amdgcn_s_memtime() - t_fetch;
+        }
+        // ---- where in this line the position lies (or where its continuation is)
+        const bool in_chunk = cont == KIND_CHUNK;
+        bool scan = false;
+        uint32_t dw = HDR_DWORDS, rem = 0, cq = 0;
+        if (have) {
+            if (!in_chunk) {  // a window line, or the far line that continues one (same header)
                 const line_head h = read_head(L);
                 const uint32_t oe = cont ? co : o;
                 if (oe <= h.span) {
-                    const uint32_t cq = (oe > h.s1 ? 1u : 0u) + (oe > h.s2 ? 1u : 0u) + (oe > h.s3 ? 1u : 0u);
+                    cq = (oe > h.s1 ? 1u : 0u) + (oe > h.s2 ? 1u : 0u) + (oe > h.s3 ? 1u : 0u);
                     const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
                     dw = HDR_DWORDS + 6u * cq;
                     rem = oe - start;
                     scan = true;
-                    same_line = cont == 0u;
                 } else if (h.kind == KIND_FAR) {
                     cblk = L.dword(LINE_DWORDS - 1u);
                     if (cblk >= nlines) cblk = 0;
                     cont = KIND_FAR;
                     co = oe - h.span;
                 } else if (h.kind == KIND_CHUNK && cont == 0u) {
+                    const uint4 h0 = L.u4(0), h1 = L.u4(4);  // the four count words (dwords 0..7)
+                    acc_lo[0] = h0.x; acc_lo[1] = h0.z; acc_lo[2] = h1.x; acc_lo[3] = h1.z;
+                    acc_hi = (h0.y & 0xFFu) | ((h0.w & 0xFFu) << 8) | ((h1.y & 0xFFu) << 16) | (h1.w << 24);
                     cdw = read_chunk_dword(L);
                     cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
                     if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
                     co = oe - h.span;
                 } else {
-                    scan = true;  // beyond what the index holds: never for idx < n; ends the walk as '$'
+                    scan = true;  // beyond what the index holds: never for idx < n; rem = 0 ends the walk as '$'
                 }
             } else {
                 dw = cdw + 2u;
                 rem = co;
                 scan = true;
             }
-            if (!scan && ++tries > 72u) scan = true;
-            if (scan) {
-                uint32_t r6[6];
-                load24(L, dw, r6);
-                c = rem ? char_at24(r6, rem) : 0u;
-                got_char = true;
-            }
+            if (!scan && ++tries > 72u) scan = true;  // a corrupt chain: rem = 0 ends the walk
         }
-        if (got_char) {
+        // ---- the symbol at the position and its rank, off the same 24 pieces (RLEBWT::getChar,
+        // rlebwt.cpp:202-227, and RLEBWT::getOcc, rlebwt.cpp:268-301: one LF step, query.cpp:49-57)
+        uint32_t r6[6];
+        load24(L, dw, r6);
+        const char_rank cr = char_rank24(r6, scan ? rem : 0u, 0u);
+        const uint32_t c = cr.c;
+        const uint32_t ci = (c - 1u) & 3u;
+        // what the line says about c before those pieces
+        uint64_t base;
+        if (in_chunk) {
+            const uint2 hd = L.u2(cdw);
+            const uint32_t hw = ci < 2u ? hd.x : hd.y;
+            const uint32_t alo = ci == 0u ? acc_lo[0] : ci == 1u ? acc_lo[1] : ci == 2u ? acc_lo[2] : acc_lo[3];
+            base = (((uint64_t)((acc_hi >> (8u * ci)) & 0xFFu) << 32) | alo) + ((hw >> (12u * (ci & 1u))) & 0xFFFu);
+        } else {
+            const uint32_t hb = read_half(L, ci + 1u);
+            const uint32_t m = matched24(L, HDR_DWORDS + 6u * (cq & 2u), ci + 1u);
+            base = read_count(L, ci + 1u) + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
+        }
+        // C[c], with every lane active (a ds_bpermute returns 0 from a masked-off source lane)
+        const uint64_t pc = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_hi) << 32) |
+                            (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_lo);
+        bool done = false;
+        if (scan) {
             if (c == 0u || c > 4u) {  // '$': the read starts here (query.cpp:52)
                 if (packed_out)  // the characters not yet written: the (len & 3) most recent ones
                     for (uint32_t t = 0; t < (len & 3u); ++t)
@@ -233,84 +252,28 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
                 plen[r] = 0xFFFFFFFFu;
                 have = false;
             } else {
-                phase = 1;
-                if (!same_line) cont = 0;  // the rank starts over at the window's line, next pass
-            }
-        }
-        // ---- phase 1: Occ(c, idx) (RLEBWT::getOcc, rlebwt.cpp:268-301), as in search_lines.hip
-        const bool ranking = have && phase == 1u && (same_line || !got_char);
-        bool done = false;
-        uint64_t occ = 0;
-        if (ranking) {
-            bool scan = false;
-            uint64_t base = 0;
-            uint32_t dw = HDR_DWORDS, rem = 0;
-            if (cont != KIND_CHUNK) {
-                const line_head h = read_head(L);
-                const uint32_t oe = cont ? co : o;
-                const uint64_t cnt = read_count(L, c);
-                if (oe <= h.span) {
-                    const uint32_t cq = (oe > h.s1 ? 1u : 0u) + (oe > h.s2 ? 1u : 0u) + (oe > h.s3 ? 1u : 0u);
-                    const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
-                    const uint32_t hb = read_half(L, c);
-                    const uint32_t m = matched24(L, HDR_DWORDS + 6u * (cq & 2u), c);
-                    base = cnt + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
-                    dw = HDR_DWORDS + 6u * cq;
-                    rem = oe - start;
-                    scan = true;
-                } else if (h.kind == KIND_FAR) {
-                    cblk = L.dword(LINE_DWORDS - 1u);
-                    if (cblk >= nlines) cblk = 0;
-                    cont = KIND_FAR;
-                    co = oe - h.span;
-                } else if (h.kind == KIND_CHUNK && cont == 0u) {
-                    acc = cnt;
-                    cdw = read_chunk_dword(L);
-                    cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
-                    if (cblk >= nlines) cblk = 0;
-                    cont = KIND_CHUNK;
-                    co = oe - h.span;
+                const uint32_t ch = (0x54474341u >> (8u * ci)) & 0xFFu;  // "ACGT"[c-1]
+                if (packed_out) {
+                    chars = (chars << 8) | ch;  // most recent character in the low byte = lowest address
+                    if ((len & 3u) == 3u) {
+                        // chars = [c(len-3) c(len-2) c(len-1) c(len)] high to low; memory order is the reverse of
+                        // production order: address stride-1-len holds c(len)
+                        *reinterpret_cast<uint32_t *>(out + r * (size_t)stride + (stride - 1u - len)) = chars;
+                    }
                 } else {
-                    base = cnt;
-                    scan = true;
+                    out[r * (size_t)stride + (stride - 1u - len)] = (uint8_t)ch;
                 }
-            } else {
-                const uint2 hd = L.u2(cdw);
-                const uint32_t hw = (c <= 2u) ? hd.x : hd.y;
-                base = acc + ((hw >> (12u * ((c - 1u) & 1u))) & 0xFFFu);
-                dw = cdw + 2u;
-                rem = co;
-                scan = true;
-            }
-            if (!scan && ++tries > 72u) scan = true;
-            if (scan) {
-                uint32_t r6[6];
-                load24(L, dw, r6);
-                occ = base + runs_scan<6>(r6, c, rem);
+                ++len;
+                idx = pc + base + cr.occ - 1ull;  // C[b] + Occ(b, idx) - 1 = this row's LF target (query.cpp:55-56)
+                cont = 0;
                 done = true;
             }
         }
-        // C[c], with every lane active (a ds_bpermute returns 0 from a masked-off source lane)
-        const uint32_t ci = (c - 1u) & 3u;
-        const uint64_t pc = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_hi) << 32) |
-                            (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ci << 2), (int)ctab_lo);
-        if (done) {
-            const uint32_t ch = (0x54474341u >> (8u * (c - 1u))) & 0xFFu;  // "ACGT"[c-1]
-            if (packed_out) {
-                chars = (chars << 8) | ch;  // most recent character in the low byte = lowest address
-                if ((len & 3u) == 3u) {
-                    // chars = [c(len-3) c(len-2) c(len-1) c(len)] high to low; memory order is the reverse of
-                    // production order: address stride-1-len holds c(len)
-                    *reinterpret_cast<uint32_t *>(out + r * (size_t)stride + (stride - 1u - len)) = chars;
-                }
-            } else {
-                out[r * (size_t)stride + (stride - 1u - len)] = (uint8_t)ch;
-            }
-            ++len;
-            idx = pc + occ - 1ull;  // C[b] + Occ(b, idx-1) of the reference = this row's LF target
-            phase = 0;
-            cont = 0;
-        }
+        if (COUNT_WORK) xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(done));
+    }
+    if (COUNT_WORK && lane == 0u) {
+        xw[XW_CYCLES] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int i = 0; i < XW_WORDS; ++i) atomicAdd(&work[i], xw[i]);
     }
 }
 
@@ -318,11 +281,12 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
 // extractPostfix (query.cpp:65-85): F / select walk right until '$', appended after the prefix.
 // tlen = length of the whole read (UINT32_MAX: it does not fit, or the prefix did not).
 // ---------------------------------------------------------------------------------------------------
+template <bool COUNT_WORK>
 __global__ void __launch_bounds__(64 * WG_WAVES)
 extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
                             const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out, uint32_t stride,
                             const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen,
-                            unsigned long long *__restrict__ pool) {
+                            unsigned long long *__restrict__ pool, unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
@@ -337,16 +301,19 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
     size_t r = 0;
     uint64_t idx = 0, bc = 0, posbase = 0;
     uint32_t len = 0, f = 0;
-    // phase 0: F symbol + select samples; 1: the window search between lo and hi; 2: select in window wlo
-    uint32_t phase = 0, wlo = 0, whi = 0, probe = 0, tries = 0;
+    // phase 0: F symbol + select samples; 3: the samples are in flight; 2: select in window wcur, which
+    // lies between the samples' windows wlo and whi
+    uint32_t phase = 0, wlo = 0, whi = 0, wcur = 0, tries = 0;
     uint32_t samp_lo = 0, samp_hi = 0;
-    uint2 probe_word = {0, 0};
     uint32_t cont = 0, cblk = 0, cdw = 0;
+    const uint32_t nwin = (uint32_t)ix.nwin;
     uint64_t t = 0;  // occurrences of f still to pass (select's running argument)
     // characters go out four at a time as aligned dwords when the row buffers allow it; `word` holds the
     // bytes of the dword being filled (low byte = lowest address), seeded with the prefix's last bytes
     const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
     uint32_t word = 0;
+    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         size_t nr = 0;
         if (draw_row(!have, pool, n, lane, rp, &nr)) {
@@ -370,49 +337,58 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
             if (rp.drained) break;
             continue;
         }
-        // ---- phase 1 (second half): the probe issued in the last pass has landed
-        if (have && phase == 1u && probe) {
-            const uint64_t cnt = ((uint64_t)(probe_word.y & 0xFFu) << 32) | probe_word.x;
-            if (cnt >= bc) whi = probe - 1u;  // floor search: largest window with count-before < bc
-            else wlo = probe;
-            probe = 0;
+        if (COUNT_WORK) {
+            ++xw[XW_PASSES];
+            xw[XW_ACTIVE] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
         }
+        // ---- the samples issued at the end of the last pass have landed: the bc-th f lies in a window
+        // between theirs.  Occurrences spread evenly between two samples more often than not, so the
+        // first window tried is the interpolated one; a wrong guess costs one more pass.
         if (have && phase == 3u) {
             wlo = samp_lo;
             whi = samp_hi < samp_lo ? samp_lo : samp_hi;
-            phase = 1;
+            wcur = wlo + (((whi - wlo) * (((uint32_t)bc - 1u) & ((1u << SEL_SHIFT) - 1u)) + (1u << (SEL_SHIFT - 1u))) >> SEL_SHIFT);
+            phase = 2;
+            cont = 0;
+            tries = 0;
         }
-        // ---- phase 1 (first half): probe the count word of the middle window, or go and select
-        if (have && phase == 1u) {
-            if (whi > wlo) {
-                probe = wlo + ((whi - wlo + 1u) >> 1);
-                const uint32_t pl = probe + (probe >> GROUP_SHIFT);
-                probe_word = *reinterpret_cast<const uint2 *>(lines_bytes + (uint64_t)pl * LINE_BYTES + 8u * (f - 1u));
-            } else {
-                phase = 2;
-                cont = 0;
-                tries = 0;
-            }
-        }
-        // ---- phase 2: the window's line (or its continuation)
+        // ---- phase 2: the window's line (or its continuation).  The bc-th f is in wcur iff
+        // count(wcur) < bc <= count(wcur + 1): the line's own count word settles the first half, the
+        // second shows when the window's pieces run out before the select argument does.
         const bool selecting = have && phase == 2u;
         uint32_t line = 0;
         if (selecting && cont == 0u) {
-            line = wlo + (wlo >> GROUP_SHIFT);
+            line = wcur + (wcur >> GROUP_SHIFT);
             if (line >= nlines) line = 0;
         }
         const uint32_t want = selecting ? (cont ? cblk : line) : ~0u;
+        unsigned long long t_fetch = 0;
+        if (COUNT_WORK) {
+            xw[XW_FETCHED] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(selecting));
+            xw[XW_CONT] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(selecting && cont != 0u));
+            __builtin_amdgcn_sched_barrier(0);
+            t_fetch = __builtin_amdgcn_s_memtime();
+        }
         glds_fetch(lines_bytes, want, lane, stage_lds);
         glds_wait();
+        if (COUNT_WORK) {
+            __builtin_amdgcn_sched_barrier(0);
+            xw[XW_WAIT] += __builtin_amdgcn_s_memtime() - t_fetch;
+        }
+        bool stepped = false, moved = false;
         if (selecting) {
             bool found = false;
             uint64_t pos = 0;
+            int move = 0;  // -1 / +1: the bc-th f is in an earlier / a later window than wcur
             if (cont != KIND_CHUNK) {
                 // a window line, or the far line that continues it: both carry absolute counts at
                 // their first piece, so the select argument is bc minus the line's count word
                 const line_head h = read_head(L);
                 const uint64_t cnt = read_count(L, f);
-                if (cont == 0u) posbase = (uint64_t)wlo * S;
+                if (cont == 0u) {
+                    posbase = (uint64_t)wcur * S;
+                    if (cnt >= bc) move = -1;
+                }
                 t = bc - cnt;
                 const uint32_t c1 = matched24(L, HDR_DWORDS, f), c2 = read_half(L, f);
                 const uint32_t c3 = c2 + matched24(L, HDR_DWORDS + 12u, f);
@@ -422,8 +398,13 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
                 uint32_t r6[6], left = 0;
                 load24(L, HDR_DWORDS + 6u * cq, r6);
-                const uint32_t p = select24(r6, f, tt - before, &left);
-                if (left == 0u) {
+                const uint32_t p = select_in24(r6, f, tt - before, &left);
+                // a hit lies within the symbols the line's own pieces hold: when the window tried is an
+                // earlier one than the bc-th f's, the argument outlasts the pieces and may "find" its f in
+                // the bytes after them (a far line's link)
+                if (move != 0) {
+                    // (nothing of this line is of use)
+                } else if (left == 0u && start + p < h.span) {
                     found = true;
                     pos = posbase + start + p;
                 } else if (h.kind == KIND_FAR) {
@@ -433,21 +414,43 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                     posbase += h.span;
                 } else if (h.kind == KIND_CHUNK && cont == 0u) {
                     cdw = read_chunk_dword(L);
-                    cblk = (wlo >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                    cblk = (wcur >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
                     if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
                     posbase += h.span;
                     t = left;  // what the chunk's pieces still have to provide
                 } else {
-                    found = true;  // never for a valid bc: end the walk
-                    pos = ix.n;
+                    move = 1;  // the window's pieces ran out first
                 }
             } else {
                 uint32_t r6[6], left = 0;
                 load24(L, cdw + 2u, r6);
-                const uint32_t p = select24(r6, f, (uint32_t)t, &left);
-                found = true;
-                pos = left == 0u ? posbase + p : ix.n;
+                const uint32_t p = select_in24(r6, f, (uint32_t)t, &left);
+                const uint2 hd = L.u2(cdw);
+                const uint32_t csym = (hd.x >> 24) | ((hd.y >> 24) << 8);  // symbols the chunk holds; the next chunk follows
+                found = left == 0u && p < csym;
+                pos = posbase + p;
+                if (!found) move = 1;
+            }
+            if (move < 0) {
+                if (wcur == 0u) {  // count(0) = 0 < bc: only a corrupt index gets here
+                    found = true;
+                    pos = ix.n;
+                }
+                whi = wcur - 1u;
+                wlo = wlo < whi ? wlo : whi;
+            } else if (move > 0) {
+                wlo = wcur + 1u;
+                whi = whi > wlo ? whi : wlo;
+                if (wlo >= nwin) {  // past the last window: a corrupt index
+                    found = true;
+                    pos = ix.n;
+                }
+            }
+            if (move != 0) {
+                wcur = wlo + ((whi - wlo) >> 1);
+                cont = 0;
+                moved = true;
             }
             if (!found && ++tries > 72u) {
                 found = true;
@@ -472,8 +475,13 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                     idx = pos;
                     phase = 0;
                     cont = 0;
+                    stepped = true;
                 }
             }
+        }
+        if (COUNT_WORK) {
+            xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(stepped));
+            xw[XW_PROBES] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(moved));
         }
         // ---- phase 0 (rows that just arrived or just stepped): getF (rlebwt.cpp:307-314) and the select
         // samples around the bc-th f; the sample loads fly with the next pass's fetches
@@ -497,6 +505,10 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 phase = 3;  // the samples are used from the next pass on
             }
         }
+    }
+    if (COUNT_WORK && lane == 0u) {
+        xw[XW_CYCLES] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int i = 0; i < XW_WORDS; ++i) atomicAdd(&work[i], xw[i]);
     }
 }
 
@@ -524,7 +536,7 @@ move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *_
 
 hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
-                               hipStream_t stream) {
+                               hipStream_t stream, unsigned long long *d_work) {
     if (n == 0) return hipSuccess;
     scratch_cache::lease mem;
     hipError_t e = scratch.take(2 * sizeof(unsigned long long), stream, &mem);
@@ -538,13 +550,22 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, con
     size_t g = (n + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
     const size_t cap = (size_t)num_cus * 4;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(extract_prefix_wave_kernel, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
-                       (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool);
+    if (d_work)
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
+    else
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
     hipLaunchKernelGGL(move_prefix_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
                        (const uint32_t *)d_plen, n);
-    hipLaunchKernelGGL(extract_postfix_wave_kernel, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
-                       select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
-                       (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1);
+    if (d_work)
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
+                           select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
+                           (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1, d_work + XW_WORDS);
+    else
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
+                           select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
+                           (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1, d_work + XW_WORDS);
     e = hipGetLastError();
     scratch.give(mem, stream);
     return e;

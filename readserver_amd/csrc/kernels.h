@@ -94,7 +94,9 @@ hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStrea
 // extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
 hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
-                               hipStream_t stream);
+                               hipStream_t stream, unsigned long long *d_work = nullptr);
+// d_work (counting mode): WORK_WORDS counters, zeroed by the caller: words 0-7 the prefix walk, 8-15 the
+// postfix walk (extract_lines.hip, XW_*)
 constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences: the window search spans a few windows
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,

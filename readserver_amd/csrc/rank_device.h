@@ -54,6 +54,90 @@ __device__ __forceinline__ uint32_t runs_scan(const uint32_t *r, uint32_t b, uin
     return acc;
 }
 
+// ---- whole-dword forms for the walk kernels (extract_lines.hip), where a lane has to find out WHICH
+// symbol sits at a position before it can rank it.  24 pieces = 6 dwords: dword totals come from
+// v_dot4, the dword holding the position from five compares, and only that dword's four pieces are
+// looked at one by one (prefix sums of its bytes = one multiply: 4 x 31 < 256).
+
+// b in every byte
+__device__ __forceinline__ uint32_t splat_byte(uint32_t b) { return __builtin_amdgcn_perm(0u, b, 0u); }
+
+// RLEBWT::getChar + RLEBWT::getOcc of that symbol (rlebwt.cpp:202-227,268-301) within 24 pieces: c =
+// rank (0..4) of the symbol of the piece holding the rem-th symbol (rem >= 1; c = 0 when the pieces
+// hold fewer, or rem == 0), occ = how many of the first rem symbols are c.  want != 0: the symbol is
+// known already (c = want), only its count is wanted.
+struct char_rank {
+    uint32_t c, occ;
+};
+__device__ __forceinline__ char_rank char_rank24(const uint32_t r[6], uint32_t rem, uint32_t want) {
+    uint32_t cum[7];
+    cum[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cum[i + 1] = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, 0x01010101u, cum[i], false);
+    uint32_t x = r[0], base = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        const bool past = rem > cum[i];
+        x = past ? r[i] : x;
+        base = past ? cum[i] : base;
+    }
+    const uint32_t rd = rem - base;
+    const uint32_t ps = (x & 0x1F1F1F1Fu) * 0x01010101u;  // bytes: symbols up to and including piece 0, 1, 2, 3
+    const uint32_t j = (rd > (ps & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 8) & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 16) & 0xFFu) ? 1u : 0u);
+    const bool found = rem != 0u && rd <= (ps >> 24);
+    const uint32_t here = (x >> (8u * j + 5u)) & 7u;
+    char_rank o;
+    o.c = want ? want : (found ? here : 0u);
+    const uint32_t pj = j ? __builtin_amdgcn_ubfe(ps, 8u * j - 8u, 8u) : 0u;  // symbols before piece j of the dword
+    const uint32_t bb = splat_byte(o.c);
+    uint32_t mcum = 0, before = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        mcum = dword_matched(r[i], bb, mcum);
+        before = rem > cum[i + 1] ? mcum : before;
+    }
+    const uint32_t xm = x & ((1u << (8u * j)) - 1u);  // the dword's pieces before piece j
+    const uint32_t inner = dword_matched(xm, bb, 0u);
+    // piece j counts up to the position (all of it when the position lies past the pieces) if it is
+    // a run of c -- always, unless c was given and differs
+    const uint32_t reach = found ? rd - pj : (rem ? (ps >> 24) - pj : 0u);
+    o.occ = before + inner + (here == o.c ? reach : 0u);
+    return o;
+}
+
+// BPTree::select's leaf step (BPTree.h:131-187) within 24 pieces: position (symbols from the first
+// piece, 0-based) of the t-th b (t >= 1); *left = what remains of t when the pieces hold fewer
+// (0: found; t == 0 gives position 0, left 0).
+__device__ __forceinline__ uint32_t select_in24(const uint32_t r[6], uint32_t b, uint32_t t, uint32_t *left) {
+    const uint32_t bb = splat_byte(b);
+    uint32_t cum[7], mat[7];
+    cum[0] = mat[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        cum[i + 1] = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, 0x01010101u, cum[i], false);
+        mat[i + 1] = dword_matched(r[i], bb, mat[i]);
+    }
+    uint32_t x = r[0], tb = 0, mb = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        const bool past = t > mat[i];
+        x = past ? r[i] : x;
+        tb = past ? cum[i] : tb;
+        mb = past ? mat[i] : mb;
+    }
+    *left = t > mat[6] ? t - mat[6] : 0u;
+    const uint32_t td = t - mb;
+    const uint32_t lx = x & 0x1F1F1F1Fu;
+    const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;
+    const uint32_t m01 = ((0x80808080u - z) >> 7) & 0x01010101u;
+    const uint32_t ps = lx * 0x01010101u;                   // symbols up to and including piece 0..3
+    const uint32_t qs = (lx & (m01 * 0xFFu)) * 0x01010101u;  // b's up to and including piece 0..3
+    const uint32_t j = (td > (qs & 0xFFu) ? 1u : 0u) + (td > ((qs >> 8) & 0xFFu) ? 1u : 0u) + (td > ((qs >> 16) & 0xFFu) ? 1u : 0u);
+    const uint32_t pj = j ? __builtin_amdgcn_ubfe(ps, 8u * j - 8u, 8u) : 0u;
+    const uint32_t qj = j ? __builtin_amdgcn_ubfe(qs, 8u * j - 8u, 8u) : 0u;
+    return t ? tb + pj + (td - qj) - 1u : 0u;
+}
+
 // w = p / S and p mod S for p < 2^40 (line_format.h, span_params): the f64 product's floor is w or
 // w - 1, one compare puts it right.  Any S works, so the window span follows the data instead of
 // the few divisors that have an exact 32-bit reciprocal.

@@ -994,3 +994,28 @@ def test_gpu_set_one_mismatch_over_the_shards(rsb, oracle):
 
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("span,long_runs,R,rows", [(0, 0, 30_000_000, 300_000), (2944, 0, 6_000_000, 300_000),
+                                                  (0, 1, 20_000_000, 200_000)])
+def test_gpu_extraction_equals_the_mirrors_walks(rsb, span, long_runs, R, rows):
+    """The wave-cooperative walks against the same walks taken step by step with the class-BWT
+    mirrors (readserver_amd/selfcheck.py), on indexes and row counts large enough for rare layout
+    cases: a select argument that outlasts a far line's 92 pieces must not find its symbol in the
+    link that follows them (seen once in 10^5 rows on a 20 GB shard before the hit was held to the
+    line's span; tools/check_extract_at_scale.py runs the same check there)."""
+    import ctypes as C
+    import torch
+    from readserver_amd import selfcheck
+    L = rsb.lib()
+    d_runs = torch.empty(R, dtype=torch.uint8, device="cuda:0")
+    assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, ((1 << 63) if long_runs else 0) | 77, 0, None) == 0
+    torch.cuda.synchronize()
+    with rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), ktab_depth=None, window_span=span) as g:
+        del d_runs
+        if span:
+            assert g.far_lines() > 0
+        r = np.random.default_rng(3).integers(0, g.getBWLen(), rows, dtype=np.uint64)
+        res = selfcheck.extraction_vs_mirrors(g, r, stride=1024)
+        assert res["rows_differing"] == 0, res

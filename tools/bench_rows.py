@@ -132,6 +132,15 @@ for h in shards:  # NR rows of every shard (row numbers are per shard: one call 
     steps += int(ln[fits].astype(np.int64).sum()) + 2 * int(fits.sum())  # one line per symbol + the two '$' steps
     nfit += int(fits.sum())
     bases += int(ln[fits].astype(np.int64).sum())
+# the walk kernels' own counters, from one counting run on the first shard
+ok(L.rsbwt_set_counting(g.handle, 1))
+run2(g)
+torch.cuda.synchronize()
+xw = (C.c_uint64 * 16)()
+ok(L.rsbwt_last_search_counters(g.handle, xw))
+ok(L.rsbwt_set_counting(g.handle, 0))
+names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "count_word_probes"]
+walk_counters = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
 reps = 3
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
@@ -147,6 +156,7 @@ out["extract"] = {
     "roofline": {"bound": "hbm", "achieved": steps * 128 / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                  "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel",
                  "algorithmic_bytes": steps * 128, "steps": steps},
+    "walk_counters_first_shard": walk_counters,
 }
 sset.close()
 for h in shards:
