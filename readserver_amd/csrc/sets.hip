@@ -99,6 +99,9 @@ struct rsbwt_set {
     std::vector<dev_group *> groups;
     bool comms_tried = false, comms_ok = false;
     std::mutex mu;
+    // Collectives on the set's communicators are enqueued by one thread at a time: two callers
+    // interleaving their group calls could reach the communicators in different orders.
+    std::mutex comm_mu;
 };
 
 namespace {
@@ -397,6 +400,7 @@ int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
         });
         // phase 2: one sum over the devices
         if (rc == RSBWT_OK && use_rccl) {
+            std::lock_guard<std::mutex> comm_lock(s->comm_mu);
             ncclResult_t nr = rccl().GroupStart();
             for (size_t gi = 0; gi < G && nr == ncclSuccess; ++gi) {
                 (void)hipSetDevice(s->groups[gi]->device);
@@ -507,6 +511,7 @@ int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, 
     if (G == 1) return RSBWT_OK;
     if (!ensure_comms(s)) return fail(RSBWT_ENODEV, "RCCL is not available: cannot gather across devices");
     size_t off = bytes[0];
+    std::lock_guard<std::mutex> comm_lock(s->comm_mu);
     ncclResult_t nr = rccl().GroupStart();
     for (size_t g = 1; g < G && nr == ncclSuccess; ++g) {
         (void)hipSetDevice(s->groups[g]->device);

@@ -9,7 +9,7 @@ needs), counted from the lengths extracted.  Prints one JSON line.
 With shards > 1 (BASELINE configs[3]/[4]: the 8 shards of one GPU) the 1-mismatch search runs over a
 shard set (rsbwt_set_find_intervals_1mm_dev, tables sized for the set) and rows are extracted from every
 shard in turn.
-usage: tools/bench_rows.py [run_bytes=2e10] [kmers=40000] [rows=2000000] [shards=1]"""
+usage: tools/bench_rows.py [run_bytes=2e10] [kmers=400000] [rows=2000000] [shards=1]"""
 import ctypes as C
 import json
 import os
@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import readserver_amd as rsb  # noqa: E402
 
 R = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000000
-M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 40000
+M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 400000
 NR = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2000000
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 k, PEAK = 31, 8000.0
