@@ -332,3 +332,43 @@ def test_gpu_service_loop_many_partitions(rsb, oracle, pb, tmp_path):
     ss.close()
     for g in shards:
         g.close()
+
+
+def test_zmq_transport_code_at_least_parses(tmp_path):
+    """libzmq is not in this image, so the ZeroMQ transport (service_loop.cpp, -DRSBWT_WITH_ZMQ) is
+    never linked here.  This only keeps it from rotting: the file is run through the compiler's
+    syntax pass against declarations of the ten libzmq entry points it uses (zmq.h 4.x signatures,
+    typed here -- not libzmq).  It says nothing about behaviour."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    (tmp_path / "zmq.h").write_text("""
+#pragma once
+#include <stddef.h>
+extern "C" {
+typedef struct zmq_msg_t { unsigned char _[64]; } zmq_msg_t;
+typedef struct zmq_pollitem_t { void *socket; int fd; short events; short revents; } zmq_pollitem_t;
+#define ZMQ_SUB 2
+#define ZMQ_PUSH 8
+#define ZMQ_SUBSCRIBE 6
+#define ZMQ_POLLIN 1
+void *zmq_ctx_new(void);
+int zmq_ctx_term(void *);
+void *zmq_socket(void *, int);
+int zmq_close(void *);
+int zmq_connect(void *, const char *);
+int zmq_setsockopt(void *, int, const void *, size_t);
+int zmq_poll(zmq_pollitem_t *, int, long);
+int zmq_msg_init(zmq_msg_t *);
+int zmq_msg_recv(zmq_msg_t *, void *, int);
+void *zmq_msg_data(zmq_msg_t *);
+int zmq_msg_close(zmq_msg_t *);
+int zmq_send(void *, const void *, size_t, int);
+}
+""")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "readserver_amd", "csrc", "service_loop.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DRSBWT_WITH_ZMQ", f"-I{tmp_path}", src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
