@@ -81,6 +81,16 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def search_kernel_name(nshards, n=0, ktab_depth=0, span=0):
+    """The kernel launch_search (csrc/search_lines.hip) picks: one lane per search for a full batch on
+    a single shard behind a deep k-mer table (4 n / 4^T <= S: capi.hip, search_dev), lane pairs
+    otherwise; RSBWT_SEARCH_KERNEL overrides."""
+    e = os.environ.get("RSBWT_SEARCH_KERNEL", "auto")
+    narrow = ktab_depth >= 2 and ((n >> (2 * ktab_depth)) << 2) <= span
+    solo = e == "solo" or (e not in ("pair", "solo") and nshards == 1 and narrow)
+    return "search_solo_kernel" if solo else "search_lines_kernel"
+
+
 def usable_cpus():
     n = len(os.sched_getaffinity(0))
     try:  # cgroup v2 quota
@@ -301,7 +311,7 @@ def main():
         b1 = (C.c_float * 64)()
         ok(L.rsbwt_search_history_ms(g0.handle, b1, n1, C.byref(cnt)))
         km1 = float(np.mean(list(b1[:cnt.value])))
-        single = {"searches_per_s": Q / d1, "kernel_ms": km1, "mean_lf_steps_per_search": w1[0] / Q,
+        single = {"searches_per_s": Q / d1, "kernel": search_kernel_name(1, int(g0.getBWLen()), g0.ktab_depth(), g0.window_span()), "kernel_ms": km1, "mean_lf_steps_per_search": w1[0] / Q,
                   "roofline_frac": (w1[2] * LINE_BYTES + Q * SEARCH_BYTES) / (km1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del lo1, up1
 
@@ -342,7 +352,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(R, Q, S, k, a.stream),
-            "kernel": "search_lines_kernel", "kernel_ms": avg_kernel_ms,
+            "kernel": search_kernel_name(S, int(n_sym), shards[0].ktab_depth(), shards[0].window_span()), "kernel_ms": avg_kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "line_reads_per_launch": ln,
             "continuation_line_reads_per_launch": hops, "occ_lookups_per_launch": oc,
             "ktab_starts_per_launch": kt, "phase_stamps": phases,

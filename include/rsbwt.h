@@ -204,7 +204,9 @@ int rsbwt_set_counting(rsbwt_t *h, int on);
 int rsbwt_last_search_work(rsbwt_t *h, uint64_t *lf_steps, uint64_t *occ_lookups,
                            uint64_t *line_reads);
 /* all 16 counter words: 0 LF steps, 1 Occ lookups, 2 window lines read, 3 k-mer-table starts,
- * 4..9 phase cycles, 10 passes, 11 continuation (spill / far) lines read.
+ * 4..9 phase cycles (lane-pair kernel only), 10 passes, 11 continuation (spill / far) lines read,
+ * 12 = 1 when the launch ran one lane per search (a full batch on a single shard behind a deep k-mer
+ * table; csrc/search_solo.h), 0 on lane pairs.
  * After an rsbwt_extract_dev in counting mode the words are the walk kernels' instead: 0..7 the LF
  * (prefix) walk, 8..15 the select (postfix) walk, each {passes, lanes holding a row over those
  * passes, steps completed, lanes on a continuation line, lines fetched, cycles, cycles from issuing

@@ -689,7 +689,9 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
     int rc = use_device(h->device);
     if (rc) return rc;
     if (h->view.n == 0 && Q) return fail(RSBWT_EINVAL, "empty index");
-    return search_launch(*h, h->d_view, 1, h->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, stream, extra);
+    search_extra ex = extra ? *extra : search_extra();
+    ex.narrow = view_is_narrow(h->view, k);
+    return search_launch(*h, h->d_view, 1, h->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper, counts_only, stream, &ex);
 }
 
 // Host buffers: slices of at most 2M k-mers alternate between the context's two streams and two

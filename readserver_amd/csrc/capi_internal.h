@@ -57,6 +57,11 @@ int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, 
 int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
                       const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
                       bool counts_only);
+// search_extra::narrow for a launch on this shard alone: a T-mer's interval is ~ n / 4^T rows wide;
+// a quarter of a window or less = the steps after the table find both positions in one line
+inline bool view_is_narrow(const shard_view &v, uint32_t k) {
+    return v.ktab && v.ktab_depth >= 2u && k >= v.ktab_depth && ((v.n >> (2u * v.ktab_depth)) << 2) <= v.sp.S;
+}
 int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
 int meter_work(search_meter &m, uint64_t *words, size_t nwords);
 

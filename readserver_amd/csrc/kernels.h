@@ -60,6 +60,9 @@ struct search_extra {
     uint32_t trace_n = 0, variants = 0;
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
     bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
+    // the k-mer table leaves intervals well inside a window (n / 4^T << S): most steps of a search find
+    // both positions in one line, which is what the one-lane-per-search kernel is for (search_solo.h)
+    bool narrow = false;
 };
 hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                          const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "kernels.h"
 #include "line_format.h"
@@ -113,7 +114,7 @@ search_init_1mm_kernel(const shard_view *__restrict__ shard, const uint64_t *__r
 }
 
 // work[] of a counting launch
-enum { WORK_STEPS = 0, WORK_OCC = 1, WORK_LINES = 2, WORK_KTAB = 3, WORK_PHASE0 = 4, WORK_PASSES = 10, WORK_HOPS = 11 };
+enum { WORK_STEPS = 0, WORK_OCC = 1, WORK_LINES = 2, WORK_KTAB = 3, WORK_PHASE0 = 4, WORK_PASSES = 10, WORK_HOPS = 11, WORK_SOLO = 12 };
 
 // LONGK: k > 32, i.e. a query spans several packed words.  A template parameter because with the
 // reload on the path -- however it is guarded at run time -- hipcc waits for vmcnt(0) at the top of
@@ -512,6 +513,36 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
 #undef STAMP
 }
 
+}  // namespace rsb
+#include "search_solo.h"
+namespace rsb {
+
+// Which kernel a plain search runs on.  RSBWT_SEARCH_KERNEL = pair | solo | auto (default).
+static int search_kernel_choice() {
+    static const int choice = [] {
+        const char *e = getenv("RSBWT_SEARCH_KERNEL");
+        if (e && !strcmp(e, "pair")) return 0;
+        if (e && !strcmp(e, "solo")) return 1;
+        return 2;
+    }();
+    return choice;
+}
+
+template <bool CW, bool CO>
+static void launch_solo(int grid, hipStream_t stream, const shard_view *shards, uint32_t nshards, const uint64_t *pk,
+                        const ulonglong2 *init, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
+                        uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n,
+                        uint32_t pairs) {
+    uint32_t qchunk = 1024;
+    while (qchunk > 64u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
+    if (wpq > 1)
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+    else
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+}
+
 template <bool CW, bool CO>
 static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uint32_t nshards, const uint64_t *pk,
                      const ulonglong2 *init, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
@@ -541,9 +572,15 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
     const uint32_t trace_n = extra ? extra->trace_n : 0u;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    // 32 searches per wave, 4 waves per workgroup
-    const size_t per_wg = 32u * WG_WAVES;
-    size_t g = (Q * nshards + per_wg - 1) / per_wg;
+    // one lane per search (search_solo.h) where intervals are narrow for most of a search: a single
+    // shard whose k-mer table is deep (extra->narrow: what is left of a hit are steps inside one
+    // window); several shards per launch run at the request ceiling on lane pairs already, and behind
+    // a shallow table the first steps are wide, where pairs take one pass and a lone lane two
+    // (and only when the batch fills every lane of the launch: below that nothing is saturated and the
+    // pairs answer sooner -- a lone request of the service loop takes half the passes)
+    const bool table_build = extra && extra->table_build;
+    const int choice = search_kernel_choice();
+    size_t g = 0;
     // Workgroups per CU: LDS admits 5 (20 waves), but 4 are as fast (the request path, not the
     // number of lookups in flight, is what saturates) and leave 32 KB of LDS and wave slots per CU
     // to kernels that run beside the search -- RCCL's, when the previous batch's intervals are
@@ -554,6 +591,10 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         return v > 0 ? v : RSB_MIN_WGS_PER_CU;
     }();
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    const bool solo = !table_build && (choice == 1 || (choice == 2 && nshards == 1 && extra && extra->narrow && Q >= cap * WG_WAVES * 64u));
+    // 32 (pairs) or 64 (solo) searches per wave, 4 waves per workgroup
+    const size_t per_wg = (solo ? 64u : 32u) * WG_WAVES;
+    g = (Q * nshards + per_wg - 1) / per_wg;
     if (g > cap) g = cap;
     const int grid = (int)g;
     const uint64_t *pk = (const uint64_t *)d_packed;
@@ -584,6 +625,14 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         while (qchunk > 32u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
         hipLaunchKernelGGL((search_lines_kernel<false, false, false, 1>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, d_shards,
                            nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, qchunk, 0u);
+    } else if (solo) {
+        if (d_work) {
+            if (counts_only) launch_solo<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+            else launch_solo<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+        } else {
+            if (counts_only) launch_solo<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+            else launch_solo<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+        }
     } else if (d_work) {
         if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
         else launch_k<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);

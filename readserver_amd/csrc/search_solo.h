@@ -1,0 +1,374 @@
+// search_solo.h -- the search kernel with ONE LANE PER SEARCH (included by search_lines.hip only).
+//
+// search_lines_kernel gives a search two lanes, one per side of updateInterval (query.cpp:11-15), so
+// a step is one pass and a wave has 64 lookups in flight for 32 searches.  Deep in a search the
+// interval is narrower than a window: both positions then lie in the same line, the pair fetches it
+// once and half of the wave's fetch slots stay empty -- on one shard with a deep k-mer table that is
+// nearly every pass, and the launch falls short of the request rate the memory system can take.
+// Here a lane owns a whole search: it looks up Occ(b, lower - 1); when upper lies within the symbols
+// the same line holds (the usual case once the interval is narrow) Occ(b, upper) is ranked out of the
+// same staged line in the same pass, otherwise upper is a lookup of its own in the next pass.  64
+// searches per wave keep 64 lookups in flight whatever the intervals' width; a wide interval costs
+// two passes per step instead of one, which a request-bound launch does not feel.
+// Same start records, results, trace and counters as search_lines_kernel.
+#ifndef RSBWT_SEARCH_SOLO_H
+#define RSBWT_SEARCH_SOLO_H
+
+namespace rsb {
+
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK>
+__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                   const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
+                   size_t Q, uint32_t k, uint32_t wpq,
+                   uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
+                   unsigned long long *__restrict__ work,
+                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs) {
+    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint4 *stage = s_stage[wave];
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
+    const uint32_t swz = lane & 7u;
+    const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
+#define SOLO_MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
+
+    unsigned long long w_steps = 0, w_occ = 0, w_lines = 0, w_hops = 0, w_ktab = 0, passes = 0;
+
+    uint32_t sid = blockIdx.x % nshards;
+    for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
+        const shard_view *sv = shards + sid;
+        const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
+        const uint32_t S = sv->sp.S;
+        const double inv = sv->sp.inv;
+        const uint32_t nlines = (uint32_t)sv->nlines;
+        const bool ktab = view_uses_ktab(*sv, k);
+        const int j_table = ktab ? (int)(k - sv->ktab_depth) - 1 : (int)k - 2;
+        const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
+        const ulonglong2 *init_s = init + (size_t)sid * Q;
+        uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
+        uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
+        unsigned long long *pool = next_query + sid;
+        // C[1..4] in lanes 0..3, picked with ds_bpermute (scalar loads: see search_lines_kernel)
+        uint32_t ctab_lo, ctab_hi;
+        {
+            const uint64_t c1 = sv->C[1], c2 = sv->C[2], c3 = sv->C[3], c4 = sv->C[4];
+            const uint32_t l3 = lane & 3u;
+            const uint64_t cv = l3 == 0u ? c1 : l3 == 1u ? c2 : l3 == 2u ? c3 : c4;
+            ctab_lo = (uint32_t)cv;
+            ctab_hi = (uint32_t)(cv >> 32);
+        }
+
+        const uint32_t QCHUNK = qchunk;
+        uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
+        bool drained = false;
+        size_t q = 0;  // the query this lane is stepping
+        bool has_q = false;
+        size_t nq = 0;  // the one it runs next, start record already prefetched
+        bool has_n = false;
+        ulonglong2 nrec = {0, 0};
+        uint64_t nword = 0;
+        int j = 0;
+        uint64_t word = 0, lo = 0, hi = 0;
+        // the step under way: sub 0 = looking up Occ(b, lower - 1), 1 = Occ(b, upper) with occL held;
+        // cont != 0 = the lookup goes on in the group's spill line / a far line (as in the pair kernel)
+        uint32_t sub = 0;
+        uint64_t occL = 0, cacc = 0;
+        uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0, w = 0;
+
+        for (;;) {
+            // ---- a lane whose query ended in the last pass takes up the one it had prefetched
+            bool done = false;
+            if (!has_q && has_n) {
+                has_q = true;
+                has_n = false;
+                q = nq;
+                sub = 0;
+                cont = 0;
+                if (nrec.x & INIT_INVALID) {
+                    lo = 1;
+                    hi = 0;
+                    j = -1;
+                    done = true;
+                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search
+                    lo = nrec.x & COUNT_MASK;
+                    hi = nrec.y;
+                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                    word = nword;
+                    done = lo > hi;
+                    if (LONGK) {
+                        if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                    }
+                } else {
+                    const bool fallback = !ktab || (nrec.x & INIT_FALLBACK) != 0ull;
+                    lo = nrec.x & COUNT_MASK;
+                    hi = nrec.y;
+                    j = fallback ? (int)k - 2 : j_table;
+                    word = nword;
+                    if (COUNT_WORK && !fallback) w_ktab += 1;
+                    done = (j < 0) || (!fallback && lo > hi);  // query.cpp:35-37
+                    if (LONGK) {
+                        if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                    }
+                }
+            }
+            // ---- hand the next queries to the lanes that have none in reserve
+            if (pool_next >= pool_end && !drained) {
+                unsigned long long c = 0;
+                if (lane == 0u) c = atomicAdd(pool, (unsigned long long)QCHUNK);
+                c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                    __builtin_amdgcn_readfirstlane((uint32_t)c);
+                pool_next = c;
+                pool_end = c + QCHUNK < Q ? c + QCHUNK : Q;
+                if (c >= Q) { drained = true; pool_next = pool_end = 0; }
+            }
+            bool got_n = false;
+            {
+                const uint64_t want_mask = __builtin_amdgcn_ballot_w64(!has_n);
+                const uint32_t before = (uint32_t)__builtin_popcountll(want_mask & ((1ull << lane) - 1ull));
+                const uint64_t mine = pool_next + before;
+                if (!has_n && mine < pool_end) {
+                    nq = (size_t)mine;
+                    got_n = true;
+                }
+                const uint64_t taken = pool_next + (uint32_t)__builtin_popcountll(want_mask);
+                pool_next = taken < pool_end ? taken : pool_end;
+            }
+            if (__builtin_amdgcn_ballot_w64(has_q || got_n) == 0ull) {
+                if (drained) break;
+                continue;  // pool exhausted mid-pass: refill at the top
+            }
+            // the two start-up loads of a query taken into reserve fly with this pass's line fetches
+            ulonglong2 rec = {0, 0};
+            uint64_t first_word = 0;
+            if (got_n) {
+                rec = init_s[nq];
+                first_word = packed[nq * wpq + w_table];
+            }
+            const bool alive = has_q;
+            const bool stepping = alive && !done;
+            const bool fresh = stepping && cont == 0u;  // starts a lookup (of either position)
+
+            // ---- this lane's lookup: symbol, position -> window line
+            uint32_t b = 1, line = 0, o = 0;
+            if (stepping) {
+                if (LONGK) {
+                    if (fresh && sub == 0u && (j & 31) == 31) word = packed[q * wpq + ((uint32_t)j >> 5)];
+                }
+                b = (uint32_t)((word >> (2u * ((uint32_t)j & 31u))) & 3u) + 1u;
+            }
+            bool no_fetch = false;  // Occ(b, -1) = 0 on the upper side too: the step completes without a line
+            if (fresh) {
+                if (sub == 0u) {
+                    // traced search (1-mismatch): the interval this query has when about to take symbol j
+                    if (trace && (uint32_t)j < trace_n) trace[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
+                    if (lo == 0ull) {  // Occ(b, -1) = 0 (rlebwt.cpp:269)
+                        occL = 0;
+                        sub = 1u;
+                    }
+                }
+                // upper = 0 + 0 - 1 wraps after a step that found no b at the top of the BWT; the reference
+                // carries on the same way and reports the empty interval one step later (query.cpp:11-15,35)
+                const uint64_t p = sub ? hi : lo - 1ull;
+                if (p == ~0ull) {
+                    no_fetch = true;
+                } else {
+                    uint32_t pin;
+                    w = fast_window(p, S, inv, pin);
+                    line = w + (w >> GROUP_SHIFT);
+                    o = pin + 1u;
+                    if (line >= nlines) line = 0;  // never for p < n; keeps a bad position from faulting
+                    if (COUNT_WORK) w_occ += 1;
+                }
+            }
+            const bool looking = stepping && !no_fetch;
+            // C[b], with every lane active: a ds_bpermute returns 0 from a masked-off source lane
+            const uint64_t pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_hi) << 32) |
+                                (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b - 1u) << 2), (int)ctab_lo);
+
+            // ---- fetch: every looking lane its line
+            const uint32_t want = looking ? (cont ? cblk : line) : ~0u;
+            if (COUNT_WORK && want != ~0u) {
+                if (cont) w_hops += 1;
+                else w_lines += 1;
+            }
+            glds_fetch(lines_bytes, want, lane, stage_lds);
+            glds_wait();
+
+            // ---- Occ(b, p) out of this lane's staged line (RLEBWT::getOcc, rlebwt.cpp:268-301)
+            bool do_scan = false, own_line = false;
+            uint64_t base = 0, cnt_b = 0;
+            uint32_t dw = HDR_DWORDS, rem = 0, oe_here = 0;
+            uint32_t s1 = 0, s2 = 0, s3 = 0, span = 0, hb = 0;
+            const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte
+            if (looking) {
+                if (cont != KIND_CHUNK) {
+                    const uint32_t oe = cont ? co : o;
+                    const uint2 cw = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(2u * (b - 1u)));
+                    const uint4 h0 = *reinterpret_cast<const lds_u4 *>(SOLO_MINE(0));
+                    const uint64_t cnt = ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
+                    const uint32_t m0 = h0.y >> 8, m1 = h0.w >> 8;
+                    s1 = m0 & 0x3FFu;
+                    s2 = (m0 >> 10) & 0x7FFu;
+                    s3 = s2 + (m1 & 0x3FFu);
+                    span = s3 + ((m1 >> 10) & 0x3FFu);
+                    const uint32_t kind = (m1 >> 20) & 3u;
+                    if (oe <= span) {
+                        const uint32_t cq = (oe > s1 ? 1u : 0u) + (oe > s2 ? 1u : 0u) + (oe > s3 ? 1u : 0u);
+                        const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+                        const uint32_t hm = *SOLO_MINE(5u + 2u * ((b - 1u) >> 1)) >> 8;
+                        hb = (hm >> (11u * ((b - 1u) & 1u))) & 0x7FFu;  // what quarters 0 and 1 hold of b
+                        const uint32_t qd = HDR_DWORDS + 6u * (cq & 2u);
+                        const uint2 x0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd));
+                        const uint2 x1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 2u));
+                        const uint2 x2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 4u));
+                        uint32_t m = dword_matched(x0.x, bb, 0u);
+                        m = dword_matched(x0.y, bb, m);
+                        m = dword_matched(x1.x, bb, m);
+                        m = dword_matched(x1.y, bb, m);
+                        m = dword_matched(x2.x, bb, m);
+                        m = dword_matched(x2.y, bb, m);
+                        base = cnt + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
+                        dw = HDR_DWORDS + 6u * cq;
+                        rem = oe - start;
+                        do_scan = true;
+                        own_line = true;  // the staged line's own pieces hold the position: they may hold upper too
+                        oe_here = oe;
+                        cnt_b = cnt;
+                    } else if (kind == KIND_FAR) {
+                        cblk = *SOLO_MINE(LINE_DWORDS - 1u);
+                        if (cblk >= nlines) cblk = 0;  // never for a built index
+                        cont = KIND_FAR;
+                        co = oe - span;
+                    } else if (kind == KIND_CHUNK && cont == 0u) {
+                        const uint32_t m2 = *SOLO_MINE(5) >> 8, m3 = *SOLO_MINE(7) >> 8;
+                        cacc = cnt;
+                        cdw = 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
+                        cblk = (w >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
+                        if (cblk >= nlines) cblk = 0;  // never for p < n
+                        cont = KIND_CHUNK;
+                        co = oe - span;
+                    } else {  // a position beyond what the index holds: never for p < n
+                        base = cnt;
+                        do_scan = true;
+                    }
+                } else {
+                    // the spill chunk: what the window's own 96 pieces hold of b, then the excess pieces
+                    const uint2 hd = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(cdw));
+                    const uint32_t hw = (b <= 2u) ? hd.x : hd.y;
+                    const uint32_t tot = (hw >> (12u * ((b - 1u) & 1u))) & 0xFFFu;
+                    base = cacc + tot;
+                    dw = cdw + 2u;
+                    rem = co;
+                    do_scan = true;
+                }
+                // a window has at most 33 lines: the bound only guards against a corrupt chain
+                if (!do_scan && ++tries > 72u) do_scan = true;
+            }
+            uint64_t occ = 0;
+            {
+                const uint2 y0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw & 31u));
+                const uint2 y1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE((dw + 2u) & 31u));
+                const uint2 y2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE((dw + 4u) & 31u));
+                const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
+                occ = base + runs_scan<6>(r6, b, rem);
+            }
+            // ---- upper out of the same line: lower - 1 was found among the line's own pieces, and
+            // upper lies d symbols further on, still among them
+            bool step_done = false;
+            uint64_t occU = 0;
+            bool second = false;
+            uint32_t oh = 0;
+            if (do_scan) {
+                cont = 0;
+                tries = 0;
+                if (sub == 0u) {
+                    occL = occ;
+                    sub = 1u;
+                    const uint64_t d = hi - (lo - 1ull);  // >= 1 for a live interval
+                    if (own_line && d <= (uint64_t)(span - oe_here)) {
+                        second = true;
+                        oh = oe_here + (uint32_t)d;
+                    }
+                } else {
+                    occU = occ;
+                    step_done = true;
+                }
+            }
+            {
+                // (every lane takes part; only `second` lanes use the result)
+                const uint32_t cq = (oh > s1 ? 1u : 0u) + (oh > s2 ? 1u : 0u) + (oh > s3 ? 1u : 0u);
+                const uint32_t start = cq == 0u ? 0u : cq == 1u ? s1 : cq == 2u ? s2 : s3;
+                const uint32_t qd = HDR_DWORDS + 6u * (cq & 2u);
+                const uint2 x0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd));
+                const uint2 x1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 2u));
+                const uint2 x2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 4u));
+                uint32_t m = dword_matched(x0.x, bb, 0u);
+                m = dword_matched(x0.y, bb, m);
+                m = dword_matched(x1.x, bb, m);
+                m = dword_matched(x1.y, bb, m);
+                m = dword_matched(x2.x, bb, m);
+                m = dword_matched(x2.y, bb, m);
+                const uint32_t dw2 = HDR_DWORDS + 6u * cq;
+                const uint2 y0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2));
+                const uint2 y1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2 + 2u));
+                const uint2 y2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2 + 4u));
+                const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
+                const uint32_t sc = runs_scan<6>(r6, b, second ? oh - start : 0u);
+                if (second) {
+                    occU = cnt_b + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u) + sc;
+                    step_done = true;
+                    if (COUNT_WORK) w_occ += 1;
+                }
+            }
+            if (stepping && no_fetch) {  // upper == 2^64 - 1: Occ = 0 without a line (only on the upper side)
+                occU = 0;
+                step_done = true;
+            }
+            // ---- updateInterval (query.cpp:11-15)
+            if (step_done) {
+                if (COUNT_WORK) w_steps += 1;
+                lo = pb + occL;
+                hi = pb + occU - 1ull;
+                --j;
+                done = (lo > hi) || (j < 0);  // query.cpp:35-37
+                sub = 0;
+            }
+            if (got_n) {
+                nrec = rec;
+                nword = first_word;
+                has_n = true;
+            }
+            if (alive && done) {
+                if (trace) {
+                    // the positions it never reached: a search resumed there ends where this one did
+                    for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
+                        trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
+                }
+                if (COUNTS_ONLY) {
+                    out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                } else if (pairs) {
+                    reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
+                } else {
+                    out_lo[q] = lo;
+                    out_up[q] = hi;
+                }
+                has_q = false;
+            }
+            if (COUNT_WORK) ++passes;
+        }
+    }
+    if (COUNT_WORK) {
+        if (lane == 0u) atomicAdd(&work[WORK_PASSES], passes);
+        if (threadIdx.x == 0u && blockIdx.x == 0u) work[WORK_SOLO] = 1ull;  // which kernel ran
+        if (w_steps) atomicAdd(&work[WORK_STEPS], w_steps);
+        if (w_occ) atomicAdd(&work[WORK_OCC], w_occ);
+        if (w_lines) atomicAdd(&work[WORK_LINES], w_lines);
+        if (w_ktab) atomicAdd(&work[WORK_KTAB], w_ktab);
+        if (w_hops) atomicAdd(&work[WORK_HOPS], w_hops);
+    }
+#undef SOLO_MINE
+}
+
+}  // namespace rsb
+#endif

@@ -445,8 +445,10 @@ int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const voi
     dev_group *g = s->groups[0];
     int rc = use_device(g->device);
     if (rc) return rc;
+    search_extra ex;
+    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper,
-                         false, (hipStream_t)stream, nullptr);
+                         false, (hipStream_t)stream, &ex);
 }
 
 int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
@@ -458,6 +460,7 @@ int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, cons
     if (rc) return rc;
     search_extra ex;
     ex.pairs = true;
+    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_pairs, nullptr,
                          false, (hipStream_t)stream, &ex);
 }
@@ -469,8 +472,10 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
     dev_group *g = s->groups[0];
     int rc = use_device(g->device);
     if (rc) return rc;
+    search_extra ex;
+    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_counts, nullptr,
-                         true, (hipStream_t)stream, nullptr);
+                         true, (hipStream_t)stream, &ex);
 }
 
 // 1-mismatch search over the shards of a one-device set.  A traced / resumed search belongs to one

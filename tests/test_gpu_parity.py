@@ -1019,3 +1019,59 @@ def test_gpu_extraction_equals_the_mirrors_walks(rsb, span, long_runs, R, rows):
         r = np.random.default_rng(3).integers(0, g.getBWLen(), rows, dtype=np.uint64)
         res = selfcheck.extraction_vs_mirrors(g, r, stride=1024)
         assert res["rows_differing"] == 0, res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,T,span", [(31, None, 0), (31, 8, 2944), (40, 10, 0), (12, 12, 300)])
+def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k, T, span):
+    """A single shard and a batch of >= 262,144 k-mers: launch_search takes the one-lane-per-search
+    kernel (search_solo.h; smaller batches and shard sets stay on lane pairs).  Intervals, counts and
+    {lower, upper} pairs against the oracle; the work counters of a counting launch add up."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    R, Q = 2_500_000, 300_000
+    runs = np.empty(R, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 4100 + k) == 0
+    oix = oracle.from_runs(runs)
+    rng = np.random.default_rng(k)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with rsb.GpuBWT(runs=runs, ktab_depth=(0 if T is None else T), window_span=span) as g:
+        km = _random_kmers(rng, Q, k)
+        d_half = torch.empty((Q // 2, k), dtype=torch.uint8, device="cuda:0")
+        assert L.rsbwt_sample_present_kmers_dev(g.handle, Q // 2, k, k, 5, p(d_half), None) == 0
+        torch.cuda.synchronize()
+        km[::2] = d_half.cpu().numpy()
+        km[11, 0] = ord("N")
+        km[12] = ord("A")
+        km[13] = ord("T")
+        elo, eup, st = oix.find_intervals(km, nthreads=8, want_steps=True)
+        wpq = (k + 31) // 32
+        d_km = torch.from_numpy(km).cuda()
+        d_pk = torch.empty((Q, wpq), dtype=torch.int64, device="cuda:0")
+        d_ok = torch.empty(Q, dtype=torch.uint8, device="cuda:0")
+        d_lo = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+        d_up = torch.empty(Q, dtype=torch.int64, device="cuda:0")
+        d_pr = torch.empty((Q, 2), dtype=torch.int64, device="cuda:0")
+        assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, None) == 0
+        assert L.rsbwt_set_counting(g.handle, 1) == 0
+        assert L.rsbwt_find_intervals_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), p(d_up), None) == 0
+        torch.cuda.synchronize()
+        w = (C.c_uint64 * 16)()
+        assert L.rsbwt_last_search_counters(g.handle, w) == 0
+        assert L.rsbwt_set_counting(g.handle, 0) == 0
+        lo, up = d_lo.cpu().numpy().view(np.uint64), d_up.cpu().numpy().view(np.uint64)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+        Td = g.ktab_depth()
+        steps = int(np.maximum(st.astype(np.int64) - (max(Td, 1) - 1 if k >= Td else 0), 0).sum())
+        assert w[0] == steps and w[2] <= w[1] <= 2 * w[0]
+        assert w[12] == 1  # one lane per search
+        assert L.rsbwt_find_interval_pairs_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_pr), None) == 0
+        assert L.rsbwt_count_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), None) == 0
+        torch.cuda.synchronize()
+        pr = d_pr.cpu().numpy().view(np.uint64)
+        assert np.array_equal(pr[:, 0], elo) and np.array_equal(pr[:, 1], eup)
+        assert np.array_equal(d_lo.cpu().numpy().view(np.uint64), np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64))
+        # the host entry point of the same batch (slices of 64K k-mers: lane pairs) agrees
+        hlo, hup = rsb.find_intervals(g, km[:70000])
+        assert np.array_equal(hlo, elo[:70000]) and np.array_equal(hup, eup[:70000])
