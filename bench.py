@@ -76,7 +76,7 @@ def parse():
 def kernel_source_sha():
     """Identifies the search kernel + layout a PMC traffic figure was measured on."""
     h = hashlib.sha256()
-    for f in ("search_lines.hip", "line_format.h", "rank_device.h"):
+    for f in ("search_lines.hip", "search_solo.h", "wave_lines.h", "line_format.h", "rank_device.h"):
         h.update(open(os.path.join(ROOT, "readserver_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
