@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Soak of the C-ABI's thread-safety claim (include/rsbwt.h: every query entry point is re-entrant; the
+reference answers from 8 + 64 pool threads on one shared index, src/service/service.cpp:88-89): N host
+threads call the host entry points of two shards and their set at random for a fixed time, with batch
+sizes from 1 to tens of thousands, and every answer is compared with the answer the same call gave
+single-threaded before the soak.  Also records the slowest call of each kind (a stall of seconds in one
+call in a few thousand is how the hipMallocAsync problem of profiles/r02d_latency.md showed).
+Prints one JSON line; exit code 1 on any mismatch or error.
+usage: tools/soak.py [seconds=120] [threads=8] [run_bytes=5e8]"""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import readserver_amd as rsb  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+R = int(float(sys.argv[3])) if len(sys.argv) > 3 else 500000000
+L = rsb.lib()
+k = 31
+shards = []
+for s in range(2):
+    runs = np.empty(R, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 31337 + s) == 0
+    shards.append(rsb.GpuBWT(runs=runs))
+    del runs
+sset = rsb.ShardSet(shards)
+g = shards[0]
+n = g.getBWLen()
+rng = np.random.default_rng(1)
+POOL = 60000
+km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (POOL, k))].copy()
+rows = rng.integers(0, n, 20000, dtype=np.uint64)
+# answers of the whole pools, single-threaded
+ref_lo, ref_up = rsb.find_intervals(g, km)
+ref_cnt = rsb.count_kmers(g, km)
+ref_slo, ref_sup = sset.find_intervals(km)
+ref_scnt = sset.count(km)
+out = np.zeros((rows.size, 1024), np.uint8)
+ln = np.empty(rows.size, np.uint32)
+pl = np.empty(rows.size, np.uint32)
+assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
+ref_out, ref_ln, ref_pl = out, ln, pl
+ref_1lo, ref_1up = rsb.find_intervals_1mm(g, km[:2000])
+
+stats = {}
+errors = []
+lock = threading.Lock()
+stop_at = time.time() + SECONDS
+
+
+def note(kind, dt):
+    with lock:
+        c = stats.setdefault(kind, {"calls": 0, "worst_ms": 0.0, "total_s": 0.0})
+        c["calls"] += 1
+        c["total_s"] += dt
+        c["worst_ms"] = max(c["worst_ms"], dt * 1e3)
+
+
+def worker(seed):
+    r = np.random.default_rng(seed)
+    try:
+        while time.time() < stop_at:
+            op = int(r.integers(0, 6))
+            size = int(2 ** r.uniform(0, 15.5))
+            a = int(r.integers(0, POOL - size))
+            t0 = time.perf_counter()
+            if op == 0:
+                lo, up = rsb.find_intervals(g, km[a:a + size])
+                ok = np.array_equal(lo, ref_lo[a:a + size]) and np.array_equal(up, ref_up[a:a + size])
+                kind = "find_intervals"
+            elif op == 1:
+                ok = np.array_equal(rsb.count_kmers(g, km[a:a + size]), ref_cnt[a:a + size])
+                kind = "count"
+            elif op == 2:
+                lo, up = sset.find_intervals(km[a:a + size])
+                ok = np.array_equal(lo, ref_slo[:, a:a + size]) and np.array_equal(up, ref_sup[:, a:a + size])
+                kind = "set_find_intervals"
+            elif op == 3:
+                ok = np.array_equal(sset.count(km[a:a + size]), ref_scnt[a:a + size])
+                kind = "set_count"
+            elif op == 4:
+                m = min(size, 5000)
+                b = int(r.integers(0, rows.size - m))
+                o = np.zeros((m, 1024), np.uint8)
+                l1 = np.empty(m, np.uint32)
+                p1 = np.empty(m, np.uint32)
+                rc = L.rsbwt_extract(g.handle, rows[b:b + m].ctypes.data, m, o.ctypes.data, 1024, l1.ctypes.data, p1.ctypes.data)
+                ok = rc == 0 and np.array_equal(l1, ref_ln[b:b + m]) and np.array_equal(p1, ref_pl[b:b + m])
+                fits = l1 != 0xFFFFFFFF
+                ok = ok and all(np.array_equal(o[i, :l1[i]], ref_out[b + i, :l1[i]]) for i in np.nonzero(fits)[0][:200])
+                kind = "extract"
+            else:
+                m = min(size, 500)
+                b = int(r.integers(0, 2000 - m))
+                lo, up = rsb.find_intervals_1mm(g, km[b:b + m])
+                ok = np.array_equal(lo, ref_1lo[b:b + m]) and np.array_equal(up, ref_1up[b:b + m])
+                kind = "find_intervals_1mm"
+            note(kind, time.perf_counter() - t0)
+            if not ok:
+                with lock:
+                    errors.append(f"{kind}: answers differ (size {size}, offset {a})")
+                return
+    except Exception as e:  # noqa: BLE001
+        with lock:
+            errors.append(repr(e))
+
+
+threads = [threading.Thread(target=worker, args=(100 + i,)) for i in range(NT)]
+t0 = time.time()
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+res = {"seconds": round(time.time() - t0, 1), "threads": NT, "run_bytes_per_shard": R, "symbols_per_shard": int(n),
+       "calls": {k_: {"calls": v["calls"], "mean_ms": round(v["total_s"] / v["calls"] * 1e3, 3), "worst_ms": round(v["worst_ms"], 2)}
+                 for k_, v in sorted(stats.items())},
+       "errors": errors[:5]}
+print(json.dumps(res))
+sset.close()
+for s in shards:
+    s.close()
+sys.exit(1 if errors else 0)
