@@ -372,3 +372,42 @@ int zmq_send(void *, const void *, size_t, int);
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DRSBWT_WITH_ZMQ", f"-I{tmp_path}", src],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_decoder_and_config_reader_survive_garbage(rsb, tmp_path):
+    """Hostile bytes: the Request decoder and the service.cfg reader are fed random and mutated inputs;
+    they may refuse them, they may not crash, hang or read past the buffer (ASan-clean by construction:
+    every length is checked against the bytes left before it is used)."""
+    L = rsb.lib()
+    rng = np.random.default_rng(12345)
+    good = bytes([0x08, 0x01, 0x10, 0x01, 0x1A, 0x05]) + b"ACGTA"
+    t, rt, q, ql = C.c_int(), C.c_int(), C.c_char_p(), C.c_size_t()
+    assert L.rsbwt_proto_decode_request(good, len(good), C.byref(t), C.byref(rt), C.byref(q), C.byref(ql)) == 0
+    assert (t.value, rt.value, ql.value) == (1, 1, 5)
+    for i in range(20000):
+        if i % 2:
+            blob = rng.integers(0, 256, int(rng.integers(0, 64)), dtype=np.uint8).tobytes()
+        else:  # a valid message with a few bytes flipped / cut short / lengths blown up
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            blob = bytes(b[: int(rng.integers(0, len(b) + 1))])
+        rc = L.rsbwt_proto_decode_request(blob, len(blob), C.byref(t), C.byref(rt), C.byref(q), C.byref(ql))
+        assert rc in (0, -6) or rc < 0
+        if rc == 0:
+            assert ql.value <= len(blob)
+    base = 'prefix = "p"; suffix = "s"; hashfile = "h"; pull = "a"; push = "b"; push_count = "c";\n' \
+           'rocksdb_path = "r"; rocksdb_ext = ".db"; rocksdb = [ "x", "y" ];\n'
+    for i in range(300):
+        b = bytearray(base.encode())
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(1, 256))
+        p = tmp_path / f"g{i}.cfg"
+        p.write_bytes(bytes(b[: int(rng.integers(1, len(b) + 1))]))
+        h = C.c_void_p()
+        rc = L.rsbwt_service_config_load(str(p).encode(), C.byref(h))
+        if rc == 0:
+            assert L.rsbwt_service_config_get(h, b"pull") is not None
+            L.rsbwt_service_config_free(h)
+        else:
+            assert not h.value
