@@ -97,6 +97,10 @@ void bpi2_builder::add(const uint8_t *runs, size_t n) {
                 break;
             }
         }
+        if ((u >> 5) > 4u) {  // not a run of $ACGT: the reference would index past its AlphaCount
+            invalid_ = true;
+            continue;
+        }
         last_[bottom * 5 + (u >> 5)] += u & 31u;
         total_ += u & 31u;
     }
@@ -214,6 +218,7 @@ int bpi2_from_bwt(const char *bwt_path, bpi2_index *ix, std::string *err) {
         left -= m;
     }
     fclose(f);
+    if (b.invalid()) return err_set(err, RSBWT_EFORMAT, std::string(bwt_path) + ": a run byte names a symbol rank above 4");
     b.finish();
     *ix = std::move(b.ix);
     return RSBWT_OK;

@@ -40,12 +40,14 @@ class bpi2_builder {
     explicit bpi2_builder(uint64_t num_runs);
     void add(const uint8_t *runs, size_t n);
     void finish();
+    bool invalid() const { return invalid_; }  // a run byte with symbol rank > 4 was fed (and skipped)
     bpi2_index ix;
 
   private:
     std::vector<uint64_t> last_;  // depth x 5: BPNodes::m_last
     std::vector<uint64_t> next_;  // nextBuckets
     uint64_t i_ = 0, total_ = 0, next_sum_ = 0;
+    bool invalid_ = false;
     void append(size_t level);
 };
 
