@@ -53,3 +53,26 @@ def test_layout_rejects_symbols_above_four(rsb):
     L = rsb.lib()
     runs = np.array([(1 << 5) | 3, (6 << 5) | 2], np.uint8)
     assert L.rsbwt_layout_selftest_host(runs.ctypes.data, 2, 0, None, None) == -3
+
+
+def test_layout_code_under_address_and_ub_sanitizers(tmp_path):
+    """tests/native/fuzz_layout_host.cpp: the layout builder and the scalar readers of line_format.h
+    (the code the GPU kernels run) built for the CPU with -fsanitize=address,undefined, on 30 random run
+    streams of six shapes at spans 2..2,944, every position held to naive ranks."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_layout_host")
+    srcs = [os.path.join(root, "tests", "native", "fuzz_layout_host.cpp"),
+            os.path.join(root, "readserver_amd", "csrc", "layout_host.cpp")]
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        f"-I{os.path.join(root, 'include')}", *srcs, "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("no sanitizer runtime here")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
