@@ -435,3 +435,27 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([exe, "300000", str(tmp_path / "f.cfg")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "accepted" in r.stdout
+
+
+def test_service_loop_under_thread_sanitizer(tmp_path):
+    """tests/native/tsan_service_loop.cpp: producer, loop, consumer and a statistics poller on the
+    in-process transport under -fsanitize=thread (the GPU engine behind the loop stubbed): no report, and
+    exactly 2 x partitions Replies per count Request."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tsan_service_loop")
+    srcs = [os.path.join(root, "tests", "native", "tsan_service_loop.cpp"),
+            os.path.join(root, "readserver_amd", "csrc", "service_slice.cpp"),
+            os.path.join(root, "readserver_amd", "csrc", "service_loop.cpp")]
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-include",
+                        os.path.join(root, "tests", "native", "tsan_prelude.h"), f"-I{os.path.join(root, 'include')}",
+                        *srcs, "-lpthread", "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("no sanitizer runtime here")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe, "50000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-4000:]
