@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-single-check", action="store_true",
                     help="skip the single-shard (configs[1]) launches after the timed region: profile passes want "
                          "only the fused launches under the kernel's name")
+    ap.add_argument("--hold-gb", type=float, default=0.0,
+                    help="rehearsal aid: hold this much HBM while the k-mer tables are sized, as rank 0 of an N-GPU "
+                         "job holds the gathered intervals (20.5 GB at N = 8)")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -169,8 +172,17 @@ def main():
     d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
     gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays)
     d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
+    hold = torch.empty(int(a.hold_gb * (1 << 30)), dtype=torch.uint8, device=dev) if a.hold_gb > 0 else None
     if a.ktab_depth == 0:
+        # The library's own rule leaves two thirds of the free HBM to a caller it knows nothing about.
+        # Here every buffer of the job already exists (rank 0's gathered intervals included), so the
+        # tables may take what is left but a reserve for the search's start records (1.4 GB), the
+        # single-shard check and RCCL's own buffers: the same depth then fits rank 0 of an 8-GPU job
+        # (20 GB of gathered intervals) and a lone GPU, and the scaling curve compares like with like.
         T = L.rsbwt_set_auto_ktab_depth(sset._s)
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
+            T += 1
         if world > 1:
             tt = torch.tensor([T], dtype=torch.int64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
