@@ -156,7 +156,7 @@ def main():
         # tables are sized afterwards, for all shards of the GPU together (explicit depth: now)
         g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local,
                        ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span)
-        if rank == 0 and s == 0 and a.cpu_sample > 0:
+        if rank == 0 and world == 1 and s == 0 and a.cpu_sample > 0:  # the CPU baseline is an N = 1 leg
             host_runs = d_runs.cpu().numpy()
         del d_runs
         torch.cuda.empty_cache()
@@ -376,6 +376,8 @@ def main():
         pair = gat.pair(step_no[0] - 1).to(dev)
         lo0, up0 = (pair[0][0], pair[1][0]) if a.separate_arrays else (pair[0, :, 0], pair[0, :, 1])
         out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, lo0, up0, Q, k)
+    elif rank == 0:
+        out["cpu_baseline"] = None  # timed at N = 1 only (or switched off with --cpu-sample 0)
     if rank == 0 and a.verify_all_shards:
         out["config"]["shards_matching_oracle"] = verify_shards(a, L, gat.pair(step_no[0] - 1).to(dev), d_kmers, S, R, Q, k, style,
                                                               rank, local, dev, sp)
