@@ -659,7 +659,7 @@ namespace rsb {
 int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                   const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                   hipStream_t stream, const search_extra *extra) {
-    const bool pairs = extra && extra->pairs;
+    const bool pairs = extra && (extra->pairs || extra->d_hit_ctl);
     if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !pairs && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
     if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1 for device-resident searches");
     if (k > 65535u) return fail(RSBWT_ERANGE, "k %u: at most 65535 symbols per k-mer", k);
@@ -823,11 +823,18 @@ static size_t variants_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
     return tn ? m * (size_t)tn * 16 + 2 * m * 8 : 0;
 }
 
+// d_hit_ctl != nullptr: instead of the [m][3k+1] matrices, the variants that occur are appended to the
+// hit list at d_lo (search_extra::d_hit_ctl) -- a variant's search index is q * (3k+1) + v.
 static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_t m, uint32_t k, const void *d_vpk,
-                           const void *d_vok, void *d_lo, void *d_up, uint8_t *scratch, hipStream_t stream) {
+                           const void *d_vok, void *d_lo, void *d_up, uint8_t *scratch, hipStream_t stream,
+                           void *d_hit_ctl = nullptr) {
     const size_t V = 3 * (size_t)k + 1;
     const uint32_t tn = trace_entries(h->view, k);
-    if (tn == 0) return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream);
+    if (tn == 0) {
+        search_extra plain;
+        plain.d_hit_ctl = d_hit_ctl;
+        return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream, &plain);
+    }
     uint8_t *d_trace = scratch, *d_olo = d_trace + m * (size_t)tn * 16, *d_oup = d_olo + m * 8;
     search_extra traced;
     traced.d_trace_out = d_trace;
@@ -838,6 +845,7 @@ static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_
     resumed.d_trace_in = d_trace;
     resumed.trace_n = tn;
     resumed.variants = (uint32_t)V;
+    resumed.d_hit_ctl = d_hit_ctl;
     return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream, &resumed);
 }
 
@@ -852,7 +860,7 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
     if (rc) return rc;
     const uint32_t wpq = words_per_kmer(k);
     const size_t V = 3 * (size_t)k + 1;
-    const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
+    const size_t SLICE = std::max<size_t>(1, (16u << 20) / V);  // ~16M variants per pass: below a few million a launch does not fill the GPU
     ctx_guard g(h->pool);
     if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
     hipStream_t st = g.c->st[0];
@@ -918,52 +926,91 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
     if (rc) return rc;
     const uint32_t wpq = words_per_kmer(k);
     const size_t V = 3 * (size_t)k + 1;
-    const size_t SLICE = std::max<size_t>(1, (4u << 20) / V);  // ~4M variants per pass
+    const size_t SLICE = std::max<size_t>(1, (16u << 20) / V);  // ~16M variants per pass: below a few million a launch does not fill the GPU
     ctx_guard g(h->pool);
     if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
     hipStream_t st = g.c->st[0];
-    std::vector<uint32_t> counts;
-    std::vector<uint64_t> offsets;
+    // The variants that occur leave the search kernel as a list (search_extra::d_hit_ctl): nothing is
+    // written, read back or compacted for the ~99 % of variants that end empty.
+    struct hit_rec { uint64_t lower, upper, index, zero; };
+    std::vector<hit_rec> got;
+    std::vector<uint32_t> first, fill, order;
     size_t total = 0;
     bool overflow = false;
-    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
-        const size_t m = std::min(SLICE, Q - q0), mv = m * V;
-        const size_t ascii_bytes = (m - 1) * stride + k;
-        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
-        const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
-        const size_t a_cnt = (m * 4 + 15) & ~(size_t)15, a_off = m * 8, a_hits = mv * sizeof(rsbwt_hit_1mm);
-        const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
-        if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_cnt + a_off + a_hits + a_scr)) != RSBWT_OK) return rc;
-        uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
-        uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_lo = d_vok + a_vok, *d_up = d_lo + mv * 8;
-        uint8_t *d_cnt = d_up + mv * 8, *d_off = d_cnt + a_cnt, *d_hits = d_off + a_off, *d_scr = d_hits + a_hits;
-        HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
-        if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, st);
-        if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-        rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_lo, d_up, d_scr, st);
-        if (rc) return rc;
-        e = launch_hits1mm_count(d_lo, d_up, m, (uint32_t)V, d_cnt, st);
-        if (e != hipSuccess) return fail_hip(e, "hit count kernel launch");
-        counts.resize(m);
-        offsets.resize(m);
-        HIP_OK(hipMemcpyAsync(counts.data(), d_cnt, m * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        uint64_t run = 0;
-        for (size_t i = 0; i < m; ++i) {
-            offsets[i] = run;
-            run += counts[i];
+    try {
+        for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+            const size_t m = std::min(SLICE, Q - q0), mv = m * V;
+            const size_t ascii_bytes = (m - 1) * stride + k;
+            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+            const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
+            const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
+            size_t room = std::max<size_t>(4 * m, 1u << 14);  // hits this slice may leave; grown when it leaves more
+            for (;;) {
+                if (room > mv) room = mv;
+                if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + a_scr + 16 + room * sizeof(hit_rec))) != RSBWT_OK) return rc;
+                uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
+                uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_scr = d_vok + a_vok;
+                uint8_t *d_ctl = d_scr + a_scr, *d_list = d_ctl + 16;
+                const uint64_t ctl[2] = {0, (uint64_t)room};
+                HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, st));
+                hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
+                if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, st);
+                if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+                rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_list, nullptr, d_scr, st, d_ctl);
+                if (rc) return rc;
+                uint64_t count = 0;
+                HIP_OK(hipMemcpyAsync(&count, d_ctl, 8, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                if (count > room) {  // the list ran out of room (the counter ran on): once more with enough
+                    room = (size_t)count;
+                    continue;
+                }
+                if (!overflow && total + count <= cap && count) {
+                    got.resize((size_t)count);
+                    HIP_OK(hipMemcpyAsync(got.data(), d_list, (size_t)count * sizeof(hit_rec), hipMemcpyDeviceToHost, st));
+                    HIP_OK(hipStreamSynchronize(st));
+                    // list order is completion order: back into (k-mer, position, base) order, which is the
+                    // order of the search indices q * V + v (variants_kernel).  A counting sort by k-mer
+                    // (a k-mer leaves a handful of hits at most), then each k-mer's few by variant.
+                    first.assign(m + 1, 0);
+                    for (const hit_rec &x : got) first[(size_t)(x.index / V) + 1] += 1;
+                    for (size_t i = 0; i < m; ++i) first[i + 1] += first[i];
+                    order.resize(got.size());
+                    fill = first;
+                    for (uint32_t i = 0; i < (uint32_t)got.size(); ++i) order[fill[(size_t)(got[i].index / V)]++] = i;
+                    for (size_t q = 0; q < m; ++q)
+                        if (first[q + 1] - first[q] > 1u)
+                            std::sort(order.begin() + first[q], order.begin() + first[q + 1],
+                                      [&](uint32_t a, uint32_t b) { return got[a].index < got[b].index; });
+                    for (size_t i = 0; i < got.size(); ++i) {
+                        const hit_rec &x = got[order[i]];
+                        const size_t q = (size_t)(x.index / V);
+                        const uint32_t v = (uint32_t)(x.index % V);
+                        rsbwt_hit_1mm &r = hits[total + i];
+                        r.lower = x.lower;
+                        r.upper = x.upper;
+                        r.query = (uint32_t)(q0 + q);
+                        r.reserved = 0;
+                        if (v == 0u) {
+                            r.pos = -1;
+                            r.base = 0;
+                        } else {
+                            const uint32_t pos = (v - 1u) / 3u, d = (v - 1u) % 3u;
+                            const int orig = rank_of(kmers[(q0 + q) * stride + pos]) - 1;  // 0..3: a hit's k-mer is all ACGT
+                            r.pos = (int16_t)pos;
+                            r.base = "ACGT"[(int)d < orig ? d : d + 1u];
+                        }
+                    }
+                } else if (total + count > cap) {
+                    overflow = true;  // keep counting so that the caller learns the size it needs
+                }
+                total += (size_t)count;
+                break;
+            }
         }
-        if (!overflow && total + run <= cap && run) {
-            HIP_OK(hipMemcpyAsync(d_off, offsets.data(), m * 8, hipMemcpyHostToDevice, st));
-            e = launch_hits1mm_write(d_lo, d_up, d_pk, m, (uint32_t)V, k, d_off, (uint32_t)q0, d_hits, st);
-            if (e != hipSuccess) return fail_hip(e, "hit write kernel launch");
-            HIP_OK(hipMemcpyAsync(hits + total, d_hits, run * sizeof(rsbwt_hit_1mm), hipMemcpyDeviceToHost, st));
-            HIP_OK(hipStreamSynchronize(st));
-        } else if (total + run > cap) {
-            overflow = true;  // keep counting so that the caller learns the size it needs
-        }
-        total += run;
+    } catch (const std::bad_alloc &) {
+        return fail(RSBWT_ENOMEM, "host allocation failed");
     }
     *nhits = total;
     if (overflow) return fail(RSBWT_ERANGE, "%zu hits, room for %zu", total, cap);

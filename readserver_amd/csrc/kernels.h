@@ -60,6 +60,10 @@ struct search_extra {
     uint32_t trace_n = 0, variants = 0;
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
     bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
+    // hit list (one shard): nothing is written for a search that ends empty; the others append
+    // {lower, upper}{search index, 0} (32 B) at d_lower, counted in d_hit_ctl[0] (u64; [1] = capacity,
+    // set by the caller; the count runs on past it so that the caller learns the size it needs)
+    void *d_hit_ctl = nullptr;
     // the k-mer table leaves intervals well inside a window (n / 4^T << S): most steps of a search find
     // both positions in one line, which is what the one-lane-per-search kernel is for (search_solo.h)
     bool narrow = false;
@@ -84,10 +88,6 @@ hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n
 // d_sel: the sampled select table (launch_select_samples)
 hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
                                size_t n, void *d_out, hipStream_t stream);
-hipError_t launch_hits1mm_count(const void *d_lower, const void *d_upper, size_t m, uint32_t V, void *d_counts,
-                                hipStream_t stream);
-hipError_t launch_hits1mm_write(const void *d_lower, const void *d_upper, const void *d_packed, size_t m, uint32_t V,
-                                uint32_t k, const void *d_offsets, uint32_t query0, void *d_hits, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each

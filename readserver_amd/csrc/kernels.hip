@@ -337,61 +337,6 @@ variants_kernel(const uint64_t *__restrict__ packed, const uint8_t *__restrict__
     vpacked[i * wpq + w] = word;
 }
 
-// Compaction of a slice's [m][V] variant intervals into the list of those that occur (SURVEY 8
-// f3's output): a count per k-mer, an exclusive scan on the host (m is a few 10^4), a scatter.
-__global__ void __launch_bounds__(256)
-hits1mm_count_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper, size_t m,
-                     uint32_t V, uint32_t *__restrict__ counts) {
-    // one wave per k-mer: lanes stride over its V variants
-    const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (q >= m) return;
-    uint32_t c = 0;
-    for (uint32_t v = lane; v < V; v += 64u) c += lower[q * V + v] <= upper[q * V + v] ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if (lane == 0u) counts[q] = c;
-}
-
-struct hit_1mm_rec {  // = rsbwt_hit_1mm (include/rsbwt.h)
-    uint64_t lower, upper;
-    uint32_t query;
-    int16_t pos;
-    char base, reserved;
-};
-
-__global__ void __launch_bounds__(256)
-hits1mm_write_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper,
-                     const uint64_t *__restrict__ packed, size_t m, uint32_t V, uint32_t wpq,
-                     const uint64_t *__restrict__ offsets, uint32_t query0, hit_1mm_rec *__restrict__ hits) {
-    const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (q >= m) return;
-    uint64_t at = offsets[q];
-    for (uint32_t v0 = 0; v0 < V; v0 += 64u) {  // V in canonical (pos, base) order: keep it
-        const uint32_t v = v0 + lane;
-        const bool hit = v < V && lower[q * V + v] <= upper[q * V + v];
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
-        if (hit) {
-            hit_1mm_rec r;
-            r.lower = lower[q * V + v];
-            r.upper = upper[q * V + v];
-            r.query = query0 + (uint32_t)q;
-            r.reserved = 0;
-            if (v == 0u) {
-                r.pos = -1;
-                r.base = 0;
-            } else {
-                const uint32_t pos = (v - 1u) / 3u, d = (v - 1u) % 3u;
-                const uint32_t orig = (uint32_t)(packed[q * wpq + (pos >> 5)] >> (2u * (pos & 31u))) & 3u;
-                r.pos = (int16_t)pos;
-                r.base = "ACGT"[d < orig ? d : d + 1u];
-            }
-            hits[at + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = r;
-        }
-        at += __builtin_popcountll(mask);
-    }
-}
-
 // query / query_exactmatch (query.cpp:87-120) over the extracted rows of a batch of k-mers: row i
 // belongs to k-mer owner[i]; flags[i] = 1 when the read equals the k-mer (exact match: the whole read
 // is the query, query.cpp:112-116).
@@ -599,24 +544,6 @@ hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, cons
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix), (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_hits1mm_count(const void *d_lower, const void *d_upper, size_t m, uint32_t V, void *d_counts,
-                                hipStream_t stream) {
-    if (m == 0) return hipSuccess;
-    hipLaunchKernelGGL(hits1mm_count_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream,
-                       (const uint64_t *)d_lower, (const uint64_t *)d_upper, m, V, (uint32_t *)d_counts);
-    return hipGetLastError();
-}
-
-hipError_t launch_hits1mm_write(const void *d_lower, const void *d_upper, const void *d_packed, size_t m, uint32_t V,
-                                uint32_t k, const void *d_offsets, uint32_t query0, void *d_hits, hipStream_t stream) {
-    if (m == 0) return hipSuccess;
-    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    hipLaunchKernelGGL(hits1mm_write_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream,
-                       (const uint64_t *)d_lower, (const uint64_t *)d_upper, (const uint64_t *)d_packed, m, V, wpq,
-                       (const uint64_t *)d_offsets, query0, (hit_1mm_rec *)d_hits);
     return hipGetLastError();
 }
 

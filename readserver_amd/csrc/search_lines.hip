@@ -480,6 +480,19 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 if (side == 0u) {
                     if (COUNTS_ONLY) {
                         out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                    } else if (pairs == 2u) {
+                        // hit list (1-mismatch search): only the searches that end on an interval leave
+                        // anything -- {lower, upper}{search index, 0} appended at an atomic counter
+                        // (out_upper: [0] = count, [1] = capacity; the count runs on past the capacity)
+                        if (lo <= hi) {
+                            unsigned long long *ctl = reinterpret_cast<unsigned long long *>(out_upper);
+                            const unsigned long long at = atomicAdd(ctl, 1ull);
+                            if (at < ctl[1]) {
+                                ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(out_lower) + 2ull * at;
+                                rec[0] = make_ulonglong2(lo, hi);
+                                rec[1] = make_ulonglong2((unsigned long long)q, 0ull);
+                            }
+                        }
                     } else if (pairs) {
 #ifdef RSB_NT_RESULTS  // tuning knob: results are written once and read by another kernel / the host
                         __builtin_nontemporal_store(lo, &out_lo[2 * q]);
@@ -568,7 +581,9 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     if (Q == 0 || nshards == 0) return hipSuccess;
     if (extra && (extra->d_trace_out || extra->d_trace_in || extra->table_build) && nshards != 1)
         return hipErrorInvalidValue;  // traced / resumed searches: one shard
-    const uint32_t pairs = (extra && extra->pairs && !counts_only) ? 1u : 0u;
+    const bool hit_list = extra && extra->d_hit_ctl && !counts_only;
+    if (hit_list && nshards != 1) return hipErrorInvalidValue;  // the list names searches, not (search, shard)
+    const uint32_t pairs = hit_list ? 2u : (extra && extra->pairs && !counts_only) ? 1u : 0u;
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
     const uint32_t trace_n = extra ? extra->trace_n : 0u;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
@@ -599,7 +614,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     const int grid = (int)g;
     const uint64_t *pk = (const uint64_t *)d_packed;
     const uint8_t *vd = (const uint8_t *)d_valid;
-    uint64_t *lo = (uint64_t *)d_lower, *up = (uint64_t *)d_upper;
+    uint64_t *lo = (uint64_t *)d_lower, *up = hit_list ? (uint64_t *)extra->d_hit_ctl : (uint64_t *)d_upper;
     // start records of this batch + the shards' query counters: scratch of this launch sequence
     // alone, so concurrent calls do not share state
     const size_t nrec = Q * nshards;

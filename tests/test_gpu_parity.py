@@ -1075,3 +1075,25 @@ def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k
         # the host entry point of the same batch (slices of 64K k-mers: lane pairs) agrees
         hlo, hup = rsb.find_intervals(g, km[:70000])
         assert np.array_equal(hlo, elo[:70000]) and np.array_equal(hup, eup[:70000])
+
+
+@pytest.mark.gpu
+def test_gpu_hit_list_that_outgrows_its_first_buffer(rsb, tmp_path):
+    """rsbwt_hits_1mm takes the variants that occur straight out of the search kernel as a list
+    (search_extra::d_hit_ctl).  Short k-mers on a small index: nearly every variant occurs, so a slice
+    leaves more hits than the room first given to it and is searched once more with enough; the list
+    must equal the non-empty cells of the dense matrices, in (k-mer, position, base) order."""
+    bwt, rd = str(tmp_path / "s.bwt"), str(tmp_path / "s.reads")
+    rsb.synth_popbwt(bwt, rd, seed=5, genome_len=40000, haplotypes=3, snp_rate=0.01, read_len=60, coverage=5.0)
+    rng = np.random.default_rng(8)
+    k = 5
+    kmers = ["".join("ACGT"[i] for i in rng.integers(0, 4, k)) for _ in range(3000)] + ["ANCGT"]
+    with rsb.GpuBWT(bwt) as g:
+        lo, up = rsb.find_intervals_1mm(g, kmers)
+        want = []
+        for qi, w in enumerate(kmers):
+            want += [(qi,) + h for h in rsb.hits_1mm(w, lo[qi], up[qi])]
+        assert len(want) > 2 * 16384  # room first given to the slice: max(4 m, 16384) records
+        hl = rsb.hits_1mm_batch(g, kmers)
+        got = [(int(r["query"]), int(r["pos"]), r["base"].decode(), int(r["lower"]), int(r["upper"])) for r in hl]
+        assert got == want
