@@ -185,6 +185,15 @@ int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *
 size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);
 int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
                                  void *d_lower, void *d_upper, void *d_scratch, void *stream);
+/* The same search leaving only the variants that occur, as a list ordered by search index: record i =
+ * {u64 lower, u64 upper, u64 index, u64 0} (32 B), index = q * (3k+1) + v (v = 0: the k-mer itself, else
+ * 1 + 3*pos + the rank of the substituted base among the three alternatives) -- the (k-mer, position, base)
+ * order of rsbwt_hits_1mm.  At most `cap` records are written to d_hits; *d_total (a u64 in HBM) receives how
+ * many there are.  Nothing is written for the variants that end empty -- no [m][3k+1] matrices.
+ * d_scratch: rsbwt_hits_1mm_scratch_bytes(h, m, k) bytes.  Nothing is synchronised. */
+size_t rsbwt_hits_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);
+int rsbwt_hits_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,
+                       size_t cap, void *d_total, void *d_scratch, void *stream);
 /* Read extraction of n rows (d_rows: u64): d_out [n][stride] bytes, d_len and d_prefix_len [n] u32. */
 int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
                       void *d_prefix_len, void *stream);

@@ -659,7 +659,7 @@ namespace rsb {
 int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                   const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                   hipStream_t stream, const search_extra *extra) {
-    const bool pairs = extra && (extra->pairs || extra->d_hit_ctl);
+    const bool pairs = extra && (extra->pairs || extra->d_hit_bits);
     if (Q && (!d_packed || !d_valid || !d_lower || (!counts_only && !pairs && !d_upper))) return fail(RSBWT_EINVAL, "null argument");
     if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1 for device-resident searches");
     if (k > 65535u) return fail(RSBWT_ERANGE, "k %u: at most 65535 symbols per k-mer", k);
@@ -823,16 +823,16 @@ static size_t variants_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
     return tn ? m * (size_t)tn * 16 + 2 * m * 8 : 0;
 }
 
-// d_hit_ctl != nullptr: instead of the [m][3k+1] matrices, the variants that occur are appended to the
-// hit list at d_lo (search_extra::d_hit_ctl) -- a variant's search index is q * (3k+1) + v.
+// d_hit_bits != nullptr: instead of the [m][3k+1] matrices, only the variants that occur are written:
+// {lower, upper} at d_lo[q * (3k+1) + v] and their bit in the map (search_extra::d_hit_bits).
 static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_t m, uint32_t k, const void *d_vpk,
                            const void *d_vok, void *d_lo, void *d_up, uint8_t *scratch, hipStream_t stream,
-                           void *d_hit_ctl = nullptr) {
+                           void *d_hit_bits = nullptr) {
     const size_t V = 3 * (size_t)k + 1;
     const uint32_t tn = trace_entries(h->view, k);
     if (tn == 0) {
         search_extra plain;
-        plain.d_hit_ctl = d_hit_ctl;
+        plain.d_hit_bits = d_hit_bits;
         return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream, &plain);
     }
     uint8_t *d_trace = scratch, *d_olo = d_trace + m * (size_t)tn * 16, *d_oup = d_olo + m * 8;
@@ -845,7 +845,7 @@ static int search_variants(rsbwt_t *h, const void *d_pk, const void *d_ok, size_
     resumed.d_trace_in = d_trace;
     resumed.trace_n = tn;
     resumed.variants = (uint32_t)V;
-    resumed.d_hit_ctl = d_hit_ctl;
+    resumed.d_hit_bits = d_hit_bits;
     return search_dev(h, d_vpk, d_vok, m * V, k, d_lo, d_up, false, stream, &resumed);
 }
 
@@ -912,6 +912,62 @@ int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d
     return search_variants(h, d_packed, d_valid, m, k, d_vpk, d_vok, d_lower, d_upper, d_scr, (hipStream_t)stream);
 }
 
+// Scratch of a hit-list search of m k-mers: the variants and the trace (rsbwt_1mm_scratch_bytes), the
+// sparse {lower, upper} array (16 B per variant, written only where a variant occurs), the hit map (one
+// bit per variant) and the block sums of its compaction.
+struct hits_layout {
+    size_t variants, sparse, bits, blocks, total;
+};
+static hits_layout hits_scratch_layout(const rsbwt_t *h, size_t m, uint32_t k) {
+    const size_t mv = m * (3 * (size_t)k + 1), nwords = (mv + 63) / 64;
+    hits_layout L;
+    L.variants = (rsbwt_1mm_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
+    L.sparse = mv * 16;
+    L.bits = (nwords * 8 + 15) & ~(size_t)15;
+    L.blocks = ((nwords + 255) / 256 + 2) * 8;
+    L.total = L.variants + L.sparse + L.bits + ((L.blocks + 15) & ~(size_t)15);
+    return L;
+}
+
+size_t rsbwt_hits_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
+    if (!h || k == 0) return 0;
+    return hits_scratch_layout(h, m, k).total;
+}
+
+// the search half: variants -> sparse results + hit map (zeroed here)
+static int hits_search(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, uint8_t *scratch,
+                       hipStream_t stream) {
+    const hits_layout L = hits_scratch_layout(h, m, k);
+    const size_t V = 3 * (size_t)k + 1, mv = m * V;
+    uint8_t *d_vpk = scratch, *d_vok = d_vpk + mv * words_per_kmer(k) * 8, *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
+    uint8_t *d_sparse = scratch + L.variants, *d_bits = d_sparse + L.sparse;
+    HIP_OK(hipMemsetAsync(d_bits, 0, L.bits, stream));
+    hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, stream);
+    if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+    return search_variants(h, d_packed, d_valid, m, k, d_vpk, d_vok, d_sparse, nullptr, d_scr, stream, d_bits);
+}
+
+int rsbwt_hits_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,
+                       size_t cap, void *d_total, void *d_scratch, void *stream) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (!d_total || (!d_hits && cap)) return fail(RSBWT_EINVAL, "null argument");
+    if (m == 0) {
+        HIP_OK(hipMemsetAsync(d_total, 0, 8, (hipStream_t)stream));
+        return RSBWT_OK;
+    }
+    if (!d_packed || !d_valid || !d_scratch) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1");
+    if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if ((rc = hits_search(h, d_packed, d_valid, m, k, (uint8_t *)d_scratch, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    const hits_layout L = hits_scratch_layout(h, m, k);
+    uint8_t *d_sparse = (uint8_t *)d_scratch + L.variants, *d_bits = d_sparse + L.sparse, *d_blocks = d_bits + L.bits;
+    const hipError_t e = launch_compact_hits(d_bits, d_sparse, m * (3 * (size_t)k + 1), d_hits, cap, d_total, d_blocks, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hit list kernels");
+    return RSBWT_OK;
+}
+
 int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
                    size_t cap, size_t *nhits) {
     if (!h || !nhits) return fail(RSBWT_EINVAL, "null argument");
@@ -930,11 +986,10 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
     ctx_guard g(h->pool);
     if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
     hipStream_t st = g.c->st[0];
-    // The variants that occur leave the search kernel as a list (search_extra::d_hit_ctl): nothing is
-    // written, read back or compacted for the ~99 % of variants that end empty.
+    // The variants that occur leave the search kernel as sparse stores + a hit map and are put in order on
+    // the device (launch_compact_hits): nothing is written or read back for the ~99 % that end empty.
     struct hit_rec { uint64_t lower, upper, index, zero; };
     std::vector<hit_rec> got;
-    std::vector<uint32_t> first, fill, order;
     size_t total = 0;
     bool overflow = false;
     try {
@@ -942,72 +997,69 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
             const size_t m = std::min(SLICE, Q - q0), mv = m * V;
             const size_t ascii_bytes = (m - 1) * stride + k;
             const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
-            const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
-            const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
-            size_t room = std::max<size_t>(4 * m, 1u << 14);  // hits this slice may leave; grown when it leaves more
+            const hits_layout L = hits_scratch_layout(h, m, k);
+            size_t room = std::min(mv, std::max<size_t>(4 * m, 1u << 14));  // records this slice may leave; more on demand
+            if ((rc = g.c->stage(a_ascii + a_pk + a_ok + L.total + 16 + room * sizeof(hit_rec))) != RSBWT_OK) return rc;
+            uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk, *d_scr = d_ok + a_ok;
+            uint8_t *d_total = d_scr + L.total, *d_list = d_total + 16;
+            uint8_t *d_sparse = d_scr + L.variants, *d_bits = d_sparse + L.sparse, *d_blocks = d_bits + L.bits;
+            HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
+            if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+            if ((rc = hits_search(h, d_pk, d_ok, m, k, d_scr, st)) != RSBWT_OK) return rc;
+            uint64_t count = 0;
             for (;;) {
-                if (room > mv) room = mv;
-                if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + a_scr + 16 + room * sizeof(hit_rec))) != RSBWT_OK) return rc;
-                uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
-                uint8_t *d_vpk = d_ok + a_ok, *d_vok = d_vpk + a_vpk, *d_scr = d_vok + a_vok;
-                uint8_t *d_ctl = d_scr + a_scr, *d_list = d_ctl + 16;
-                const uint64_t ctl[2] = {0, (uint64_t)room};
-                HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemcpyAsync(d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, st));
-                hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
-                if (e == hipSuccess) e = launch_variants(d_pk, d_ok, m, k, d_vpk, d_vok, st);
-                if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
-                rc = search_variants(h, d_pk, d_ok, m, k, d_vpk, d_vok, d_list, nullptr, d_scr, st, d_ctl);
-                if (rc) return rc;
-                uint64_t count = 0;
-                HIP_OK(hipMemcpyAsync(&count, d_ctl, 8, hipMemcpyDeviceToHost, st));
+                e = launch_compact_hits(d_bits, d_sparse, mv, d_list, room, d_total, d_blocks, st);
+                if (e != hipSuccess) return fail_hip(e, "hit list kernels");
+                HIP_OK(hipMemcpyAsync(&count, d_total, 8, hipMemcpyDeviceToHost, st));
                 HIP_OK(hipStreamSynchronize(st));
-                if (count > room) {  // the list ran out of room (the counter ran on): once more with enough
-                    room = (size_t)count;
-                    continue;
+                if (count <= room || overflow || total + count > cap) break;
+                // more hits than the list had room for: the search's results are still in place, only the
+                // list is made again, in a buffer of its own (growing the staging buffer would move them)
+                room = (size_t)count;
+                void *bigger = nullptr;
+                HIP_OK(hipMalloc(&bigger, room * sizeof(hit_rec)));
+                e = launch_compact_hits(d_bits, d_sparse, mv, bigger, room, d_total, d_blocks, st);
+                hipError_t e2 = hipSuccess;
+                if (e == hipSuccess) {
+                    got.resize((size_t)count);
+                    e2 = hipMemcpyAsync(got.data(), bigger, (size_t)count * sizeof(hit_rec), hipMemcpyDeviceToHost, st);
+                    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
                 }
-                if (!overflow && total + count <= cap && count) {
+                (void)hipFree(bigger);
+                if (e != hipSuccess) return fail_hip(e, "hit list kernels");
+                if (e2 != hipSuccess) return fail_hip(e2, "hit list copy");
+                d_list = nullptr;  // `got` is filled
+                break;
+            }
+            if (!overflow && total + count <= cap && count) {
+                if (d_list) {
                     got.resize((size_t)count);
                     HIP_OK(hipMemcpyAsync(got.data(), d_list, (size_t)count * sizeof(hit_rec), hipMemcpyDeviceToHost, st));
                     HIP_OK(hipStreamSynchronize(st));
-                    // list order is completion order: back into (k-mer, position, base) order, which is the
-                    // order of the search indices q * V + v (variants_kernel).  A counting sort by k-mer
-                    // (a k-mer leaves a handful of hits at most), then each k-mer's few by variant.
-                    first.assign(m + 1, 0);
-                    for (const hit_rec &x : got) first[(size_t)(x.index / V) + 1] += 1;
-                    for (size_t i = 0; i < m; ++i) first[i + 1] += first[i];
-                    order.resize(got.size());
-                    fill = first;
-                    for (uint32_t i = 0; i < (uint32_t)got.size(); ++i) order[fill[(size_t)(got[i].index / V)]++] = i;
-                    for (size_t q = 0; q < m; ++q)
-                        if (first[q + 1] - first[q] > 1u)
-                            std::sort(order.begin() + first[q], order.begin() + first[q + 1],
-                                      [&](uint32_t a, uint32_t b) { return got[a].index < got[b].index; });
-                    for (size_t i = 0; i < got.size(); ++i) {
-                        const hit_rec &x = got[order[i]];
-                        const size_t q = (size_t)(x.index / V);
-                        const uint32_t v = (uint32_t)(x.index % V);
-                        rsbwt_hit_1mm &r = hits[total + i];
-                        r.lower = x.lower;
-                        r.upper = x.upper;
-                        r.query = (uint32_t)(q0 + q);
-                        r.reserved = 0;
-                        if (v == 0u) {
-                            r.pos = -1;
-                            r.base = 0;
-                        } else {
-                            const uint32_t pos = (v - 1u) / 3u, d = (v - 1u) % 3u;
-                            const int orig = rank_of(kmers[(q0 + q) * stride + pos]) - 1;  // 0..3: a hit's k-mer is all ACGT
-                            r.pos = (int16_t)pos;
-                            r.base = "ACGT"[(int)d < orig ? d : d + 1u];
-                        }
-                    }
-                } else if (total + count > cap) {
-                    overflow = true;  // keep counting so that the caller learns the size it needs
                 }
-                total += (size_t)count;
-                break;
+                for (size_t i = 0; i < got.size(); ++i) {  // already in (k-mer, position, base) order
+                    const size_t q = (size_t)(got[i].index / V);
+                    const uint32_t v = (uint32_t)(got[i].index % V);
+                    rsbwt_hit_1mm &r = hits[total + i];
+                    r.lower = got[i].lower;
+                    r.upper = got[i].upper;
+                    r.query = (uint32_t)(q0 + q);
+                    r.reserved = 0;
+                    if (v == 0u) {
+                        r.pos = -1;
+                        r.base = 0;
+                    } else {
+                        const uint32_t pos = (v - 1u) / 3u, d = (v - 1u) % 3u;
+                        const int orig = rank_of(kmers[(q0 + q) * stride + pos]) - 1;  // 0..3: a hit's k-mer is all ACGT
+                        r.pos = (int16_t)pos;
+                        r.base = "ACGT"[(int)d < orig ? d : d + 1u];
+                    }
+                }
+            } else if (total + count > cap) {
+                overflow = true;  // keep counting so that the caller learns the size it needs
             }
+            total += (size_t)count;
         }
     } catch (const std::bad_alloc &) {
         return fail(RSBWT_ENOMEM, "host allocation failed");

@@ -60,10 +60,11 @@ struct search_extra {
     uint32_t trace_n = 0, variants = 0;
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
     bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
-    // hit list (one shard): nothing is written for a search that ends empty; the others append
-    // {lower, upper}{search index, 0} (32 B) at d_lower, counted in d_hit_ctl[0] (u64; [1] = capacity,
-    // set by the caller; the count runs on past it so that the caller learns the size it needs)
-    void *d_hit_ctl = nullptr;
+    // sparse results (one shard): nothing is written for a search that ends empty; the others store
+    // {lower, upper} at d_lower[search index] (16 B each, as with `pairs`) and set their bit in the map
+    // d_hit_bits (one bit per search, zeroed by the caller); launch_compact_hits turns the two into a
+    // list ordered by search index
+    void *d_hit_bits = nullptr;
     // the k-mer table leaves intervals well inside a window (n / 4^T << S): most steps of a search find
     // both positions in one line, which is what the one-lane-per-search kernel is for (search_solo.h)
     bool narrow = false;
@@ -88,6 +89,11 @@ hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n
 // d_sel: the sampled select table (launch_select_samples)
 hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
                                size_t n, void *d_out, hipStream_t stream);
+// The list of the set bits of `bits` (n_searches bits), in order: record i = {lower, upper, search index, 0}
+// (32 B) from sparse[index]; at most `cap` records are written, *d_total receives how many there are.
+// d_block_counts: (n_searches / 16384 + 2) u64 of scratch.
+hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t n_searches, void *d_hits, size_t cap,
+                               void *d_total, void *d_block_counts, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each

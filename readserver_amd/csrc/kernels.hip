@@ -337,6 +337,81 @@ variants_kernel(const uint64_t *__restrict__ packed, const uint8_t *__restrict__
     vpacked[i * wpq + w] = word;
 }
 
+// ---- 1-mismatch hit list: the set bits of the search kernels' hit map, in order -------------------
+// Three small launches over n/64 words (the map of 3.8*10^7 variants is 4.7 MB): set bits per block of
+// 256 words, an exclusive scan of the block sums by one workgroup, the scatter.
+constexpr uint32_t HITS_BLOCK_WORDS = 256;
+
+__global__ void __launch_bounds__(256)
+hit_block_counts_kernel(const uint64_t *__restrict__ bits, size_t nwords, unsigned long long *__restrict__ block_counts) {
+    const size_t w = (size_t)blockIdx.x * HITS_BLOCK_WORDS + threadIdx.x;
+    uint32_t c = w < nwords ? (uint32_t)__builtin_popcountll(bits[w]) : 0u;
+    __shared__ uint32_t part[4];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0u) block_counts[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan in place; block_counts[nblocks] and *total receive the sum
+__global__ void __launch_bounds__(256)
+hit_block_scan_kernel(unsigned long long *__restrict__ block_counts, size_t nblocks, unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long carry, sums[256];
+    if (threadIdx.x == 0u) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nblocks; base += 256) {
+        const size_t i = base + threadIdx.x;
+        const unsigned long long v = i < nblocks ? block_counts[i] : 0ull;
+        sums[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256u; off <<= 1) {  // Hillis-Steele, inclusive
+            const unsigned long long t = threadIdx.x >= off ? sums[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            sums[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_counts[i] = carry + sums[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255u) carry += sums[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0u) {
+        block_counts[nblocks] = carry;
+        *total = carry;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+hit_scatter_kernel(const uint64_t *__restrict__ bits, const ulonglong2 *__restrict__ sparse, size_t nwords,
+                   const unsigned long long *__restrict__ block_offsets, ulonglong2 *__restrict__ hits, size_t cap) {
+    const size_t w = (size_t)blockIdx.x * HITS_BLOCK_WORDS + threadIdx.x;
+    uint64_t word = w < nwords ? bits[w] : 0ull;
+    const uint32_t c = (uint32_t)__builtin_popcountll(word);
+    // exclusive prefix of c over the block: within the wave by shuffles, across the four waves through LDS
+    uint32_t incl = c;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __shared__ uint32_t wave_tot[4];
+    if (lane == 63u) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (uint32_t v = 0; v < (threadIdx.x >> 6); ++v) before += wave_tot[v];
+    unsigned long long at = block_offsets[blockIdx.x] + before;
+    while (word) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(word);
+        word &= word - 1ull;
+        const unsigned long long index = (unsigned long long)w * 64ull + b;
+        if (at < cap) {
+            hits[2 * at] = sparse[index];
+            hits[2 * at + 1] = make_ulonglong2(index, 0ull);
+        }
+        ++at;
+    }
+}
+
 // query / query_exactmatch (query.cpp:87-120) over the extracted rows of a batch of k-mers: row i
 // belongs to k-mer owner[i]; flags[i] = 1 when the read equals the k-mer (exact match: the whole read
 // is the query, query.cpp:112-116).
@@ -544,6 +619,19 @@ hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, cons
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix), (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t n_searches, void *d_hits, size_t cap,
+                               void *d_total, void *d_block_counts, hipStream_t stream) {
+    const size_t nwords = (n_searches + 63) / 64, nblocks = (nwords + HITS_BLOCK_WORDS - 1) / HITS_BLOCK_WORDS;
+    if (nwords == 0) return hipMemsetAsync(d_total, 0, 8, stream);
+    hipLaunchKernelGGL(hit_block_counts_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const uint64_t *)d_bits, nwords,
+                       (unsigned long long *)d_block_counts);
+    hipLaunchKernelGGL(hit_block_scan_kernel, dim3(1), dim3(256), 0, stream, (unsigned long long *)d_block_counts, nblocks,
+                       (unsigned long long *)d_total);
+    hipLaunchKernelGGL(hit_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const uint64_t *)d_bits,
+                       (const ulonglong2 *)d_sparse, nwords, (const unsigned long long *)d_block_counts, (ulonglong2 *)d_hits, cap);
     return hipGetLastError();
 }
 

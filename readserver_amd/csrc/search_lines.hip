@@ -481,17 +481,13 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                     if (COUNTS_ONLY) {
                         out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
                     } else if (pairs == 2u) {
-                        // hit list (1-mismatch search): only the searches that end on an interval leave
-                        // anything -- {lower, upper}{search index, 0} appended at an atomic counter
-                        // (out_upper: [0] = count, [1] = capacity; the count runs on past the capacity)
+                        // sparse results (1-mismatch hit list): only a search that ends on an interval leaves
+                        // anything -- its {lower, upper} at its own place and its bit in the map at out_upper (an
+                        // atomic nobody waits for; a counter handing out list positions would stall the wave for a
+                        // round trip per hit and serialise on one address).  compact_hits orders them afterwards.
                         if (lo <= hi) {
-                            unsigned long long *ctl = reinterpret_cast<unsigned long long *>(out_upper);
-                            const unsigned long long at = atomicAdd(ctl, 1ull);
-                            if (at < ctl[1]) {
-                                ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(out_lower) + 2ull * at;
-                                rec[0] = make_ulonglong2(lo, hi);
-                                rec[1] = make_ulonglong2((unsigned long long)q, 0ull);
-                            }
+                            reinterpret_cast<ulonglong2 *>(out_lower)[q] = make_ulonglong2(lo, hi);
+                            atomicOr(reinterpret_cast<unsigned long long *>(out_upper) + (q >> 6), 1ull << (q & 63u));
                         }
                     } else if (pairs) {
 #ifdef RSB_NT_RESULTS  // tuning knob: results are written once and read by another kernel / the host
@@ -581,7 +577,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     if (Q == 0 || nshards == 0) return hipSuccess;
     if (extra && (extra->d_trace_out || extra->d_trace_in || extra->table_build) && nshards != 1)
         return hipErrorInvalidValue;  // traced / resumed searches: one shard
-    const bool hit_list = extra && extra->d_hit_ctl && !counts_only;
+    const bool hit_list = extra && extra->d_hit_bits && !counts_only;
     if (hit_list && nshards != 1) return hipErrorInvalidValue;  // the list names searches, not (search, shard)
     const uint32_t pairs = hit_list ? 2u : (extra && extra->pairs && !counts_only) ? 1u : 0u;
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
@@ -614,7 +610,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     const int grid = (int)g;
     const uint64_t *pk = (const uint64_t *)d_packed;
     const uint8_t *vd = (const uint8_t *)d_valid;
-    uint64_t *lo = (uint64_t *)d_lower, *up = hit_list ? (uint64_t *)extra->d_hit_ctl : (uint64_t *)d_upper;
+    uint64_t *lo = (uint64_t *)d_lower, *up = hit_list ? (uint64_t *)extra->d_hit_bits : (uint64_t *)d_upper;
     // start records of this batch + the shards' query counters: scratch of this launch sequence
     // alone, so concurrent calls do not share state
     const size_t nrec = Q * nshards;

@@ -347,15 +347,14 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 }
                 if (COUNTS_ONLY) {
                     out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
-                } else if (pairs == 2u) {  // hit list: see search_lines_kernel
+                } else if (pairs == 2u) {
+                    // sparse results (1-mismatch hit list): only a search that ends on an interval leaves
+                    // anything -- its {lower, upper} at its own place and its bit in the map at out_upper (an
+                    // atomic nobody waits for; a counter handing out list positions would stall the wave for a
+                    // round trip per hit and serialise on one address).  compact_hits orders them afterwards.
                     if (lo <= hi) {
-                        unsigned long long *ctl = reinterpret_cast<unsigned long long *>(out_upper);
-                        const unsigned long long at = atomicAdd(ctl, 1ull);
-                        if (at < ctl[1]) {
-                            ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(out_lower) + 2ull * at;
-                            rec[0] = make_ulonglong2(lo, hi);
-                            rec[1] = make_ulonglong2((unsigned long long)q, 0ull);
-                        }
+                        reinterpret_cast<ulonglong2 *>(out_lower)[q] = make_ulonglong2(lo, hi);
+                        atomicOr(reinterpret_cast<unsigned long long *>(out_upper) + (q >> 6), 1ull << (q & 63u));
                     }
                 } else if (pairs) {
                     reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);

@@ -1097,3 +1097,27 @@ def test_gpu_hit_list_that_outgrows_its_first_buffer(rsb, tmp_path):
         hl = rsb.hits_1mm_batch(g, kmers)
         got = [(int(r["query"]), int(r["pos"]), r["base"].decode(), int(r["lower"]), int(r["upper"])) for r in hl]
         assert got == want
+        # the device-resident form: the same records ordered by index = q * (3k+1) + v; a list that is too
+        # short is filled to its capacity and the total still says how many there are
+        import ctypes as C
+        import torch
+        L = rsb.lib()
+        km = np.frombuffer("".join(kmers).encode(), np.uint8).reshape(len(kmers), k)
+        m, V = len(kmers), 3 * k + 1
+        p = lambda t: C.c_void_p(t.data_ptr())
+        d_km = torch.from_numpy(km.copy()).cuda()
+        d_pk = torch.empty(m, dtype=torch.int64, device="cuda:0")
+        d_ok = torch.empty(m, dtype=torch.uint8, device="cuda:0")
+        assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+        d_scr = torch.empty(L.rsbwt_hits_1mm_scratch_bytes(g.handle, m, k), dtype=torch.uint8, device="cuda:0")
+        dense = [(qi * V + v, int(lo[qi, v]), int(up[qi, v])) for qi in range(m) for v in range(V) if lo[qi, v] <= up[qi, v]]
+        for room in (len(dense) + 100, 1000, 0):
+            d_hits = torch.full((max(room, 1), 4), -1, dtype=torch.int64, device="cuda:0")
+            d_tot = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+            assert L.rsbwt_hits_1mm_dev(g.handle, p(d_pk), p(d_ok), m, k, p(d_hits), room, p(d_tot), p(d_scr), None) == 0
+            torch.cuda.synchronize()
+            assert int(d_tot.item()) == len(dense)
+            n = min(room, len(dense))
+            rec = d_hits.cpu().numpy().view(np.uint64)
+            assert [(int(r[2]), int(r[0]), int(r[1])) for r in rec[:n]] == dense[:n] and (rec[:n, 3] == 0).all()
+            assert (rec[n:] == np.uint64(2**64 - 1)).all()  # nothing past the capacity

@@ -114,7 +114,39 @@ out["one_mismatch"] = {
                  "frac": alg / (kms * 1e-3) / 1e9 / PEAK, "kernel": "search_lines_kernel (variants resumed from the trace)",
                  "algorithmic_bytes": alg},
 }
-del d_lo, d_up, d_scr
+# the same search leaving only the variants that occur (rsbwt_hits_1mm_dev), first shard
+room = 8 * M
+d_hl = torch.empty((room, 4), dtype=torch.int64, device=dev)
+d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+d_hscr = torch.empty(L.rsbwt_hits_1mm_scratch_bytes(g.handle, M, k), dtype=torch.uint8, device=dev)
+def run_hits():
+    ok(L.rsbwt_hits_1mm_dev(g.handle, p(d_pk), p(d_ok), M, k, p(d_hl), room, p(d_tot), p(d_hscr), None))
+ok(L.rsbwt_set_counting(g.handle, 1))
+run_hits()
+torch.cuda.synchronize()
+wh = (C.c_uint64 * 16)()
+ok(L.rsbwt_last_search_counters(g.handle, wh))
+ok(L.rsbwt_set_counting(g.handle, 0))
+for _ in range(2):
+    run_hits()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    run_hits()
+torch.cuda.synchronize()
+dth = (time.perf_counter() - t0) / reps
+buf = (C.c_float * 64)()
+cnt = C.c_size_t()
+ok(L.rsbwt_search_history_ms(g.handle, buf, 2 * reps, C.byref(cnt)))
+kmh = sum(buf[:cnt.value]) / reps
+algh = wh[2] * 128 + M * V * 24 + int(d_tot.item()) * 48  # lines + start record and packed word per search + 16 + 32 B per hit
+out["one_mismatch_hit_list_first_shard"] = {
+    "kmers": M, "kmers_per_s": M / dth, "variant_searches_per_s": M * V / dth, "ms_per_call": dth * 1e3,
+    "search_kernels_ms_per_call": kmh, "hits": int(d_tot.item()),
+    "roofline": {"bound": "hbm", "achieved": algh / (kmh * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
+                 "frac": algh / (kmh * 1e-3) / 1e9 / PEAK, "algorithmic_bytes": algh},
+}
+del d_lo, d_up, d_scr, d_hl, d_hscr
 
 # ---- f2: extraction of random rows (the run stream is not a valid BWT: walks end at the '$' they meet) -
 stride = 512
