@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-single-check", action="store_true",
                     help="skip the single-shard (configs[1]) launches after the timed region: profile passes want "
                          "only the fused launches under the kernel's name")
+    ap.add_argument("--counts", action="store_true",
+                    help="variant (N = 1 only, not the headline): the service's count path -- rsbwt_set_count_dev, one u64 "
+                         "count per (query, shard) instead of the interval pairs; checked against the pairs of one launch")
     ap.add_argument("--hold-gb", type=float, default=0.0,
                     help="rehearsal aid: hold this much HBM while the k-mer tables are sized, as rank 0 of an N-GPU "
                          "job holds the gathered intervals (20.5 GB at N = 8)")
@@ -223,6 +226,12 @@ def main():
         del mine, idx, parts
 
     step_no = [0]
+    d_counts = None
+    if a.counts:
+        if world != 1 or a.separate_arrays:
+            raise SystemExit("bench.py --counts: one GPU, default result layout")
+        a.cpu_sample, a.no_single_check = 0, True
+        d_counts = torch.empty((S, Q), dtype=torch.int64, device=dev)
 
     def step():
         i = step_no[0]
@@ -232,7 +241,9 @@ def main():
         if d_res is not None:  # rehearsal: search into HBM, gather from a host copy
             host_pair, pair = pair, d_res[i % 2]
         ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
-        if a.separate_arrays:
+        if a.counts:
+            ok(L.rsbwt_set_count_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(d_counts), sp))
+        elif a.separate_arrays:
             ok(L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
         else:
             ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair), sp))
@@ -258,6 +269,15 @@ def main():
     phases = {"passes": npass, "cycles_per_pass": [round(w[4 + i] / max(npass, 1)) for i in range(6)],
               "names": ["setup", "issue", "wait", "rank", "exchange", "update"]}
 
+    if a.counts:  # the counts of a launch against the interval pairs of the same batch
+        pr = gat.pair(0)
+        ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr), sp))
+        step()
+        torch.cuda.synchronize()
+        want = torch.where(pr[..., 1] >= pr[..., 0], pr[..., 1] - pr[..., 0] + 1, torch.zeros_like(pr[..., 0]))
+        if not torch.equal(want, d_counts):
+            raise SystemExit("bench.py --counts: counts differ from upper - lower + 1 of the same batch")
+        del pr, want
     for _ in range(a.warmup):
         step()
     barrier()
@@ -357,7 +377,8 @@ def main():
             "index_hbm_bytes_per_gpu": hbm, "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
             "index_build_s": round(t_build, 2),
             "gather_verified": gather_verified,
-            "results": ("lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
+            "results": ("counts[S][Q] (rsbwt_set_count_dev: the service's count path, NOT the headline)" if a.counts else
+                        "lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
             "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
             "single_shard_check": single,
         },

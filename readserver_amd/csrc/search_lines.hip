@@ -479,7 +479,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 }
                 if (side == 0u) {
                     if (COUNTS_ONLY) {
-                        out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                        if (hi >= lo) out_lo[q] = hi - lo + 1ull;  // service.cpp:304; the array is zeroed before the launch: most searches end empty and store nothing
                     } else if (pairs == 2u) {
                         // sparse results (1-mismatch hit list): only a search that ends on an interval leaves
                         // anything -- its {lower, upper} at its own place and its bit in the map at out_upper (an
@@ -617,6 +617,13 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     scratch_cache::lease mem;
     hipError_t e = scratch.take(nrec * sizeof(ulonglong2) + nshards * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
+    if (counts_only) {  // counts: only the searches that find something store theirs
+        e = hipMemsetAsync(d_lower, 0, nrec * sizeof(uint64_t), stream);
+        if (e != hipSuccess) {
+            scratch.give(mem, stream);
+            return e;
+        }
+    }
     ulonglong2 *init = (ulonglong2 *)mem.p;
     unsigned long long *ctr = (unsigned long long *)(init + nrec);
     e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);

@@ -346,7 +346,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
                 }
                 if (COUNTS_ONLY) {
-                    out_lo[q] = hi >= lo ? hi - lo + 1ull : 0ull;  // service.cpp:304
+                    if (hi >= lo) out_lo[q] = hi - lo + 1ull;  // service.cpp:304; the array is zeroed before the launch: most searches end empty and store nothing
                 } else if (pairs == 2u) {
                     // sparse results (1-mismatch hit list): only a search that ends on an interval leaves
                     // anything -- its {lower, upper} at its own place and its bit in the map at out_upper (an
