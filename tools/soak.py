@@ -115,6 +115,12 @@ threads = [threading.Thread(target=worker, args=(100 + i,)) for i in range(NT)]
 t0 = time.time()
 for t in threads:
     t.start()
+while any(t.is_alive() for t in threads):  # a line every half minute: a silent GPU run is taken to be hung
+    time.sleep(1.0)
+    if int(time.time() - t0) % 30 == 0:
+        with lock:
+            print(f"soak: {int(time.time() - t0)} s, {sum(v['calls'] for v in stats.values())} calls, {len(errors)} errors",
+                  file=sys.stderr, flush=True)
 for t in threads:
     t.join()
 res = {"seconds": round(time.time() - t0, 1), "threads": NT, "run_bytes_per_shard": R, "symbols_per_shard": int(n),
