@@ -9,7 +9,10 @@ needs), counted from the lengths extracted.  Prints one JSON line.
 With shards > 1 (BASELINE configs[3]/[4]: the 8 shards of one GPU) the 1-mismatch search runs over a
 shard set (rsbwt_set_find_intervals_1mm_dev, tables sized for the set) and rows are extracted from every
 shard in turn.
-usage: tools/bench_rows.py [run_bytes=2e10] [kmers=400000] [rows=2000000] [shards=1]"""
+With stride < 512 (5th argument) walks longer than the row buffer are cut where the buffer ends and reported as
+not fitting (the reference's reads are at most 100 long; the synthetic stream's are geometric with mean
+81 per direction): their steps still count, from the walk kernels' own counters.
+usage: tools/bench_rows.py [run_bytes=2e10] [kmers=400000] [rows=2000000] [shards=1] [stride=512]"""
 import ctypes as C
 import json
 import os
@@ -26,6 +29,7 @@ R = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000000
 M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 400000
 NR = int(float(sys.argv[3])) if len(sys.argv) > 3 else 2000000
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+STRIDE = int(sys.argv[5]) if len(sys.argv) > 5 else 512
 k, PEAK = 31, 8000.0
 L = rsb.lib()
 dev = torch.device("cuda", 0)
@@ -149,7 +153,7 @@ out["one_mismatch_hit_list_first_shard"] = {
 del d_lo, d_up, d_scr, d_hl, d_hscr
 
 # ---- f2: extraction of random rows (the run stream is not a valid BWT: walks end at the '$' they meet) -
-stride = 512
+stride = STRIDE
 rows = torch.randint(0, n, (NR,), generator=gen, device=dev, dtype=torch.int64)
 d_out = torch.empty((NR, stride), dtype=torch.uint8, device=dev)
 d_len = torch.empty(NR, dtype=torch.int32, device=dev)
@@ -173,6 +177,8 @@ ok(L.rsbwt_last_search_counters(g.handle, xw))
 ok(L.rsbwt_set_counting(g.handle, 0))
 names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "count_word_probes"]
 walk_counters = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
+if STRIDE != 512:  # walks are cut at the buffer's end: the steps actually taken, from the kernels' counters
+    steps = S * (walk_counters["prefix"]["steps"] + walk_counters["postfix"]["steps"])
 reps = 3
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
@@ -183,7 +189,7 @@ ev1.record()
 torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1) / reps
 out["extract"] = {
-    "rows": S * NR, "rows_fitting_stride": nfit, "mean_read_length": bases / max(nfit, 1),
+    "rows": S * NR, "stride": stride, "rows_fitting_stride": nfit, "mean_read_length": bases / max(nfit, 1),
     "reads_per_s": S * NR / (ms * 1e-3), "bases_per_s": bases / (ms * 1e-3), "ms_per_call": ms,
     "roofline": {"bound": "hbm", "achieved": steps * 128 / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                  "frac": steps * 128 / (ms * 1e-3) / 1e9 / PEAK, "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel",
