@@ -489,12 +489,22 @@ hipError_t scratch_cache::take(size_t bytes, hipStream_t stream, lease *out) {
     }
     if (pick < 0 && grow >= 0) {  // an idle buffer that is too small is replaced
         slot_t &s = slots_[grow];
+        // by one at least twice its size (hipFree waits for the whole device: batches that creep up in
+        // size, as a service's windows do, should not pay that at every step)
+        const size_t bigger = want > 2 * s.bytes ? want : 2 * s.bytes;
         (void)hipFree(s.p);
         s.p = nullptr;
         s.bytes = 0;
-        const hipError_t e = hipMalloc(&s.p, want);
-        if (e != hipSuccess) { s.p = nullptr; return e; }
-        s.bytes = want;
+        hipError_t e = hipMalloc(&s.p, bigger);
+        if (e == hipSuccess) {
+            s.bytes = bigger;
+        } else {
+            (void)hipGetLastError();
+            s.p = nullptr;
+            e = hipMalloc(&s.p, want);
+            if (e != hipSuccess) { s.p = nullptr; return e; }
+            s.bytes = want;
+        }
         s.recorded = false;
         pick = grow;
     }
