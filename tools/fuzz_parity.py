@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign on the GPU box (not part of the suite: it runs for as long as it is
+told to): random run streams x layouts (window span, k-mer table depth) x query lengths, the HIP path
+against the oracle -- intervals, counts, the 1-mismatch hit list against the dense matrices, read
+extraction row by row.  Test infrastructure: the oracle is the checker, as in tests/.
+Prints a progress line per configuration and one JSON line at the end; exit code 1 on any difference.
+usage: tools/fuzz_parity.py [seconds=300] [seed=1]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_binding  # noqa: E402
+import readserver_amd as rsb  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+L = rsb.lib()
+orc = oracle_binding.load()
+rng = np.random.default_rng(SEED)
+acgt = np.frombuffer(b"ACGT", np.uint8)
+t_end = time.time() + SECONDS
+done, failures = 0, []
+
+
+def make_runs(R, shape):
+    sym = rng.integers(0, 5, R)
+    ln = rng.integers(1, 32, R)
+    if shape == 1:
+        ln[:] = 31
+    elif shape == 2:
+        ln = rng.integers(1, 3, R)
+    elif shape == 3:
+        sym[rng.random(R) < 0.3] = 0
+    elif shape == 4:
+        sym = np.where(rng.random(R) < 0.995, 1 + (np.arange(R) // 5000) % 4, sym)
+    elif shape == 5:  # the library's own generators
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, int(rng.integers(1, 1 << 30)) | (int(rng.integers(0, 2)) << 63)) == 0
+        return runs
+    return ((sym << 5) | ln).astype(np.uint8)
+
+
+while time.time() < t_end:
+    R = int(2 ** rng.uniform(0, 21.5))
+    shape = int(rng.integers(0, 6))
+    runs = make_runs(R, shape)
+    span = 0 if rng.random() < 0.4 else int(rng.integers(2, 2945))
+    T = [None, 0, 0, int(rng.integers(2, 13))][int(rng.integers(0, 4))]
+    k = int(rng.integers(1, 71)) if rng.random() < 0.5 else 31
+    oix = orc.from_runs(runs)
+    n = oix.bwlen()
+    cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n)}
+    try:
+        with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span) as g:
+            Q = 20000
+            km = acgt[rng.integers(0, 4, (Q, k))].copy()
+            # k-mers that occur: spelled from the BWT's own rows by the oracle's extraction
+            rows = rng.integers(0, n, 400, dtype=np.uint64)
+            texts = []
+            for r in rows[:200]:
+                try:
+                    pre, post = oix.extract(int(r), cap=2000)
+                    texts.append((pre + post).encode())
+                except AssertionError:  # a walk longer than the oracle's buffer (streams with hardly any '$')
+                    texts.append(None)
+            j = 0
+            for tx in texts:
+                if tx is None:
+                    continue
+                for a in range(0, max(0, len(tx) - k + 1), max(1, k // 2)):
+                    if j < Q // 2:
+                        km[2 * j] = np.frombuffer(tx[a:a + k], np.uint8)
+                        j += 1
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            lo, up = rsb.find_intervals(g, km)
+            assert np.array_equal(lo, elo) and np.array_equal(up, eup), "intervals"
+            assert np.array_equal(rsb.count_kmers(g, km), np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64)), "counts"
+            if k <= 40:
+                m = 150
+                dlo, dup = rsb.find_intervals_1mm(g, km[:m])
+                want = []
+                for qi in range(m):
+                    want += [(qi,) + h for h in rsb.hits_1mm(km[qi].tobytes().decode(), dlo[qi], dup[qi])]
+                hl = rsb.hits_1mm_batch(g, km[:m])
+                got = [(int(r["query"]), int(r["pos"]), r["base"].decode(), int(r["lower"]), int(r["upper"])) for r in hl]
+                assert got == want, "1-mismatch hit list"
+                vlo, vup = oix.find_intervals(np.array([list(km[0])], np.uint8))
+                assert (int(dlo[0, 0]), int(dup[0, 0])) == (int(vlo[0]), int(vup[0])), "1-mismatch column 0"
+            stride = 2048
+            out = np.zeros((rows.size, stride), np.uint8)
+            ln = np.empty(rows.size, np.uint32)
+            pl = np.empty(rows.size, np.uint32)
+            assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, stride, ln.ctypes.data, pl.ctypes.data) == 0
+            for i in range(200):
+                tx = texts[i]
+                if tx is not None and len(tx) <= stride:
+                    assert ln[i] != 0xFFFFFFFF and out[i, :ln[i]].tobytes() == tx, f"extraction of row {int(rows[i])}"
+        done += 1
+        print(f"ok {done}: {cfg}", file=sys.stderr, flush=True)
+    except AssertionError as e:
+        failures.append({"config": cfg, "what": str(e)})
+        print(f"FAILED: {cfg}: {e}", file=sys.stderr, flush=True)
+        if len(failures) >= 5:
+            break
+    oix.close()
+print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "failures": failures}))
+sys.exit(1 if failures else 0)
