@@ -58,7 +58,8 @@ while time.time() < t_end:
     cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n)}
     try:
         with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span) as g:
-            Q = 20000
+            Q = 300000 if rng.random() < 0.1 else 20000  # the larger batch takes the one-lane-per-search kernel on a deep table
+            cfg["Q"] = Q
             km = acgt[rng.integers(0, 4, (Q, k))].copy()
             # k-mers that occur: spelled from the BWT's own rows by the oracle's extraction
             rows = rng.integers(0, n, 400, dtype=np.uint64)
@@ -81,6 +82,19 @@ while time.time() < t_end:
             lo, up = rsb.find_intervals(g, km)
             assert np.array_equal(lo, elo) and np.array_equal(up, eup), "intervals"
             assert np.array_equal(rsb.count_kmers(g, km), np.where(eup >= elo, eup - elo + 1, 0).astype(np.uint64)), "counts"
+            if rng.random() < 0.15:  # a shard set: this shard next to a second one, one fused launch
+                runs2 = make_runs(int(2 ** rng.uniform(0, 19)), int(rng.integers(0, 6)))
+                oix2 = orc.from_runs(runs2)
+                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5][int(rng.integers(0, 3))]) as g2:
+                    ss = rsb.ShardSet([g, g2])
+                    slo, sup = ss.find_intervals(km[:5000])
+                    e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
+                    ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
+                           np.array_equal(slo[1], e2lo) and np.array_equal(sup[1], e2up))
+                    ss.close()
+                oix2.close()
+                assert ok2, "shard set"
+                cfg["set"] = True
             if k <= 40:
                 m = 150
                 dlo, dup = rsb.find_intervals_1mm(g, km[:m])
