@@ -71,3 +71,21 @@ def test_synth_runs_host_matches_documented_mix(rsb):
     ln = a & 31
     assert ln.min() >= 1 and 9.5 < ln.mean() < 11.5
     assert (a >> 5).max() <= 4 and 0.005 < np.mean((a >> 5) == 0) < 0.02
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rsbwt.h is the drop-in boundary: it must compile as C99 with nothing but libc headers
+    (plain pointers and sizes, no C++ or torch types), and again from C++."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "rsbwt.h"\nint main(void) { return (int)sizeof(rsbwt_hit_1mm) - 24; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        r = subprocess.run([cc, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-x", "c" if cc == "gcc" else "c++",
+                            f"-I{os.path.join(root, 'include')}", "-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
