@@ -184,6 +184,13 @@ def main():
         # (20 GB of gathered intervals) and a lone GPU, and the scaling curve compares like with like.
         T = L.rsbwt_set_auto_ktab_depth(sset._s)
         free_b = torch.cuda.mem_get_info(dev)[0]
+        if a.rehearse_on_one_gpu:  # the ranks share one GPU: each sizes its tables out of its share
+            if world > 1:
+                dist.barrier()  # every rank's buffers exist before anyone looks at what is free
+                free_b = torch.cuda.mem_get_info(dev)[0]
+            free_b //= world
+            while T >= 2 and S * 8 * 4 ** T > free_b // 2:
+                T -= 1
         while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
             T += 1
         if world > 1:
