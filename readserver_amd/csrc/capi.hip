@@ -77,6 +77,10 @@ call_ctx *ctx_pool::acquire() {
                 if (created == 0) return nullptr;  // not even one context: report it
                 continue;
             }
+            if (hipHostMalloc(&c->h_pin, call_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                c->h_pin = nullptr;  // small calls go the ordinary way
+            }
             return c;
         }
         cv.wait(lock);
@@ -98,6 +102,7 @@ void ctx_pool::destroy() {
         (void)hipStreamSynchronize(c->st[0]);
         (void)hipStreamSynchronize(c->st[1]);
         if (c->d_stage) (void)hipFree(c->d_stage);
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
         (void)hipStreamDestroy(c->st[0]);
         (void)hipStreamDestroy(c->st[1]);
         delete c;
@@ -714,6 +719,29 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
     const size_t half = a_ascii + a_packed + a_valid + 2 * a_res;
     int rc;
     if ((rc = g.c->stage(Q > SLICE ? 2 * half : half)) != RSBWT_OK) return rc;
+    // A small call (everything fits the context's page-locked buffer): k-mers and answers travel through
+    // that buffer, one upload and one download, both truly asynchronous.
+    {
+        const size_t ascii_bytes = (Q - 1) * stride + k, res_bytes = (size_t)nshards * Q * 8;
+        const size_t h_res = (ascii_bytes + 15) & ~(size_t)15;
+        if (g.c->h_pin && Q <= SLICE && h_res + 2 * res_bytes <= call_ctx::PIN_BYTES) {
+            uint8_t *hp = (uint8_t *)g.c->h_pin;
+            uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_packed = d_ascii + a_ascii, *d_valid = d_packed + a_packed;
+            uint8_t *d_lo = d_valid + a_valid;  // d_up follows at d_lo + a_res = d_lo + res_bytes (m_max = Q)
+            hipStream_t st = g.c->st[0];
+            memcpy(hp, kmers, ascii_bytes);
+            HIP_OK(hipMemcpyAsync(d_ascii, hp, ascii_bytes, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_pack(d_ascii, Q, k, stride, d_packed, d_valid, st);
+            if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, Q, k, d_lo, d_lo + a_res, counts_only, st, nullptr);
+            if (rc) return rc;
+            HIP_OK(hipMemcpyAsync(hp + h_res, d_lo, (counts_only ? 1 : 2) * res_bytes, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            memcpy(lower, hp + h_res, res_bytes);
+            if (!counts_only) memcpy(upper, hp + h_res + res_bytes, res_bytes);
+            return RSBWT_OK;
+        }
+    }
     struct slice_t {
         size_t q0 = 0, m = 0;
         uint8_t *d_lo = nullptr, *d_up = nullptr;

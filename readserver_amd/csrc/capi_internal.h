@@ -27,6 +27,12 @@ struct call_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     int stage(size_t bytes);  // grows the staging buffer; RSBWT_OK or RSBWT_ENOMEM
+    // a small page-locked host buffer: the k-mers and answers of a SMALL call travel through it (a copy to
+    // or from pageable memory costs the runtime a staging step and a wait of its own, three of them are
+    // half of a lone request's latency); nullptr when it could not be had -- the call then goes the
+    // ordinary way
+    static constexpr size_t PIN_BYTES = 256u << 10;
+    void *h_pin = nullptr;
 };
 
 struct ctx_pool {
