@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-single-check", action="store_true",
                     help="skip the single-shard (configs[1]) launches after the timed region: profile passes want "
                          "only the fused launches under the kernel's name")
+    ap.add_argument("--gather-unpacked", action="store_true",
+                    help="N > 1: gather the 16-byte {lower, upper} pairs as they are instead of their 10-byte form")
     ap.add_argument("--counts", action="store_true",
                     help="variant (N = 1 only, not the headline): the service's count path -- rsbwt_set_count_dev, one u64 "
                          "count per (query, shard) instead of the interval pairs; checked against the pairs of one launch")
@@ -173,7 +175,11 @@ def main():
     d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
     d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
-    gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays)
+    # N > 1: the pairs travel as 10-byte {lower:40, width:40} records (exact for every interval; 5/8 of the
+    # bytes): an xGMI link moves ~77 GB/s per direction, so 1.28 GB of 16-byte pairs per peer and batch would
+    # take longer than the 12 ms search that produced them
+    wire_packed = world > 1 and not a.separate_arrays and not a.gather_unpacked
+    gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev)
     d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
     hold = torch.empty(int(a.hold_gb * (1 << 30)), dtype=torch.uint8, device=dev) if a.hold_gb > 0 else None
     if a.ktab_depth == 0:
@@ -254,9 +260,9 @@ def main():
             ok(L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
         else:
             ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair), sp))
-        if host_pair is not None:
+        if host_pair is not None and not wire_packed:
             host_pair.copy_(pair)
-        gat.submit(i)
+        gat.submit(i, source=pair if wire_packed else None)
 
     def barrier():
         gat.drain()
@@ -308,12 +314,20 @@ def main():
     gather_verified = None
     if world > 1:
         last = step_no[0] - 1
-        mine_sum = gat.pair(last).sum().reshape(1).to(cdev)
+        sent = gat.wire(last) if wire_packed else gat.pair(last)
+        mine_sum = sent.sum(dtype=torch.int64).reshape(1).to(cdev)
+        exact = torch.ones(1, dtype=torch.int64, device=cdev)
+        if wire_packed:  # the 10-byte form carries this rank's pairs exactly
+            src = d_res[last % 2] if d_res is not None else gat.pair(last)
+            back = gat.unpack_block(sent.to(src.device))
+            exact[0] = int(torch.equal(back, src))
+            del back
         sums = [torch.empty_like(mine_sum) for _ in range(world)]
         dist.all_gather(sums, mine_sum)
+        dist.all_reduce(exact, op=dist.ReduceOp.MIN)
         if rank == 0:
             got = gat.result(last)
-            gather_verified = all(int(got[r].sum().item()) == int(sums[r].item()) for r in range(world))
+            gather_verified = bool(exact.item()) and all(int(got[r].sum(dtype=torch.int64).item()) == int(sums[r].item()) for r in range(world))
 
     searches = world * S * Q * a.steps
     value = searches / dt
@@ -384,6 +398,8 @@ def main():
             "index_hbm_bytes_per_gpu": hbm, "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
             "index_build_s": round(t_build, 2),
             "gather_verified": gather_verified,
+            "gathered_as": (None if world == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact"
+                            if wire_packed else "16-byte pairs"),
             "results": ("counts[S][Q] (rsbwt_set_count_dev: the service's count path, NOT the headline)" if a.counts else
                         "lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
             "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),

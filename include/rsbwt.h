@@ -180,6 +180,15 @@ int rsbwt_count_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_
  * bytes per k-mer, written by one store per search (the separate arrays cost two scattered stores). */
 int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                                   void *d_pairs, void *stream);
+/* Interval pairs for the wire.  Every interval findInterval leaves (empty ones, the (1, 0) of an invalid
+ * k-mer and the reference's (0, 2^64-1) corner included) is {lower < 2^40, upper = lower + width - 1 mod 2^64,
+ * width < 2^40}, so {lower:40, width:40} carries it exactly: n pairs (16 n bytes, as rsbwt_*_interval_pairs_dev
+ * writes them) <-> rsbwt_packed_pairs_bytes(n) = 10 n bytes rounded up to 4.  What a rank sends to the root GPU
+ * of a multi-GPU job (5/8 of the bytes over xGMI).  d_unfit (optional u32 in HBM, zeroed by the caller) counts
+ * pairs that do not fit the record -- none does for an interval this library produced. */
+size_t rsbwt_packed_pairs_bytes(size_t n);
+int rsbwt_pack_interval_pairs_dev(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, int device, void *stream);
+int rsbwt_unpack_interval_pairs_dev(const void *d_packed, size_t n, void *d_pairs, int device, void *stream);
 /* 1-mismatch search of m packed k-mers: d_lower/d_upper [m][3k+1] (rsbwt_find_intervals_1mm's layout);
  * d_scratch: rsbwt_1mm_scratch_bytes(h, m, k) bytes. */
 size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);

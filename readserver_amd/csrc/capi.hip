@@ -830,6 +830,26 @@ int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *
     return search_dev(h, d_packed, d_valid, Q, k, d_pairs, nullptr, false, (hipStream_t)stream, &ex);
 }
 
+size_t rsbwt_packed_pairs_bytes(size_t n) { return (n * 10 + 3) / 4 * 4; }
+
+int rsbwt_pack_interval_pairs_dev(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, int device, void *stream) {
+    if (n == 0) return RSBWT_OK;
+    if (!d_pairs || !d_packed) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const hipError_t e = launch_pack_pairs10(d_pairs, n, d_packed, d_unfit, (hipStream_t)stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "pack kernel launch");
+}
+
+int rsbwt_unpack_interval_pairs_dev(const void *d_packed, size_t n, void *d_pairs, int device, void *stream) {
+    if (n == 0) return RSBWT_OK;
+    if (!d_pairs || !d_packed) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const hipError_t e = launch_unpack_pairs10(d_packed, n, d_pairs, (hipStream_t)stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "unpack kernel launch");
+}
+
 int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                          uint64_t *lower, uint64_t *upper) {
     return search_host(h, kmers, Q, k, stride, lower, upper, false);

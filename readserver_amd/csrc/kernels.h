@@ -94,6 +94,10 @@ hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, cons
 // d_block_counts: (n_searches / 16384 + 2) u64 of scratch.
 hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t n_searches, void *d_hits, size_t cap,
                                void *d_total, void *d_block_counts, hipStream_t stream);
+// {lower, upper} pairs <-> 10-byte {lower:40, width:40} records (kernels.hip); d_unfit: optional u32 counter of
+// pairs that do not fit the record (none does for an interval findInterval produced)
+hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, hipStream_t stream);
+hipError_t launch_unpack_pairs10(const void *d_packed, size_t n, void *d_pairs, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each

@@ -412,6 +412,79 @@ hit_scatter_kernel(const uint64_t *__restrict__ bits, const ulonglong2 *__restri
     }
 }
 
+// ---- interval pairs for the wire: 10 bytes instead of 16 ----------------------------------------
+// Every interval findInterval leaves -- empty ones, the (1, 0) of an invalid k-mer and the reference's
+// (0, 2^64 - 1) corner included -- satisfies upper = lower + width - 1 (mod 2^64) with lower < 2^40 and
+// 0 <= width < 2^40 (Occ is monotone, so an empty interval is always (lower, lower - 1)).  {lower:40,
+// width:40} therefore carries a pair exactly; the gather of a batch's pairs to the root GPU moves 5/8
+// of the bytes (xGMI links run ~77 GB/s per direction: 1.28 GB of pairs per peer and batch would take
+// longer than the search that produced them).  Four pairs (64 B) <-> ten dwords per thread.
+__global__ void __launch_bounds__(256)
+pack_pairs10_kernel(const ulonglong2 *__restrict__ pairs, size_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ unfit) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = 4 * t;
+    uint64_t f[8];  // lo0, w0, lo1, w1, ...  (a thread past the end packs zeros and writes nothing)
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ulonglong2 p = make_ulonglong2(0, 0);
+        if (i0 + j < n) p = pairs[i0 + j];
+        const uint64_t w = p.y - p.x + 1ull;
+        bad |= i0 + j < n && ((p.x >> 40) != 0ull || (w >> 40) != 0ull);
+        f[2 * j] = p.x & 0xFFFFFFFFFFull;
+        f[2 * j + 1] = w & 0xFFFFFFFFFFull;
+    }
+    if (bad && unfit) atomicAdd(unfit, 1u);
+    // eight 40-bit fields = 320 bits = ten dwords, little endian, field k at bit 40 k
+    uint32_t d[10];
+#pragma unroll
+    for (int w = 0; w < 10; ++w) {
+        const int bit = 32 * w, k0 = bit / 40, off = bit - 40 * k0;  // dword w starts inside field k0
+        uint64_t v = f[k0] >> off;
+        if (off > 8 && k0 + 1 < 8) v |= f[k0 + 1] << (40 - off);
+        d[w] = (uint32_t)v;
+    }
+    // through LDS, so that the block's 2,560 dwords leave as ten runs of 256 consecutive ones instead of
+    // 256 interleaved 40-byte pieces
+    __shared__ uint32_t turn[2560];
+#pragma unroll
+    for (int w = 0; w < 10; ++w) turn[10 * threadIdx.x + w] = d[w];
+    __syncthreads();
+    const size_t block0 = (size_t)blockIdx.x * 2560;               // first dword of this block's records
+    const size_t total = (n * 10 + 3) / 4;                          // dwords the whole buffer holds
+#pragma unroll
+    for (int w = 0; w < 10; ++w) {
+        const size_t at = block0 + 256u * w + threadIdx.x;
+        if (at < total) out[at] = turn[256 * w + threadIdx.x];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+unpack_pairs10_kernel(const uint32_t *__restrict__ in, size_t n, ulonglong2 *__restrict__ pairs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = 4 * t;
+    __shared__ uint32_t turn[2560];
+    const size_t block0 = (size_t)blockIdx.x * 2560, total = (n * 10 + 3) / 4;
+#pragma unroll
+    for (int w = 0; w < 10; ++w) {  // the block's dwords in ten coalesced runs
+        const size_t at = block0 + 256u * w + threadIdx.x;
+        turn[256 * w + threadIdx.x] = at < total ? in[at] : 0u;
+    }
+    __syncthreads();
+    uint32_t d[10];
+#pragma unroll
+    for (int w = 0; w < 10; ++w) d[w] = turn[10 * threadIdx.x + w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint64_t f[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int bit = 40 * (2 * j + h), w0 = bit / 32, off = bit - 32 * w0;  // off is 0, 8, 16 or 24
+            const uint64_t lo64 = (uint64_t)d[w0] | ((uint64_t)d[w0 + 1 < 10 ? w0 + 1 : 9] << 32);
+            f[h] = (lo64 >> off) & 0xFFFFFFFFFFull;
+        }
+        if (i0 + j < n) pairs[i0 + j] = make_ulonglong2(f[0], f[0] + f[1] - 1ull);
+    }
+}
+
 // query / query_exactmatch (query.cpp:87-120) over the extracted rows of a batch of k-mers: row i
 // belongs to k-mer owner[i]; flags[i] = 1 when the read equals the k-mer (exact match: the whole read
 // is the query, query.cpp:112-116).
@@ -642,6 +715,20 @@ hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t 
                        (unsigned long long *)d_total);
     hipLaunchKernelGGL(hit_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const uint64_t *)d_bits,
                        (const ulonglong2 *)d_sparse, nwords, (const unsigned long long *)d_block_counts, (ulonglong2 *)d_hits, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_pairs10_kernel, dim3(blocks256((n + 3) / 4)), dim3(256), 0, stream, (const ulonglong2 *)d_pairs, n,
+                       (uint32_t *)d_packed, (uint32_t *)d_unfit);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_pairs10(const void *d_packed, size_t n, void *d_pairs, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_pairs10_kernel, dim3(blocks256((n + 3) / 4)), dim3(256), 0, stream, (const uint32_t *)d_packed, n,
+                       (ulonglong2 *)d_pairs);
     return hipGetLastError();
 }
 

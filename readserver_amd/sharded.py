@@ -54,6 +54,61 @@ def broadcast_queries(kmers, src=0, group=None):
     return kmers
 
 
+_M40 = (1 << 40) - 1
+
+
+def packed_pairs_bytes(n):
+    return (n * 10 + 3) // 4 * 4
+
+
+def pack_pairs(pairs, out=None):
+    """[..., 2] int64 {lower, upper} -> uint8 [packed_pairs_bytes(n)]: {lower:40, width:40} per pair, width =
+    upper - lower + 1 mod 2^64 (include/rsbwt.h, rsbwt_pack_interval_pairs_dev).  On a GPU tensor the
+    library's kernel does it; this torch form serves host tensors (gloo tests, the one-GPU rehearsal) and is
+    what the kernel is tested against."""
+    flat = pairs.reshape(-1, 2)
+    n = flat.shape[0]
+    if flat.is_cuda:
+        from ._native import lib
+        import ctypes as C
+        if out is None or out.device != flat.device:
+            out = torch.empty(packed_pairs_bytes(n), dtype=torch.uint8, device=flat.device)
+        rc = lib().rsbwt_pack_interval_pairs_dev(C.c_void_p(flat.data_ptr()), n, C.c_void_p(out.data_ptr()), None,
+                                                 flat.device.index or 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib().rsbwt_last_error().decode())
+        return out
+    lo = flat[:, 0] & _M40
+    w = (flat[:, 1] - flat[:, 0] + 1) & _M40
+    f = torch.stack([lo, w], 1).reshape(-1)  # 2n fields of 40 bits
+    by = torch.stack([(f >> (8 * b)) & 0xFF for b in range(5)], 1).to(torch.uint8).reshape(-1)  # little endian
+    if out is None:
+        out = torch.zeros(packed_pairs_bytes(n), dtype=torch.uint8)
+    out[: by.numel()] = by
+    return out
+
+
+def unpack_pairs(packed, n, out=None):
+    """The inverse: n pairs as an [n, 2] int64 tensor (uint64 bit patterns)."""
+    if packed.is_cuda:
+        from ._native import lib
+        import ctypes as C
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.int64, device=packed.device)
+        rc = lib().rsbwt_unpack_interval_pairs_dev(C.c_void_p(packed.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                   packed.device.index or 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib().rsbwt_last_error().decode())
+        return out
+    by = packed[: 10 * n].to(torch.int64).reshape(-1, 5)
+    f = sum(by[:, b] << (8 * b) for b in range(5)).reshape(n, 2)
+    res = torch.stack([f[:, 0], f[:, 0] + f[:, 1] - 1], 1)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
 class IntervalGatherer:
     """Gather of per-shard intervals to rank `dst`, pipelined behind the next batch's search.
 
@@ -65,16 +120,30 @@ class IntervalGatherer:
     On rank `dst`, `result(i)` is the list of `world` tensors [2, S_local, Q] of batch i.
     """
 
-    def __init__(self, s_local, q, device, depth=2, dst=0, group=None, dtype=torch.int64, interleaved=False):
+    def __init__(self, s_local, q, device, depth=2, dst=0, group=None, dtype=torch.int64, interleaved=False,
+                 packed=False, wire_device=None):
         """interleaved: buffers are [S_local, Q, 2] = {lower, upper} pairs (what rsbwt_*_interval_pairs_dev
-        writes) instead of [2, S_local, Q]."""
+        writes) instead of [2, S_local, Q].  packed (with interleaved): what travels is the 10-byte form of the
+        pairs (pack_pairs): 5/8 of the bytes over xGMI; `result_packed(i)` holds the ranks' blocks as they
+        arrived, `unpack_block` turns one back into pairs.  wire_device: where the packed buffers live when that
+        is not `device` (the one-GPU rehearsal packs on the GPU and gathers host copies over gloo)."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.dst, self.group, self.depth = dst, group, depth
         shape = (s_local, q, 2) if interleaved else (2, s_local, q)
         self._pairs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
         self._out = None
-        if self.world > 1 and self.rank == dst:
+        self.packed = bool(packed) and self.world > 1
+        self.n_pairs = s_local * q
+        if self.packed:
+            if not interleaved:
+                raise ValueError("packed gathering needs the interleaved {lower, upper} layout")
+            wd = wire_device if wire_device is not None else device
+            nb = packed_pairs_bytes(self.n_pairs)
+            self._wire = [torch.empty(nb, dtype=torch.uint8, device=wd) for _ in range(depth)]
+            if self.rank == dst:
+                self._out = [[torch.empty(nb, dtype=torch.uint8, device=wd) for _ in range(self.world)] for _ in range(depth)]
+        elif self.world > 1 and self.rank == dst:
             self._out = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)]
                          for _ in range(depth)]
         self._work = [None] * depth
@@ -90,10 +159,19 @@ class IntervalGatherer:
             self._work[i % self.depth] = None
         return self._pairs[i % self.depth]
 
-    def submit(self, i):
+    def submit(self, i, source=None):
+        """source: where batch i's pairs are when that is not pair(i) (the rehearsal searches into HBM)."""
         if self.world == 1:
             return
         j = i % self.depth
+        if self.packed:
+            src = self._pairs[j] if source is None else source
+            wire = pack_pairs(src, out=self._wire[j])  # on the GPU: the library's kernel, on the stream the search ran on
+            if wire.data_ptr() != self._wire[j].data_ptr():  # the rehearsal: packed in HBM, gathered from the host
+                self._wire[j].copy_(wire)
+            self._work[j] = dist.gather(self._wire[j], self._out[j] if self.rank == self.dst else None,
+                                        dst=self.dst, group=self.group, async_op=True)
+            return
         self._work[j] = dist.gather(self._pairs[j], self._out[j] if self.rank == self.dst else None,
                                     dst=self.dst, group=self.group, async_op=True)
 
@@ -104,6 +182,15 @@ class IntervalGatherer:
                 self._work[j] = None
 
     def result(self, i):
+        """Rank dst: the list of `world` blocks of batch i -- pairs, or (packed) their 10-byte form."""
         if self.world == 1:
             return [self._pairs[i % self.depth]]
         return self._out[i % self.depth] if self.rank == self.dst else None
+
+    def wire(self, i):
+        """What this rank sent for batch i (packed mode)."""
+        return self._wire[i % self.depth]
+
+    def unpack_block(self, block):
+        """One gathered 10-byte block back into [S_local, Q, 2] pairs."""
+        return unpack_pairs(block, self.n_pairs).reshape(self._pairs[0].shape)

@@ -90,7 +90,7 @@ def test_world2_gather_and_reduce(rsb, tmp_path):
     assert q.get() == "ok"
 
 
-def _pipeline_worker(rank, world, port, q, interleaved=False):
+def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -98,7 +98,7 @@ def _pipeline_worker(rank, world, port, q, interleaved=False):
     try:
         from readserver_amd import sharded
         S, Q, steps = 2, 1000, 7
-        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2, interleaved=interleaved)
+        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2, interleaved=interleaved, packed=packed)
         lo_of = (lambda t: t[..., 0]) if interleaved else (lambda t: t[0])  # {lower, upper} pairs / two arrays
         up_of = (lambda t: t[..., 1]) if interleaved else (lambda t: t[1])
         seen = {}
@@ -107,6 +107,12 @@ def _pipeline_worker(rank, world, port, q, interleaved=False):
             assert buf.shape == ((S, Q, 2) if interleaved else (2, S, Q))
             lo_of(buf)[:] = 1000 * i + 10 * rank + torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
             up_of(buf)[:] = lo_of(buf) + 7
+            if packed:  # the corners the 10-byte form must carry: empty, invalid (1, 0), the (0, 2^64-1) wrap, 2^40-1
+                up_of(buf)[0, :4] = lo_of(buf)[0, :4] - 1
+                buf[1, 0] = torch.tensor([1, 0])
+                buf[1, 1] = torch.tensor([0, -1])
+                buf[1, 2] = torch.tensor([(1 << 40) - 1, (1 << 40) - 2])
+                buf[1, 3] = torch.tensor([1, (1 << 40) - 1])
             g.submit(i)
             if rank == 0 and i >= 1:
                 # batch i - 1 is complete once its handle has been waited for; acquire(i + 1) does
@@ -114,7 +120,21 @@ def _pipeline_worker(rank, world, port, q, interleaved=False):
                 g._work[(i - 1) % 2].wait()
                 seen[i - 1] = [t.clone() for t in g.result(i - 1)]
         g.drain()
-        if rank == 0:
+        if rank == 0 and packed:  # what arrived is the 10-byte form: 5/8 of the pairs' bytes
+            assert all(t.dtype == torch.uint8 and t.numel() == sharded.packed_pairs_bytes(S * Q) for t in g.result(0))
+            seen[steps - 1] = [t.clone() for t in g.result(steps - 1)]
+            seen = {i: [g.unpack_block(t) for t in v] for i, v in seen.items()}
+            for i in range(steps):
+                for r in range(world):
+                    b = seen[i][r]
+                    assert torch.equal(b[1, 0], torch.tensor([1, 0])) and torch.equal(b[1, 1], torch.tensor([0, -1]))
+                    assert torch.equal(b[1, 2], torch.tensor([(1 << 40) - 1, (1 << 40) - 2]))
+                    assert torch.equal(b[1, 3], torch.tensor([1, (1 << 40) - 1]))
+                    assert torch.equal(b[0, :4, 1], b[0, :4, 0] - 1)
+                    assert torch.equal(b[0, 4:, 0], (1000 * i + 10 * r + torch.arange(S * Q, dtype=torch.int64).reshape(S, Q))[0, 4:])
+                    assert torch.equal(b[0, 4:, 1], b[0, 4:, 0] + 7)
+            q.put("ok")
+        elif rank == 0:
             seen[steps - 1] = [t.clone() for t in g.result(steps - 1)]
             base = torch.arange(S * Q, dtype=torch.int64).reshape(S, Q)
             for i in range(steps):
@@ -128,15 +148,16 @@ def _pipeline_worker(rank, world, port, q, interleaved=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("interleaved", [False, True, "packed"])
 def test_world2_pipelined_interval_gather(interleaved):
     """bench.py's N > 1 data path: searches write into one of two resident buffers while the other one's
     gather to rank 0 is in flight ({lower, upper} pairs as rsbwt_set_find_interval_pairs_dev writes them,
     or two arrays)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + 3 + int(interleaved)) % 2000
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, interleaved)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + 3 + [False, True, "packed"].index(interleaved)) % 2000
+    packed = interleaved == "packed"
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, bool(interleaved), packed)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

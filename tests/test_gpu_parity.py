@@ -1121,3 +1121,55 @@ def test_gpu_hit_list_that_outgrows_its_first_buffer(rsb, tmp_path):
             rec = d_hits.cpu().numpy().view(np.uint64)
             assert [(int(r[2]), int(r[0]), int(r[1])) for r in rec[:n]] == dense[:n] and (rec[:n, 3] == 0).all()
             assert (rec[n:] == np.uint64(2**64 - 1)).all()  # nothing past the capacity
+
+
+@pytest.mark.gpu
+def test_gpu_interval_pairs_for_the_wire(rsb, oracle):
+    """rsbwt_pack / unpack_interval_pairs_dev: {lower:40, width:40} records carry every interval exactly --
+    real search output (hits, empty intervals, an invalid k-mer's (1, 0)), the reference's (0, 2^64-1)
+    corner and the 2^40-1 extremes -- byte for byte what the torch reference in sharded.py packs, for
+    every tail length; a pair that does not fit is counted."""
+    import ctypes as C
+    import torch
+    from readserver_amd import sharded
+    L = rsb.lib()
+    R = 400000
+    runs = np.empty(R, np.uint8)
+    assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 606) == 0
+    rng = np.random.default_rng(9)
+    with rsb.GpuBWT(runs=runs) as g:
+        km = _random_kmers(rng, 50001, 12)  # 4^12 = 1.7e7 against 4e6 symbols: hits and misses
+        km[3, 5] = ord("N")
+        lo, up = rsb.find_intervals(g, km)
+        assert (up >= lo).any() and (up < lo).any()
+    pairs = np.stack([lo, up], 1)
+    pairs[7] = (0, 2**64 - 1)
+    pairs[8] = (2**40 - 1, 2**40 - 2)
+    pairs[9] = (1, 2**40 - 1)
+    t = torch.from_numpy(pairs.view(np.int64))
+    p = lambda x: C.c_void_p(x.data_ptr())
+    for n in (1, 2, 3, 4, 5, 7, 1003, 50001):
+        sub = t[:n].contiguous()
+        want = sharded.pack_pairs(sub)
+        assert want.numel() == L.rsbwt_packed_pairs_bytes(n) == sharded.packed_pairs_bytes(n)
+        d_pairs = sub.cuda()
+        d_pk = torch.full((want.numel() + 16,), 0xAB, dtype=torch.uint8, device="cuda:0")
+        d_bad = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        assert L.rsbwt_pack_interval_pairs_dev(p(d_pairs), n, p(d_pk), p(d_bad), 0, None) == 0
+        torch.cuda.synchronize()
+        got = d_pk.cpu()
+        assert torch.equal(got[: 10 * n], want[: 10 * n]) and int(d_bad.item()) == 0
+        assert (got[want.numel():] == 0xAB).all()  # nothing past the buffer's size
+        d_back = torch.full((n + 2, 2), -7, dtype=torch.int64, device="cuda:0")
+        assert L.rsbwt_unpack_interval_pairs_dev(p(d_pk), n, p(d_back), 0, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_back[:n].cpu(), sub) and (d_back[n:] == -7).all()
+        assert torch.equal(sharded.unpack_pairs(want, n), sub)
+        # the wrappers on GPU tensors go through the same kernels
+        assert torch.equal(sharded.unpack_pairs(sharded.pack_pairs(d_pairs), n).cpu(), sub)
+    bad = torch.tensor([[1 << 40, (1 << 40) + 5], [5, 4], [0, 1 << 41]], dtype=torch.int64, device="cuda:0")
+    d_pk = torch.zeros(32, dtype=torch.uint8, device="cuda:0")
+    d_bad = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    assert L.rsbwt_pack_interval_pairs_dev(p(bad), 3, p(d_pk), p(d_bad), 0, None) == 0
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == 1  # one thread saw pairs that do not fit
