@@ -76,7 +76,7 @@ def parse():
                          "count per (query, shard) instead of the interval pairs; checked against the pairs of one launch")
     ap.add_argument("--hold-gb", type=float, default=0.0,
                     help="rehearsal aid: hold this much HBM while the k-mer tables are sized, as rank 0 of an N-GPU "
-                         "job holds the gathered intervals (20.5 GB at N = 8)")
+                         "job holds the gathered intervals (12.8 GB of 10-byte records at N = 8; 20.5 GB unpacked)")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -187,7 +187,7 @@ def main():
         # Here every buffer of the job already exists (rank 0's gathered intervals included), so the
         # tables may take what is left but a reserve for the search's start records (1.4 GB), the
         # single-shard check and RCCL's own buffers: the same depth then fits rank 0 of an 8-GPU job
-        # (20 GB of gathered intervals) and a lone GPU, and the scaling curve compares like with like.
+        # (13-20 GB of gathered intervals) and a lone GPU, and the scaling curve compares like with like.
         T = L.rsbwt_set_auto_ktab_depth(sset._s)
         free_b = torch.cuda.mem_get_info(dev)[0]
         if a.rehearse_on_one_gpu:  # the ranks share one GPU: each sizes its tables out of its share
