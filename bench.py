@@ -16,6 +16,10 @@ shards.  `--shards-per-gpu 1` is configs[1] (one shard, deepest k-mer table).
 
     python bench.py [--gpus N --steps K --warmup W] [--runs R --queries Q --shards-per-gpu S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(self_launch below: the parent makes no GPU call, starts torch.distributed.run as a child, relays
+rank 0's line and exits with the child's code).
 """
 import argparse
 import ctypes as C
@@ -110,8 +114,45 @@ def usable_cpus():
     return n
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch_cmd(argv, n, port):
+    """The command a plain `python bench.py --gpus N ...` turns itself into: one rank per GPU under
+    torch.distributed.run on this node, every rank running this same script with the same arguments
+    (the reference's shape: every request goes to every partition, src/service/server.cpp:124,578)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv):
+    """Parent of an N > 1 run started without a launcher.  It must not have touched the GPU (no
+    torch.cuda.*, no rsb.lib()): a process that has initialised HIP may not be replaced or forked into
+    the ranks, so the ranks are children started from a clean process and this one only waits."""
+    import subprocess
+    assert "torch" not in sys.modules and "readserver_amd" not in sys.modules, "the launcher parent imports no GPU code"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = self_launch_cmd(argv, a.gpus, int(os.environ.get("BENCH_MASTER_PORT", "0")) or free_port())
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, env=env)  # stdout/stderr inherited: rank 0's JSON line arrives on our stdout
+    try:
+        rc = p.wait()
+    except KeyboardInterrupt:
+        p.terminate()
+        rc = p.wait()
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a, sys.argv[1:])
     import torch
     import torch.distributed as dist
     import readserver_amd as rsb

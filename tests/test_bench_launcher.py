@@ -1,0 +1,73 @@
+"""`python bench.py --gpus N` launches its own N ranks (the driver calls it exactly like that).
+
+The parent may not have made any GPU call before it starts the ranks -- a process that has
+initialised HIP must not be forked or replaced on this pool -- so these tests hold it to importing
+neither torch nor the library, to the command it builds, and to its exit code."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_launch_command_shape():
+    b = _bench()
+    cmd = b.self_launch_cmd(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]  # the ranks get the same arguments
+
+
+def test_parent_touches_no_gpu_code_and_relays_the_exit_code(tmp_path):
+    """A stand-in for torch.distributed.run records what it was started with and how: the parent
+    reached it without torch or the library in sys.modules, and passes its exit code on."""
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import sys, json, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench, subprocess\n"
+        "seen = {}\n"
+        "class P:\n"
+        "    def __init__(self, cmd, env=None):\n"
+        "        seen['cmd'] = cmd; seen['mods'] = [m for m in ('torch', 'readserver_amd', 'numpy.core._multiarray_umath') if m in sys.modules]\n"
+        "        seen['ipc'] = env.get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
+        "    def wait(self):\n"
+        "        return 7\n"
+        "subprocess.Popen = P\n"
+        "sys.argv = ['bench.py', '--gpus', '2', '--rehearse-on-one-gpu']\n"
+        "os.environ.pop('WORLD_SIZE', None)\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    seen['rc'] = e.code\n"
+        "print(json.dumps(seen))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(probe)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    import json
+    seen = json.loads(out.stdout.strip().splitlines()[-1])
+    assert seen["rc"] == 7
+    assert "torch" not in seen["mods"] and "readserver_amd" not in seen["mods"]
+    assert seen["ipc"] == "0"
+    assert seen["cmd"][-3:] == ["--gpus", "2", "--rehearse-on-one-gpu"]
+    assert "--nproc-per-node=2" in seen["cmd"]
+
+
+def test_inside_a_launcher_it_does_not_launch_again():
+    """With WORLD_SIZE set (a rank under torch.distributed.run) the script goes straight on; here that
+    ends at the GPU check (no GPU in the build container) or at the world-size check."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and "launching" not in out.stderr
