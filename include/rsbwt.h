@@ -387,6 +387,12 @@ void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6);
 int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
                                uint64_t *stats6, uint64_t *first_bad);
 
+/* Test hook (answers no query): overwrites n bytes of the index in HBM -- region 0: the window lines,
+ * 1: the handle's own k-mer table -- so that tests can hold the kernels to what they do with a DAMAGED
+ * index: no read outside the index, every wave drains, a table entry that is not an interval of this BWT
+ * is not believed.  RSBWT_ERANGE outside the region. */
+int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

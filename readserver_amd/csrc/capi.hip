@@ -75,6 +75,7 @@ call_ctx *ctx_pool::acquire() {
                 lock.lock();
                 --created;
                 if (created == 0) return nullptr;  // not even one context: report it
+                cv.wait(lock);  // others exist: wait for one of them instead of asking the runtime again at once
                 continue;
             }
             if (hipHostMalloc(&c->h_pin, call_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
@@ -441,6 +442,23 @@ uint64_t rsbwt_far_lines(const rsbwt_t *h) { return h->far_lines; }
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h) { return h->spilled_symbols; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
+
+// Test hook: overwrites n bytes of the index in HBM (region 0: the lines, 1: the k-mer table) with `bytes`,
+// so that a test can hold the kernels to what they do with a DAMAGED index (never read outside it, every
+// wave drains); answers no query.
+int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes, size_t n) {
+    if (!h || (!bytes && n)) return fail(RSBWT_EINVAL, "null argument");
+    const uint64_t size = region == 0 ? h->view.nlines * (uint64_t)LINE_BYTES
+                          : region == 1 && h->view.ktab && h->ktab_owned ? 8ull << (2u * h->view.ktab_depth) : 0ull;
+    if (offset > size || n > size - offset) return fail(RSBWT_ERANGE, "poke outside the region (%llu bytes)", (unsigned long long)size);
+    if (n == 0) return RSBWT_OK;
+    int rc = use_device(h->device);
+    if (rc != RSBWT_OK) return rc;
+    char *base = region == 0 ? (char *)h->view.lines : (char *)h->view.ktab;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(base + offset, bytes, n, hipMemcpyHostToDevice);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "rsbwt_debug_poke");
+}
 
 // ---- class BWT mirrors ------------------------------------------------------------------------
 

@@ -130,6 +130,7 @@ __global__ void ktab_encode_kernel(const uint64_t *__restrict__ lower, const uin
 // positions past their window's own pieces take the general walk (line_format.h).
 // ------------------------------------------------------------------------------------------
 __device__ uint32_t thread_char_occ(const shard_view &v, uint64_t p, uint64_t *occ_of_char) {
+    if (p >= v.n) p = v.n - 1ull;  // never for a walk over a sound index: keeps the line address inside it
     uint32_t pin;
     const uint32_t w = fast_window(p, v.sp.S, v.sp.inv, pin);
     const uint32_t o = pin + 1u;
@@ -229,9 +230,13 @@ select_sample_kernel(const shard_view ix, uint32_t *__restrict__ sel, uint64_t s
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= ix.nwin) return;
     for (uint32_t c = 0; c <= 4; ++c) {
-        const uint64_t cb = count_before_window(ix, w, c);
-        const uint64_t ce = count_before_window(ix, w + 1, c);
-        if (ce == cb) continue;
+        // (held to the symbol's total: the sample index below is then inside the table whatever the lines
+        // say -- a damaged count word would otherwise send this loop writing far outside it)
+        const uint64_t tc = ix.total[c];
+        uint64_t cb = count_before_window(ix, w, c);
+        uint64_t ce = count_before_window(ix, w + 1, c);
+        ce = ce < tc ? ce : tc;
+        if (ce <= cb) continue;
         // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
         for (uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT; (m << SEL_SHIFT) < ce; ++m)
             sel[c * stride_m + m] = (uint32_t)w;

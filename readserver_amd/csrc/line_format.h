@@ -153,7 +153,8 @@ RSB_HD void walk_window(const shard_view &v, uint64_t w, F &&f) {
             const uint32_t *Cn = v.lines + spill_line_of_window(w) * LINE_DWORDS + m.cdw;
             const uint32_t csym = (Cn[0] >> 24) | ((Cn[1] >> 24) << 8);
             uint32_t seen = 0;
-            for (uint32_t i = 0; i < CHUNK_MAX_PIECES && seen < csym; ++i) {
+            // (the dword bound matters for a damaged header only: a built chunk ends inside its spill line)
+            for (uint32_t i = 0; i < CHUNK_MAX_PIECES && seen < csym && m.cdw + 2u + (i >> 2) < LINE_DWORDS; ++i) {
                 const uint32_t u = dword_piece(Cn + 2, i);
                 if ((u & 31u) == 0u) break;
                 seen += u & 31u;

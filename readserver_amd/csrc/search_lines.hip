@@ -51,7 +51,9 @@ __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const u
         if (sh + 2u * T > 64u) bits |= last << (64u - sh);
         const uint64_t e = ix.ktab[(bits & ((1ull << (2u * T)) - 1ull)) * ix.ktab_stride];
         const uint32_t width = (uint32_t)(e >> COUNT_BITS);
-        if (width != KTAB_WIDE) {
+        // an entry is an interval of this BWT's rows: one that is not (a damaged table) is not believed --
+        // the search then starts from initInterval like an untabulated one and still ends on the right rows
+        if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix.n) {
             rec.x = e & COUNT_MASK;
             rec.y = rec.x + width - 1ull;
             return rec;
@@ -443,6 +445,16 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
 #endif
                 if (do_scan) {
                     occ_hold = base + sc;
+#ifdef RSB_FAULT_INJECT_WILD_OCC  // fault-injection build (tools/README.md): answers are WRONG by design -- one
+                    // lookup in 16 returns a wild count, so lower / upper leave [0, n) and every fetch index
+                    // has to survive a position the index does not hold.  Wild within what ANY line contents
+                    // can give: a count is a 40-bit word plus a few 12-bit fields, < 2^41 -- which is what
+                    // leaves bit 63 of occ_hold free to carry `ready` in the exchange below (a first version of
+                    // this injection added 64-bit values, the partner lane read the flag out of a stale count,
+                    // the two sides of a pair fell out of step and their wave never drained)
+                    if ((((uint32_t)q + (uint32_t)j) * 2654435761u >> 28) == 0u)
+                        occ_hold = (occ_hold + (((uint64_t)q * 0x9E3779B97F4A7C15ull) >> (23u + (((uint32_t)q + (uint32_t)j) & 31u)))) & ((1ull << 41) - 1ull);
+#endif
                     ready = true;
                     cont = 0;
                     tries = 0;
@@ -450,6 +462,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
             }
             STAMP(3)  // rank out of LDS
             // ---- the two sides of a query trade results; updateInterval (query.cpp:11-15)
+            // (bit 63 travels as the ready flag: a count is < 2^41 whatever the line held)
             const uint32_t occ_hi = (uint32_t)(occ_hold >> 32) | (ready ? 0x80000000u : 0u);
             const auto sw_lo = __builtin_amdgcn_permlane32_swap((uint32_t)occ_hold, (uint32_t)occ_hold, false, false);
             const auto sw_hi = __builtin_amdgcn_permlane32_swap(occ_hi, occ_hi, false, false);

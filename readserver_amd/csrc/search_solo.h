@@ -272,6 +272,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 const uint2 y2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE((dw + 4u) & 31u));
                 const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
                 occ = base + runs_scan<6>(r6, b, rem);
+#ifdef RSB_FAULT_INJECT_WILD_OCC  // fault-injection build (search_lines.hip): wild counts, answers WRONG by design
+                if ((((uint32_t)q + (uint32_t)j) * 2654435761u >> 28) == 0u)
+                    occ = (occ + (((uint64_t)q * 0x9E3779B97F4A7C15ull) >> (23u + (((uint32_t)q + (uint32_t)j) & 31u)))) & ((1ull << 41) - 1ull);
+#endif
             }
             // ---- upper out of the same line: lower - 1 was found among the line's own pieces, and
             // upper lies d symbols further on, still among them
