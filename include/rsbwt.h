@@ -41,6 +41,7 @@ extern "C" {
 #define RSBWT_ENODEV (-5)  /* no usable HIP device                           */
 #define RSBWT_EHIP (-6)    /* a HIP runtime call failed (see rsbwt_last_error) */
 #define RSBWT_ERANGE (-7)  /* shard exceeds format limits (2^40 symbols) / buffer too small */
+#define RSBWT_ESYS (-8)    /* the host runtime failed (a thread could not be started, ...)   */
 
 /* open flags */
 /* bits 0..4: reserved (0).
@@ -355,7 +356,11 @@ const char *rsbwt_service_config_array_item(const rsbwt_service_config_t *cfg, c
  * (service.cpp:1493-1502).  In-process: a queue pair for tests and embedding. */
 typedef struct rsbwt_transport rsbwt_transport_t;
 int rsbwt_transport_inproc(rsbwt_transport_t **out);
-int rsbwt_transport_zmq(const char *pull, const char *push, const char *push_count, rsbwt_transport_t **out); /* RSBWT_ENODEV without libzmq */
+/* ZeroMQ (src/service/service.cpp:1493-1502: SUB connect(pull) + subscribe-all, PUSH connect(push), PUSH
+ * connect(push_count)).  libzmq is bound at run time (dlopen of libzmq.so.5; RSBWT_LIBZMQ names another):
+ * RSBWT_ENODEV on a box without it, no rebuild on one with it. */
+int rsbwt_transport_zmq(const char *pull, const char *push, const char *push_count, rsbwt_transport_t **out);
+int rsbwt_zmq_available(void); /* 1 when libzmq could be bound */
 void rsbwt_transport_free(rsbwt_transport_t *t);
 int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_t n); /* in-process only */
 int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "rsbwt_service_config_array_item": (C.c_char_p, [_vp, C.c_char_p, C.c_size_t]),
     "rsbwt_transport_inproc": (C.c_int, [C.POINTER(_vp)]),
     "rsbwt_transport_zmq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "rsbwt_zmq_available": (C.c_int, []),
     "rsbwt_transport_free": (None, [_vp]),
     "rsbwt_transport_push_request": (C.c_int, [_vp, _vp, C.c_size_t]),
     "rsbwt_transport_pop_reply": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int64]),

@@ -12,7 +12,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # index_rlebwt: the twin of the reference's src/util/index_rlebwt.cpp (writes "<bwt>.bpi2"); host code only
 "${CXX:-g++}" -O2 -std=c++17 -Wall -I"$here/../include" "$src/index_rlebwt_main.cpp" "$src/bpi2.cpp" "$src/bwt_file.cpp" \
   -o "$here/lib/index_rlebwt"
-# rsbwt_service: the twin of the reference's `service` process for the count path (needs libzmq for its
-# sockets: add -DRSBWT_WITH_ZMQ -lzmq to the librsbwt.so line where it exists)
+# rsbwt_service: the twin of the reference's `service` process for the count path (libzmq is bound at run
+# time by librsbwt.so: nothing to add here on a box that has it)
 "${CXX:-g++}" -O2 -std=c++17 -Wall -I"$here/../include" "$src/service_main.cpp" -L"$here/lib" -lrsbwt \
   -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -o "$here/lib/rsbwt_service"

@@ -194,6 +194,7 @@ const char *rsbwt_strerror(int code) {
     case RSBWT_ENODEV: return "no usable HIP device";
     case RSBWT_EHIP: return "HIP runtime error";
     case RSBWT_ERANGE: return "shard exceeds format limits";
+    case RSBWT_ESYS: return "host runtime error";
     default: return "unknown error";
     }
 }

@@ -14,9 +14,15 @@
 // window with one batched search per query length over the shard set (service_slice.cpp), and sends
 // the replies in arrival order.  Requests of other types are handed to the caller's handler (the
 // RocksDB / alignment paths stay with the reference's code).  The transport is an interface: an
-// in-process queue pair for tests and embedding, ZeroMQ where libzmq exists (-DRSBWT_WITH_ZMQ).
+// in-process queue pair for tests and embedding, and ZeroMQ -- libzmq is BOUND AT RUN TIME (dlopen, as
+// sets.hip binds RCCL): the same librsbwt.so serves a box with libzmq.so.5 and reports RSBWT_ENODEV on
+// one without; no zmq.h is needed to build (the handful of libzmq 4.x entry points and constants used
+// are declared below).
+#include <dlfcn.h>
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -33,9 +39,7 @@
 #include "../../include/rsbwt.h"
 #include "service.h"
 
-#ifdef RSBWT_WITH_ZMQ
-#include <zmq.h>
-#endif
+#include "capi_guard.h"
 
 using namespace rsb;
 
@@ -206,58 +210,150 @@ class inproc_transport : public transport {
     bool closed_ = false;
 };
 
-#ifdef RSBWT_WITH_ZMQ
+// ---- libzmq 4.x, bound at run time.  The ABI used (zmq.h of 4.0 .. 4.3): socket types, option and
+// flag numbers are part of the wire / C contract and have not changed since 3.x.
+constexpr int ZMQ_SUB_ = 2, ZMQ_PUSH_ = 8, ZMQ_SUBSCRIBE_ = 6, ZMQ_LINGER_ = 17, ZMQ_POLLIN_ = 1;
+struct zmq_msg_ {  // zmq_msg_t: 64 opaque bytes, pointer-aligned
+    alignas(8) unsigned char _[64];
+};
+struct zmq_pollitem_ {  // zmq_pollitem_t on POSIX
+    void *socket;
+    int fd;
+    short events, revents;
+};
+struct zmq_api {
+    void *lib = nullptr;
+    void *(*ctx_new)() = nullptr;
+    int (*ctx_term)(void *) = nullptr;
+    void *(*socket)(void *, int) = nullptr;
+    int (*close)(void *) = nullptr;
+    int (*connect)(void *, const char *) = nullptr;
+    int (*setsockopt)(void *, int, const void *, size_t) = nullptr;
+    int (*poll)(zmq_pollitem_ *, int, long) = nullptr;
+    int (*msg_init)(zmq_msg_ *) = nullptr;
+    int (*msg_recv)(zmq_msg_ *, void *, int) = nullptr;
+    void *(*msg_data)(zmq_msg_ *) = nullptr;
+    int (*msg_close)(zmq_msg_ *) = nullptr;
+    int (*send)(void *, const void *, size_t, int) = nullptr;
+    int (*zerrno)() = nullptr;
+    const char *(*strerror)(int) = nullptr;
+    bool ok = false;
+};
+
+zmq_api &zmq() {
+    static zmq_api api = [] {
+        zmq_api a;
+        // RSBWT_LIBZMQ names the library outright; otherwise the loader's search path, then two prefixes
+        // where distributions that are not on it keep theirs
+        const char *env = getenv("RSBWT_LIBZMQ");
+        const char *names[] = {env, "libzmq.so.5", "libzmq.so", "/usr/local/lib/libzmq.so.5", "/opt/conda/lib/libzmq.so.5"};
+        for (const char *name : names) {
+            if (!name || !*name) continue;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+#define ZMQ_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, sym))
+        ZMQ_SYM(ctx_new, "zmq_ctx_new");
+        ZMQ_SYM(ctx_term, "zmq_ctx_term");
+        ZMQ_SYM(socket, "zmq_socket");
+        ZMQ_SYM(close, "zmq_close");
+        ZMQ_SYM(connect, "zmq_connect");
+        ZMQ_SYM(setsockopt, "zmq_setsockopt");
+        ZMQ_SYM(poll, "zmq_poll");
+        ZMQ_SYM(msg_init, "zmq_msg_init");
+        ZMQ_SYM(msg_recv, "zmq_msg_recv");
+        ZMQ_SYM(msg_data, "zmq_msg_data");
+        ZMQ_SYM(msg_close, "zmq_msg_close");
+        ZMQ_SYM(send, "zmq_send");
+        ZMQ_SYM(zerrno, "zmq_errno");
+        ZMQ_SYM(strerror, "zmq_strerror");
+#undef ZMQ_SYM
+        a.ok = a.ctx_new && a.ctx_term && a.socket && a.close && a.connect && a.setsockopt && a.poll && a.msg_init &&
+               a.msg_recv && a.msg_data && a.msg_close && a.send && a.zerrno && a.strerror;
+        return a;
+    }();
+    return api;
+}
+
 // ZeroMQ: SUB connect(pull) + subscribe-all, PUSH connect(push), PUSH connect(push_count)
-// (service.cpp:1493-1502).  Compiled only where libzmq's zmq.h exists.
+// (service.cpp:1493-1502).
 class zmq_transport : public transport {
   public:
     zmq_transport(const std::string &pull, const std::string &push, const std::string &push_count) {
-        ctx_ = zmq_ctx_new();
-        sub_ = zmq_socket(ctx_, ZMQ_SUB);
-        ok_ = zmq_connect(sub_, pull.c_str()) == 0 && zmq_setsockopt(sub_, ZMQ_SUBSCRIBE, "", 0) == 0;
-        out_[PUSH] = zmq_socket(ctx_, ZMQ_PUSH);
-        out_[PUSH_COUNT] = zmq_socket(ctx_, ZMQ_PUSH);
-        ok_ = ok_ && zmq_connect(out_[PUSH], push.c_str()) == 0 && zmq_connect(out_[PUSH_COUNT], push_count.c_str()) == 0;
+        zmq_api &z = zmq();
+        ctx_ = z.ctx_new();
+        if (!ctx_) return;
+        sub_ = z.socket(ctx_, ZMQ_SUB_);
+        out_[PUSH] = z.socket(ctx_, ZMQ_PUSH_);
+        out_[PUSH_COUNT] = z.socket(ctx_, ZMQ_PUSH_);
+        if (!sub_ || !out_[PUSH] || !out_[PUSH_COUNT]) return;
+        // replies not yet delivered when the service stops are dropped after a second instead of holding
+        // zmq_ctx_term for ever (the reference's process simply exits)
+        const int linger_ms = 1000;
+        for (void *so : {sub_, out_[PUSH], out_[PUSH_COUNT]}) (void)z.setsockopt(so, ZMQ_LINGER_, &linger_ms, sizeof linger_ms);
+        ok_ = z.connect(sub_, pull.c_str()) == 0 && z.setsockopt(sub_, ZMQ_SUBSCRIBE_, "", 0) == 0 &&
+              z.connect(out_[PUSH], push.c_str()) == 0 && z.connect(out_[PUSH_COUNT], push_count.c_str()) == 0;
+        if (!ok_) err_ = z.strerror(z.zerrno());
     }
     ~zmq_transport() override {
-        zmq_close(sub_);
-        zmq_close(out_[0]);
-        zmq_close(out_[1]);
-        zmq_ctx_term(ctx_);
+        zmq_api &z = zmq();
+        if (sub_) z.close(sub_);
+        if (out_[0]) z.close(out_[0]);
+        if (out_[1]) z.close(out_[1]);
+        if (ctx_) z.ctx_term(ctx_);
     }
     bool ok() const { return ok_; }
+    const std::string &error() const { return err_; }
     bool recv(std::vector<uint8_t> *msg, int64_t timeout_us) override {
-        zmq_pollitem_t it = {sub_, 0, ZMQ_POLLIN, 0};
-        const long ms = timeout_us < 0 ? -1 : (long)((timeout_us + 999) / 1000);
-        if (zmq_poll(&it, 1, ms) <= 0) return false;
-        zmq_msg_t m;
-        zmq_msg_init(&m);
-        const int n = zmq_msg_recv(&m, sub_, 0);
-        if (n >= 0) msg->assign((const uint8_t *)zmq_msg_data(&m), (const uint8_t *)zmq_msg_data(&m) + n);
-        zmq_msg_close(&m);
+        zmq_api &z = zmq();
+        zmq_pollitem_ it = {sub_, 0, (short)ZMQ_POLLIN_, 0};
+        // a stop request must be seen: never sleep longer than 50 ms in one poll
+        const long ms = timeout_us < 0 ? 50 : (long)std::min<int64_t>((timeout_us + 999) / 1000, 50);
+        if (z.poll(&it, 1, ms) <= 0) return false;  // nothing yet, or EINTR: the loop asks again
+        zmq_msg_ m;
+        z.msg_init(&m);
+        const int n = z.msg_recv(&m, sub_, 0);
+        if (n >= 0) msg->assign((const uint8_t *)z.msg_data(&m), (const uint8_t *)z.msg_data(&m) + n);
+        z.msg_close(&m);
         return n >= 0;
     }
     bool closed() override { return stop_.load(); }
     bool closing() override { return stop_.load(); }
     void send(channel c, const uint8_t *data, size_t n) override {
+        zmq_api &z = zmq();
         std::lock_guard<std::mutex> lock(mu_);  // the reference guards sender->send the same way (service.cpp:311-313)
-        zmq_send(out_[c], data, n, 0);
+        // the front-end waits for every reply and has no timeout (server.cpp:403,469): an interrupted send is
+        // repeated; any other failure is counted and logged, never silently dropped
+        for (;;) {
+            if (z.send(out_[c], data, n, 0) >= 0) return;
+            const int e = z.zerrno();
+            if (e == EINTR) continue;
+            const uint64_t k = send_failures_.fetch_add(1) + 1;
+            if (k <= 10 || (k & (k - 1)) == 0)
+                fprintf(stderr, "rsbwt service: zmq_send of a %zu-byte reply failed (%s); %llu replies lost so far\n", n,
+                        z.strerror(e), (unsigned long long)k);
+            return;
+        }
     }
+    uint64_t send_failures() const { return send_failures_.load(); }
     void stop() { stop_.store(true); }
 
   private:
     void *ctx_ = nullptr, *sub_ = nullptr, *out_[2] = {nullptr, nullptr};
     bool ok_ = false;
+    std::string err_;
     std::atomic<bool> stop_{false};
+    std::atomic<uint64_t> send_failures_{0};
     std::mutex mu_;
 };
-#endif
 
 }  // namespace
 
 struct rsbwt_transport {
     transport *t = nullptr;
     inproc_transport *inproc = nullptr;  // same object when in-process
+    zmq_transport *zmq = nullptr;        // same object when ZeroMQ
 };
 
 struct rsbwt_service {
@@ -362,7 +458,7 @@ struct rsbwt_service {
 extern "C" {
 
 // ---- configuration ---------------------------------------------------------------------------------
-int rsbwt_service_config_load(const char *path, rsbwt_service_config_t **out) {
+static int rsbwt_service_config_load_body(const char *path, rsbwt_service_config_t **out) {
     if (!path || !out) return fail(RSBWT_EINVAL, "null argument");
     *out = nullptr;
     FILE *f = fopen(path, "rb");
@@ -393,6 +489,10 @@ int rsbwt_service_config_load(const char *path, rsbwt_service_config_t **out) {
     *out = cfg;
     return RSBWT_OK;
 }
+int rsbwt_service_config_load(const char *path, rsbwt_service_config_t **out) {
+    return guarded("rsbwt_service_config_load", [&]() -> int { return rsbwt_service_config_load_body(path, out); });
+}
+
 
 void rsbwt_service_config_free(rsbwt_service_config_t *cfg) { delete cfg; }
 
@@ -415,7 +515,7 @@ const char *rsbwt_service_config_array_item(const rsbwt_service_config_t *cfg, c
 }
 
 // ---- transports ------------------------------------------------------------------------------------
-int rsbwt_transport_inproc(rsbwt_transport_t **out) {
+static int rsbwt_transport_inproc_body(rsbwt_transport_t **out) {
     if (!out) return fail(RSBWT_EINVAL, "null argument");
     rsbwt_transport *t = new (std::nothrow) rsbwt_transport();
     inproc_transport *ip = new (std::nothrow) inproc_transport();
@@ -425,21 +525,33 @@ int rsbwt_transport_inproc(rsbwt_transport_t **out) {
     *out = t;
     return RSBWT_OK;
 }
+int rsbwt_transport_inproc(rsbwt_transport_t **out) {
+    return guarded("rsbwt_transport_inproc", [&]() -> int { return rsbwt_transport_inproc_body(out); });
+}
+
 
 int rsbwt_transport_zmq(const char *pull, const char *push, const char *push_count, rsbwt_transport_t **out) {
     if (!pull || !push || !push_count || !out) return fail(RSBWT_EINVAL, "null argument");
-#ifdef RSBWT_WITH_ZMQ
-    rsbwt_transport *t = new (std::nothrow) rsbwt_transport();
-    zmq_transport *z = new (std::nothrow) zmq_transport(pull, push, push_count);
-    if (!t || !z || !z->ok()) { delete t; delete z; return fail(RSBWT_EIO, "cannot connect the ZeroMQ sockets (%s, %s, %s)", pull, push, push_count); }
-    t->t = z;
-    *out = t;
-    return RSBWT_OK;
-#else
     *out = nullptr;
-    return fail(RSBWT_ENODEV, "this build has no libzmq (compile service_loop.cpp with -DRSBWT_WITH_ZMQ -lzmq)");
-#endif
+    return guarded("rsbwt_transport_zmq", [&]() -> int {
+        if (!zmq().ok)
+            return fail(RSBWT_ENODEV, "libzmq could not be bound at run time (libzmq.so.5 not on the loader's path; RSBWT_LIBZMQ names one)");
+        rsbwt_transport *t = new (std::nothrow) rsbwt_transport();
+        zmq_transport *z = new (std::nothrow) zmq_transport(pull, push, push_count);
+        if (!t || !z || !z->ok()) {
+            const std::string why = z ? z->error() : std::string("host allocation failed");
+            delete t;
+            delete z;
+            return fail(RSBWT_EIO, "cannot connect the ZeroMQ sockets (%s, %s, %s): %s", pull, push, push_count, why.c_str());
+        }
+        t->t = z;
+        t->zmq = z;
+        *out = t;
+        return RSBWT_OK;
+    });
 }
+
+int rsbwt_zmq_available(void) { return zmq().ok ? 1 : 0; }
 
 void rsbwt_transport_free(rsbwt_transport_t *t) {
     if (!t) return;
@@ -447,13 +559,17 @@ void rsbwt_transport_free(rsbwt_transport_t *t) {
     delete t;
 }
 
-int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_t n) {
+static int rsbwt_transport_push_request_body(rsbwt_transport_t *t, const uint8_t *msg, size_t n) {
     if (!t || !t->inproc || (!msg && n)) return fail(RSBWT_EINVAL, "not an in-process transport");
     t->inproc->push_request(msg, n);
     return RSBWT_OK;
 }
+int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_t n) {
+    return guarded("rsbwt_transport_push_request", [&]() -> int { return rsbwt_transport_push_request_body(t, msg, n); });
+}
 
-int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us) {
+
+static int rsbwt_transport_pop_reply_body(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us) {
     if (!t || !t->inproc || !n || channel < 0 || channel > 1) return fail(RSBWT_EINVAL, "not an in-process transport");
     std::vector<uint8_t> m;
     if (!t->inproc->pop_reply(channel, &m, timeout_us)) return fail(RSBWT_EIO, "no reply within %lld us", (long long)timeout_us);
@@ -462,16 +578,18 @@ int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, s
     if (!m.empty()) memcpy(buf, m.data(), m.size());
     return RSBWT_OK;
 }
+int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us) {
+    return guarded("rsbwt_transport_pop_reply", [&]() -> int { return rsbwt_transport_pop_reply_body(t, channel, buf, cap, n, timeout_us); });
+}
+
 
 void rsbwt_transport_close(rsbwt_transport_t *t) {
     if (t && t->inproc) t->inproc->close();
-#ifdef RSBWT_WITH_ZMQ
-    else if (t) static_cast<zmq_transport *>(t->t)->stop();
-#endif
+    else if (t && t->zmq) t->zmq->stop();
 }
 
 // ---- the service ------------------------------------------------------------------------------------
-int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch, int per_partition,
+static int rsbwt_service_create_body(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch, int per_partition,
                          rsbwt_service_t **out) {
     if (!set || !t || !out) return fail(RSBWT_EINVAL, "null argument");
     rsbwt_service *s = new (std::nothrow) rsbwt_service();
@@ -484,6 +602,11 @@ int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_
     *out = s;
     return RSBWT_OK;
 }
+int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch, int per_partition,
+                         rsbwt_service_t **out) {
+    return guarded("rsbwt_service_create", [&]() -> int { return rsbwt_service_create_body(set, t, window_us, max_batch, per_partition, out); });
+}
+
 
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg) {
     if (!s) return;
@@ -491,26 +614,38 @@ void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn 
     s->other_arg = arg;
 }
 
-int rsbwt_service_run(rsbwt_service_t *s) {
+static int rsbwt_service_run_body(rsbwt_service_t *s) {
     if (!s) return fail(RSBWT_EINVAL, "null service");
     s->run();
     return s->last_rc == RSBWT_OK ? RSBWT_OK : fail(s->last_rc, "%s", s->last_err.c_str());
 }
+int rsbwt_service_run(rsbwt_service_t *s) {
+    return guarded("rsbwt_service_run", [&]() -> int { return rsbwt_service_run_body(s); });
+}
 
-int rsbwt_service_start(rsbwt_service_t *s) {
+
+static int rsbwt_service_start_body(rsbwt_service_t *s) {
     if (!s || s->worker.joinable()) return fail(RSBWT_EINVAL, "null or already running service");
     s->stop.store(false);
     s->worker = std::thread([s] { s->run(); });
     return RSBWT_OK;
 }
+int rsbwt_service_start(rsbwt_service_t *s) {
+    return guarded("rsbwt_service_start", [&]() -> int { return rsbwt_service_start_body(s); });
+}
 
-int rsbwt_service_stop(rsbwt_service_t *s) {
+
+static int rsbwt_service_stop_body(rsbwt_service_t *s) {
     if (!s) return fail(RSBWT_EINVAL, "null service");
     // a transport that is closing drains: the loop ends by itself once what was received is answered
     if (!s->tr->closing()) s->stop.store(true);
     if (s->worker.joinable()) s->worker.join();
     return s->last_rc == RSBWT_OK ? RSBWT_OK : fail(s->last_rc, "%s", s->last_err.c_str());
 }
+int rsbwt_service_stop(rsbwt_service_t *s) {
+    return guarded("rsbwt_service_stop", [&]() -> int { return rsbwt_service_stop_body(s); });
+}
+
 
 void rsbwt_service_free(rsbwt_service_t *s) {
     if (!s) return;

@@ -34,6 +34,13 @@ int main(int argc, char **argv) {
         return EXIT_FAILURE;
     }
     printf("starting server for %s\n", get(cfg, "suffix", ""));
+    // the sockets first: a box without libzmq should say so before minutes are spent loading shards into HBM
+    // (connecting is asynchronous in ZeroMQ: nothing is received until the loop polls)
+    rsbwt_transport_t *tr = nullptr;
+    if (rsbwt_transport_zmq(get(cfg, "pull", ""), get(cfg, "push", ""), get(cfg, "push_count", ""), &tr) != RSBWT_OK) {
+        fprintf(stderr, "%s\n", rsbwt_last_error());
+        return EXIT_FAILURE;
+    }
     std::vector<std::string> paths;
     const size_t ns = rsbwt_service_config_array_len(cfg, "shards");
     for (size_t i = 0; i < ns; ++i) paths.push_back(std::string(rsbwt_service_config_array_item(cfg, "shards", i)) + ".bwt");
@@ -55,11 +62,6 @@ int main(int argc, char **argv) {
         return EXIT_FAILURE;
     }
     printf("loaded %zu bwt shard(s) on %zu GPU(s).\n", rsbwt_set_size(set), rsbwt_set_devices(set));
-    rsbwt_transport_t *tr = nullptr;
-    if (rsbwt_transport_zmq(get(cfg, "pull", ""), get(cfg, "push", ""), get(cfg, "push_count", ""), &tr) != RSBWT_OK) {
-        fprintf(stderr, "%s\n", rsbwt_last_error());
-        return EXIT_FAILURE;
-    }
     rsbwt_service_t *svc = nullptr;
     const bool summed = strcmp(get(cfg, "replies", "per_partition"), "summed") == 0;
     if (rsbwt_service_create(set, tr, atoll(get(cfg, "batch_window_us", "200")), (size_t)atoll(get(cfg, "batch_max", "4096")),

@@ -18,6 +18,7 @@
 
 #include "../../include/rsbwt.h"
 #include "service.h"
+#include "capi_guard.h"
 
 namespace {
 
@@ -230,7 +231,7 @@ bool service_decode(const uint8_t *msg, size_t len, service_request *out) {
 
 extern "C" {
 
-int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
+static int rsbwt_service_counts_body(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
                          size_t n, uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed) {
     if (!set || (!requests && n) || !req_off || !rep_off) return rsb::fail(RSBWT_EINVAL, "null argument");
     for (size_t i = 0; i < n; ++i)
@@ -261,5 +262,10 @@ int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t reque
         return rsb::fail(RSBWT_ENOMEM, "host allocation failed");
     }
 }
+int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
+                         size_t n, uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed) {
+    return rsb::guarded("rsbwt_service_counts", [&]() -> int { return rsbwt_service_counts_body(set, requests, requests_len, req_off, n, replies, cap, rep_off, needed); });
+}
+
 
 }  // extern "C"

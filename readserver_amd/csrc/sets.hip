@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rsbwt.h"
+#include "capi_guard.h"
 #include "capi_internal.h"
 
 using namespace rsb;
@@ -209,25 +210,36 @@ void rsbwt_set_close(rsbwt_set_t *s) {
     delete s;
 }
 
-int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
+static int rsbwt_set_from_handles_body(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
     if (!out || (!handles && num_shards)) return fail(RSBWT_EINVAL, "null argument");
     *out = nullptr;
     if (num_shards == 0) return fail(RSBWT_EINVAL, "a shard set needs at least one shard");
+    if (num_shards > (1u << 16)) return fail(RSBWT_ERANGE, "%zu shards: a set holds at most 65536", num_shards);
     rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
     if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
     s->owns = false;
-    s->shards.assign(handles, handles + num_shards);
+    try {
+        s->shards.assign(handles, handles + num_shards);
+    } catch (...) {
+        delete s;
+        throw;  // guarded() turns it into RSBWT_ENOMEM
+    }
     int rc = make_groups(s);
     if (rc) { rsbwt_set_close(s); return rc; }
     *out = s;
     return RSBWT_OK;
 }
+int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set_t **out) {
+    return guarded("rsbwt_set_from_handles", [&]() -> int { return rsbwt_set_from_handles_body(handles, num_shards, out); });
+}
 
-int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
+
+static int rsbwt_set_open_body(const char *const *bwt_paths, size_t num_shards, const int *device_map,
                    uint32_t flags, rsbwt_set_t **out) {
     if (!out || (!bwt_paths && num_shards)) return fail(RSBWT_EINVAL, "null argument");
     *out = nullptr;
     if (num_shards == 0) return fail(RSBWT_EINVAL, "a shard set needs at least one shard");
+    if (num_shards > (1u << 16)) return fail(RSBWT_ERANGE, "%zu shards: a set holds at most 65536", num_shards);
     rsbwt_set_t *s = new (std::nothrow) rsbwt_set();
     if (!s) return fail(RSBWT_ENOMEM, "host allocation failed");
     s->owns = true;
@@ -247,6 +259,11 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
     *out = s;
     return RSBWT_OK;
 }
+int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *device_map,
+                   uint32_t flags, rsbwt_set_t **out) {
+    return guarded("rsbwt_set_open", [&]() -> int { return rsbwt_set_open_body(bwt_paths, num_shards, device_map, flags, out); });
+}
+
 
 // The depth rsbwt_set_attach_ktabs(s, 0) would give the shards of device group g: the deepest T whose
 // tables (one per shard of that device without one) fit a third of the device's free HBM, none larger
@@ -280,7 +297,7 @@ uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {
 // Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.  The
 // tables of one device are interleaved in one allocation of the set (line_format.h): the start
 // records of a query for all shards come out of one stretch of 8 x shards bytes.
-int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
+static int rsbwt_set_attach_ktabs_body(rsbwt_set_t *s, uint32_t depth) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     for (dev_group *g : s->groups) {
         uint32_t T = depth ? depth : auto_ktab_depth(s, g);
@@ -303,13 +320,17 @@ int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
     }
     return publish_views(s);
 }
+int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
+    return guarded("rsbwt_set_attach_ktabs", [&]() -> int { return rsbwt_set_attach_ktabs_body(s, depth); });
+}
+
 
 size_t rsbwt_set_size(const rsbwt_set_t *s) { return s ? s->shards.size() : 0; }
 rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i) { return (s && i < s->shards.size()) ? s->shards[i] : nullptr; }
 size_t rsbwt_set_devices(const rsbwt_set_t *s) { return s ? s->groups.size() : 0; }
 
 // Host buffers.  lower/upper: [num_shards][Q] in the set's shard order.
-int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+static int rsbwt_set_find_intervals_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
                              uint64_t *lower, uint64_t *upper) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     if (Q == 0) return RSBWT_OK;
@@ -343,11 +364,16 @@ int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32
         return RSBWT_OK;
     });
 }
+int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                             uint64_t *lower, uint64_t *upper) {
+    return guarded("rsbwt_set_find_intervals", [&]() -> int { return rsbwt_set_find_intervals_body(s, kmers, Q, k, stride, lower, upper); });
+}
+
 
 // counts[Q] summed over the set's shards, the way the front-end sums per-partition replies
 // (src/service/server.cpp:184-197): per device one fused search + a row sum; the per-device sums
 // are reduced onto the first device over RCCL when there are several, and cross PCIe once.
-int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
+static int rsbwt_set_count_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
     if (!s || (!counts && Q)) return fail(RSBWT_EINVAL, "null argument");
     if (Q == 0) return RSBWT_OK;
     if (!kmers) return fail(RSBWT_EINVAL, "null argument");
@@ -435,6 +461,10 @@ int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
     }
     return RSBWT_OK;
 }
+int rsbwt_set_count(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *counts) {
+    return guarded("rsbwt_set_count", [&]() -> int { return rsbwt_set_count_body(s, kmers, Q, k, stride, counts); });
+}
+
 
 // Device-resident, for a set whose shards all sit on one device: one fused launch on `stream`;
 // d_lower/d_upper: [num_shards][Q].  Nothing is synchronised.
@@ -488,7 +518,7 @@ size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
     return need;
 }
 
-int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+static int rsbwt_set_find_intervals_1mm_dev_body(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
                                      void *d_lower, void *d_upper, void *d_scratch, void *stream) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
@@ -502,12 +532,17 @@ int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const
     }
     return RSBWT_OK;
 }
+int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
+                                     void *d_lower, void *d_upper, void *d_scratch, void *stream) {
+    return guarded("rsbwt_set_find_intervals_1mm_dev", [&]() -> int { return rsbwt_set_find_intervals_1mm_dev_body(s, d_packed, d_valid, m, k, d_lower, d_upper, d_scratch, stream); });
+}
+
 
 // Gathers per-device interval blocks onto the first device of the set over RCCL (xGMI): d_blocks[g]
 // = device g's [S_g][Q] x {lower, upper} block of `bytes[g]` bytes on that device; d_root on device 0
 // receives them back to back in device order.  One call per batch; nothing is synchronised beyond
 // the streams given (streams[g] on device g).  With one device it is a device-to-device copy.
-int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes, void *d_root,
+static int rsbwt_set_gather_intervals_dev_body(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes, void *d_root,
                                    void *const *streams) {
     if (!s || !d_blocks || !bytes || !d_root || !streams) return fail(RSBWT_EINVAL, "null argument");
     const size_t G = s->groups.size();
@@ -531,6 +566,11 @@ int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, 
     if (nr != ncclSuccess) return fail(RSBWT_EHIP, "RCCL gather: %s", rccl().GetErrorString(nr));
     return RSBWT_OK;
 }
+int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes, void *d_root,
+                                   void *const *streams) {
+    return guarded("rsbwt_set_gather_intervals_dev", [&]() -> int { return rsbwt_set_gather_intervals_dev_body(s, d_blocks, bytes, d_root, streams); });
+}
+
 
 int rsbwt_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
