@@ -360,6 +360,7 @@ def main():
         exact = torch.ones(1, dtype=torch.int64, device=cdev)
         if wire_packed:  # the 10-byte form carries this rank's pairs exactly
             src = d_res[last % 2] if d_res is not None else gat.pair(last)
+            sharded.pack_pairs(src, check=True)  # raises if a pair of this rank does not fit the 10-byte record
             back = gat.unpack_block(sent.to(src.device))
             exact[0] = int(torch.equal(back, src))
             del back

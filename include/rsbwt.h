@@ -398,6 +398,11 @@ int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t 
  * is not believed.  RSBWT_ERANGE outside the region. */
 int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes, size_t n);
 
+/* Test hook (answers no query): the kernels' position -> window division (an f64 multiply and one fix-up step
+ * instead of a 64-bit divide) on n host positions: w[i] = p[i] / S, r[i] = p[i] % S, so that a test can hold
+ * it to integer division up to the 2^40 symbols a shard may have, for every span S in 2..2944. */
+int rsbwt_debug_fast_window(const uint64_t *p, size_t n, uint32_t S, uint32_t *w, uint32_t *r, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -444,6 +444,23 @@ uint64_t rsbwt_spilled_symbols(const rsbwt_t *h) { return h->spilled_symbols; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
+// Test hook: w[i] = p[i] / S, r[i] = p[i] % S as the KERNELS compute them (fast_window); host buffers.
+int rsbwt_debug_fast_window(const uint64_t *p, size_t n, uint32_t S, uint32_t *w, uint32_t *r, int device) {
+    if ((!p || !w || !r) && n) return fail(RSBWT_EINVAL, "null argument");
+    if (S < 2u || S > MAX_SPAN) return fail(RSBWT_ERANGE, "span %u outside 2..%u", S, MAX_SPAN);
+    if (n == 0) return RSBWT_OK;
+    int rc = use_device(device);
+    if (rc) return rc;
+    uint8_t *d = nullptr;
+    HIP_OK(hipMalloc(&d, n * 16));
+    hipError_t e = hipMemcpy(d, p, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_debug_fast_window(d, n, S, d + n * 8, d + n * 12, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(w, d + n * 8, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(r, d + n * 12, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "rsbwt_debug_fast_window");
+}
+
 // Test hook: overwrites n bytes of the index in HBM (region 0: the lines, 1: the k-mer table) with `bytes`,
 // so that a test can hold the kernels to what they do with a DAMAGED index (never read outside it, every
 // wave drains); answers no query.
@@ -934,8 +951,8 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
     for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
         const size_t m = std::min(SLICE, Q - q0), mv = m * V;
         const size_t ascii_bytes = (m - 1) * stride + k;
-        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
-        const size_t a_vpk = mv * wpq * 8, a_vok = (mv + 15) & ~(size_t)15;
+        const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = (m * wpq * 8 + 15) & ~(size_t)15, a_ok = (m + 15) & ~(size_t)15;
+        const size_t a_vpk = (mv * wpq * 8 + 15) & ~(size_t)15, a_vok = (mv + 15) & ~(size_t)15;
         const size_t a_scr = (variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15;
         if ((rc = g.c->stage(a_ascii + a_pk + a_ok + a_vpk + a_vok + 2 * mv * 8 + a_scr)) != RSBWT_OK) return rc;
         uint8_t *d_ascii = (uint8_t *)g.c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
@@ -959,7 +976,8 @@ int rsbwt_find_intervals_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k
 size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
     if (!h || k == 0) return 0;
     const size_t V = 3 * (size_t)k + 1, mv = m * V;
-    return mv * words_per_kmer(k) * 8 + ((mv + 15) & ~(size_t)15) + ((variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15);
+    // every part starts on a 16-byte boundary: the trace and the sparse results are read and written as 16-byte words
+    return ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15) + ((mv + 15) & ~(size_t)15) + ((variants_scratch_bytes(h, m, k) + 15) & ~(size_t)15);
 }
 
 int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
@@ -972,7 +990,7 @@ int rsbwt_find_intervals_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d
     int rc = use_device(h->device);
     if (rc) return rc;
     const size_t V = 3 * (size_t)k + 1, mv = m * V;
-    uint8_t *d_vpk = (uint8_t *)d_scratch, *d_vok = d_vpk + mv * words_per_kmer(k) * 8;
+    uint8_t *d_vpk = (uint8_t *)d_scratch, *d_vok = d_vpk + ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15);
     uint8_t *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
     hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
@@ -1006,7 +1024,7 @@ static int hits_search(rsbwt_t *h, const void *d_packed, const void *d_valid, si
                        hipStream_t stream) {
     const hits_layout L = hits_scratch_layout(h, m, k);
     const size_t V = 3 * (size_t)k + 1, mv = m * V;
-    uint8_t *d_vpk = scratch, *d_vok = d_vpk + mv * words_per_kmer(k) * 8, *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
+    uint8_t *d_vpk = scratch, *d_vok = d_vpk + ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15), *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
     uint8_t *d_sparse = scratch + L.variants, *d_bits = d_sparse + L.sparse;
     HIP_OK(hipMemsetAsync(d_bits, 0, L.bits, stream));
     hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, stream);
@@ -1063,7 +1081,7 @@ int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t s
         for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
             const size_t m = std::min(SLICE, Q - q0), mv = m * V;
             const size_t ascii_bytes = (m - 1) * stride + k;
-            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = (m * wpq * 8 + 15) & ~(size_t)15, a_ok = (m + 15) & ~(size_t)15;
             const hits_layout L = hits_scratch_layout(h, m, k);
             size_t room = std::min(mv, std::max<size_t>(4 * m, 1u << 14));  // records this slice may leave; more on demand
             if ((rc = g.c->stage(a_ascii + a_pk + a_ok + L.total + 16 + room * sizeof(hit_rec))) != RSBWT_OK) return rc;

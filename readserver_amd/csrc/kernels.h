@@ -102,6 +102,7 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each
 // symbol) and the walk kernel
+hipError_t launch_debug_fast_window(const void *d_p, size_t n, uint32_t S, void *d_w, void *d_r, hipStream_t stream);
 uint64_t select_sample_stride(const shard_view &ix);
 hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream);
 // extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative

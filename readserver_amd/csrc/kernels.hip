@@ -748,6 +748,24 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
     return hipGetLastError();
 }
 
+// Test hook: the device's position -> window division (rank_device.h, fast_window) on caller-supplied
+// positions, so that a test can hold it to integer division over the whole 40-bit range for every span.
+__global__ void __launch_bounds__(256)
+debug_fast_window_kernel(const uint64_t *__restrict__ p, size_t n, span_params sp, uint32_t *__restrict__ w,
+                         uint32_t *__restrict__ r) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t pin;
+    w[i] = fast_window(p[i], sp.S, sp.inv, pin);
+    r[i] = pin;
+}
+hipError_t launch_debug_fast_window(const void *d_p, size_t n, uint32_t S, void *d_w, void *d_r, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(debug_fast_window_kernel, dim3(blocks256(n)), dim3(256), 0, stream, (const uint64_t *)d_p, n,
+                       make_span(S), (uint32_t *)d_w, (uint32_t *)d_r);
+    return hipGetLastError();
+}
+
 uint64_t select_sample_stride(const shard_view &ix) {
     uint64_t mx = 0;
     for (int c = 0; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;

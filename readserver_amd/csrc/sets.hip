@@ -404,7 +404,7 @@ static int rsbwt_set_count_body(rsbwt_set_t *s, const char *kmers, size_t Q, uin
             ctx[gi] = c;
             const size_t Sg = g->idx.size();
             const size_t ascii_bytes = (m - 1) * stride + k;
-            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = m * wpq * 8, a_ok = (m + 15) & ~(size_t)15;
+            const size_t a_ascii = (ascii_bytes + 15) & ~(size_t)15, a_pk = (m * wpq * 8 + 15) & ~(size_t)15, a_ok = (m + 15) & ~(size_t)15;
             if ((r = c->stage(a_ascii + a_pk + a_ok + (Sg + 2) * m * 8)) != RSBWT_OK) return r;
             uint8_t *d_ascii = (uint8_t *)c->d_stage, *d_pk = d_ascii + a_ascii, *d_ok = d_pk + a_pk;
             uint64_t *d_cnt = (uint64_t *)(d_ok + a_ok);

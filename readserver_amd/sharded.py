@@ -61,11 +61,13 @@ def packed_pairs_bytes(n):
     return (n * 10 + 3) // 4 * 4
 
 
-def pack_pairs(pairs, out=None):
+def pack_pairs(pairs, out=None, check=False):
     """[..., 2] int64 {lower, upper} -> uint8 [packed_pairs_bytes(n)]: {lower:40, width:40} per pair, width =
     upper - lower + 1 mod 2^64 (include/rsbwt.h, rsbwt_pack_interval_pairs_dev).  On a GPU tensor the
     library's kernel does it; this torch form serves host tensors (gloo tests, the one-GPU rehearsal) and is
-    what the kernel is tested against."""
+    what the kernel is tested against.  Every interval findInterval leaves fits the record (shards hold at
+    most 2^40 symbols); check=True counts the pairs that do not (arbitrary tensors) and raises -- it costs a
+    device synchronisation, so the pipelined gather leaves it off and bench.py's verification turns it on."""
     flat = pairs.reshape(-1, 2)
     n = flat.shape[0]
     if flat.is_cuda:
@@ -73,13 +75,21 @@ def pack_pairs(pairs, out=None):
         import ctypes as C
         if out is None or out.device != flat.device:
             out = torch.empty(packed_pairs_bytes(n), dtype=torch.uint8, device=flat.device)
-        rc = lib().rsbwt_pack_interval_pairs_dev(C.c_void_p(flat.data_ptr()), n, C.c_void_p(out.data_ptr()), None,
+        unfit = torch.zeros(1, dtype=torch.int32, device=flat.device) if check else None
+        rc = lib().rsbwt_pack_interval_pairs_dev(C.c_void_p(flat.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(unfit.data_ptr()) if check else None,
                                                  flat.device.index or 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError(lib().rsbwt_last_error().decode())
+        if check and int(unfit.item()):
+            raise ValueError(f"{int(unfit.item())} of {n} pairs do not fit the 10-byte {{lower:40, width:40}} record")
         return out
     lo = flat[:, 0] & _M40
     w = (flat[:, 1] - flat[:, 0] + 1) & _M40
+    if check:
+        bad = int((((flat[:, 0] >> 40) != 0) | ((((flat[:, 1] - flat[:, 0] + 1)) >> 40) != 0)).sum())
+        if bad:
+            raise ValueError(f"{bad} of {n} pairs do not fit the 10-byte {{lower:40, width:40}} record")
     f = torch.stack([lo, w], 1).reshape(-1)  # 2n fields of 40 bits
     by = torch.stack([(f >> (8 * b)) & 0xFF for b in range(5)], 1).to(torch.uint8).reshape(-1)  # little endian
     if out is None:
@@ -124,7 +134,7 @@ class IntervalGatherer:
                  packed=False, wire_device=None):
         """interleaved: buffers are [S_local, Q, 2] = {lower, upper} pairs (what rsbwt_*_interval_pairs_dev
         writes) instead of [2, S_local, Q].  packed (with interleaved): what travels is the 10-byte form of the
-        pairs (pack_pairs): 5/8 of the bytes over xGMI; `result_packed(i)` holds the ranks' blocks as they
+        pairs (pack_pairs): 5/8 of the bytes over xGMI; `result(i)` holds the ranks' blocks as they
         arrived, `unpack_block` turns one back into pairs.  wire_device: where the packed buffers live when that
         is not `device` (the one-GPU rehearsal packs on the GPU and gathers host copies over gloo)."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -174,3 +174,17 @@ def test_single_process_gatherer_is_a_no_op():
     g.submit(0)
     g.drain()
     assert g.result(0)[0] is g.pair(0) and int(g.pair(0).sum()) == 60
+
+
+def test_pack_pairs_check_refuses_what_the_record_cannot_carry():
+    """{lower:40, width:40} carries every interval findInterval leaves; an arbitrary pair may not fit, and
+    check=True says so instead of truncating it on the wire."""
+    import torch
+    from readserver_amd import sharded
+    ok = torch.tensor([[0, -1], [1, 0], [5, 9], [(1 << 40) - 1, (1 << 40) - 2], [7, 7 + (1 << 40) - 2]], dtype=torch.int64)
+    assert torch.equal(sharded.unpack_pairs(sharded.pack_pairs(ok, check=True), ok.shape[0]), ok)
+    for bad in ([[1 << 40, (1 << 40) + 3]], [[0, 1 << 40]]):
+        t = torch.tensor(bad, dtype=torch.int64)
+        with pytest.raises(ValueError):
+            sharded.pack_pairs(t, check=True)
+        sharded.pack_pairs(t)  # unchecked: truncates, as documented

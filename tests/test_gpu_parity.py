@@ -80,7 +80,7 @@ def test_gpu_golden_extract(rsb, gix, golden):
         assert s.encode() == e[:n].tobytes() and pl == gpl
 
 
-@pytest.mark.parametrize("k", [1, 5, 31, 33])
+@pytest.mark.parametrize("k", [1, 4, 5, 31, 32, 33])  # 301 k-mers: with even k the [m][3k+1] parts of the scratch have odd sizes
 def test_gpu_one_mismatch_equals_composition_of_exact_searches(rsb, oracle, tmp_path, k):
     """configs[3] is not in the reference: the result is defined as the oracle's exact findInterval
     of every single-substitution variant."""

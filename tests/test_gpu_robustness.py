@@ -132,3 +132,113 @@ def test_gpu_wild_counts_do_not_leave_the_index(rsb, kernel, depth):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wildocc_probe.py"), str(depth)], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "survived" in out.stdout, out.stderr[-2000:]
+
+
+# ---- the 40-bit range: positions near 2^40, the widest span -------------------------------------------
+
+def test_gpu_fast_window_is_integer_division_up_to_2_pow_40(rsb):
+    """w = p / S by an f64 multiply and one fix-up step (csrc/rank_device.h) against integer division over
+    the positions a shard can have: p < 2^40 and fewer than 2^32 lines (17 lines per 16 windows), i.e. p <
+    min(2^40, S * 4042322160).  Every span 2..2944 on the last 4096 such positions and on multiples of S
+    +- 1; seven spans (the widest, the bench streams' own) on the whole last 2^20 positions and 10^6 random
+    ones."""
+    L = rsb.lib()
+    rng = np.random.default_rng(40)
+
+    def top(S):
+        return min(1 << 40, S * 4042322160)
+
+    def check(S, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        w, r = np.empty(p.size, np.uint32), np.empty(p.size, np.uint32)
+        assert L.rsbwt_debug_fast_window(p.ctypes.data, p.size, S, w.ctypes.data, r.ctypes.data, 0) == 0
+        assert np.array_equal(w.astype(np.uint64), p // np.uint64(S)), S
+        assert np.array_equal(r.astype(np.uint64), p % np.uint64(S)), S
+    for S in range(2, 2945):
+        t = top(S)
+        m = rng.integers(1, t // S, 512).astype(np.uint64) * np.uint64(S)
+        check(S, np.concatenate([np.arange(t - 4096, t, dtype=np.uint64), m - np.uint64(1), m, m + np.uint64(1),
+                                 np.array([0, 1, S - 1, S, (t - 1) // S * S], dtype=np.uint64)]))
+    for S in (2, 3, 272, 915, 2233, 2943, 2944):
+        check(S, np.arange(top(S) - (1 << 20), top(S), dtype=np.uint64))
+        check(S, rng.integers(0, top(S), 1000000).astype(np.uint64))
+    one = np.zeros(1, np.uint64)
+    assert L.rsbwt_debug_fast_window(one.ctypes.data, 1, 1, one.ctypes.data, one.ctypes.data, 0) == -7
+
+
+def test_gpu_index_at_the_top_of_the_40_bit_range(rsb):
+    """A shard of 2^40 - 1 - ((2^40 - 1) mod 31) symbols (the format's limit is 2^40) with the widest window
+    span, 2,944: A^31 C^31 G^31 T^31 repeated, for which Occ has a closed form -- so every answer can be
+    checked without a CPU index of 35 GB.  Occ at the last 2^20 positions and at 10^6 random ones, the
+    select round trip, and findInterval (with and without the k-mer table) against the same backward search
+    done in numpy on the closed form; one symbol more is refused with RSBWT_ERANGE."""
+    import ctypes as C
+    import torch
+    L = rsb.lib()
+    R = ((1 << 40) - 1) // 31
+    n = 31 * R
+    assert (1 << 40) - 31 <= n < (1 << 40)
+    d_runs = torch.empty(R + 1, dtype=torch.uint8, device="cuda:0")
+    step = 1 << 28
+    for i in range(0, R + 1, step):
+        j = min(R + 1, i + step)
+        d_runs[i:j] = ((((torch.arange(i, j, device="cuda:0") & 3) + 1) << 5) | 31).to(torch.uint8)
+    torch.cuda.synchronize()
+
+    def occ(b, p):  # closed form: # of symbol b (1..4) in [0, p]; p = -1 gives 0
+        c = p.astype(np.int64) + 1
+        m, r = c // 31, c % 31
+        return 31 * ((m + 3 - (b - 1)) // 4) + np.where(m % 4 == b - 1, r, 0)
+
+    with pytest.raises(rsb.RsbwtError) as e:  # 31 symbols more: past 2^40
+        rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R + 1), window_span=2944, ktab_depth=None)
+    assert e.value.code == -7
+    g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), window_span=2944, ktab_depth=None)
+    del d_runs
+    torch.cuda.empty_cache()
+    assert g.getBWLen() == n and g.window_span() == 2944
+    rng = np.random.default_rng(41)
+    pos = np.concatenate([np.arange(n - (1 << 20), n), rng.integers(0, n, 1000000)]).astype(np.uint64)
+    tot = {b: int(occ(b, np.array([n - 1]))[0]) for b in (1, 2, 3, 4)}
+    Cb = {1: 0, 2: tot[1], 3: tot[1] + tot[2], 4: tot[1] + tot[2] + tot[3]}
+    for b, ch in enumerate("ACGT", 1):
+        assert g.getPC(ch) == Cb[b]
+        assert np.array_equal(g.occ_batch(ch, pos).astype(np.int64), occ(b, pos)), ch
+        bc = np.concatenate([rng.integers(1, tot[b] + 1, 20000), [1, tot[b]]]).astype(np.uint64)
+        idx = g.occ_at_batch(ch, bc)
+        assert (g.char_batch(idx) == ord(ch)).all() and np.array_equal(g.occ_batch(ch, idx), bc)
+    assert not g.occ_batch("$", pos).any()
+    # findInterval: k-mers that live long on this text (runs of one symbol), random ones, and the corners
+    km = _kmers(rng, 30000, 31)
+    km[:10000] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (10000, 1))]       # X^31
+    sw = rng.integers(1, 31, 5000)
+    for i in range(5000):                                                                # X^a Y^(31-a)
+        km[10000 + i, sw[i]:] = km[10000 + i, 0] if km[10000 + i, 0] != km[10000 + i, 30] else ord("C")
+    code = {65: 1, 67: 2, 71: 3, 84: 4}
+    kb = np.vectorize(code.get)(km)
+    lo = np.array([Cb[b] for b in kb[:, 30]], dtype=np.int64)
+    hi = np.array([Cb[b] + tot[b] - 1 for b in kb[:, 30]], dtype=np.int64)
+    alive = np.ones(km.shape[0], bool)
+    for j in range(29, -1, -1):  # query.cpp:32-38
+        b = kb[:, j]
+        nl, nh = lo.copy(), hi.copy()
+        for s in (1, 2, 3, 4):
+            sel = alive & (b == s)
+            nl[sel] = Cb[s] + occ(s, lo[sel] - 1)
+            nh[sel] = Cb[s] + occ(s, hi[sel]) - 1
+        lo, hi = nl, nh
+        alive &= lo <= hi
+    glo, gup = rsb.find_intervals(g, km)
+    assert np.array_equal(glo.astype(np.int64), lo) and np.array_equal(gup.astype(np.int64), hi)
+    assert alive.sum() > 2000 and (hi[alive] > (1 << 39)).any() and (~alive).sum() > 2000  # both kinds are there
+    assert L.rsbwt_attach_ktab(g.handle, 12) == 0
+    glo, gup = rsb.find_intervals(g, km)
+    assert np.array_equal(glo.astype(np.int64), lo) and np.array_equal(gup.astype(np.int64), hi)
+    # reads out of the same shard: every step of the walks is an Occ / select near the top of the range
+    rows = np.concatenate([rng.integers(n - (1 << 30), n, 2000), rng.integers(0, n, 2000)]).astype(np.uint64)
+    out = np.empty((rows.size, 64), np.uint8)
+    ln, pl = np.empty(rows.size, np.uint32), np.empty(rows.size, np.uint32)
+    assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 64, ln.ctypes.data, pl.ctypes.data) == 0
+    # no '$' anywhere: every walk runs into the stride (the reference would spin, query.cpp:48) and is marked
+    assert (ln == 0xFFFFFFFF).all()
+    g.close()
