@@ -316,6 +316,33 @@ int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, cons
  * receives the blocks back to back.  For GPU-resident consumers of all shards' intervals. */
 int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, const size_t *bytes,
                                    void *d_root, void *const *streams);
+/* BASELINE configs[3] / configs[4] over a set that may span devices.  The reference's front-end sends every
+ * request to every partition and CONCATENATES the per-partition read lists (src/service/server.cpp:124,199-261):
+ * the set-level forms are every shard's own result, side by side.  Devices work concurrently, a device's shards
+ * take turns; each device's lists / reads cross its own PCIe link straight into the caller's buffers.
+ *
+ * rsbwt_set_hits_1mm: every shard's rsbwt_hits_1mm list: hits[first[i] .. first[i+1]) = shard i's (first has
+ * num_shards + 1 entries; *nhits = first[num_shards]); RSBWT_ERANGE with *nhits and first[] set when cap is short. */
+int rsbwt_set_hits_1mm(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
+                       size_t cap, uint64_t *first, size_t *nhits);
+/* rsbwt_extract for rows of several shards: row i = SA row rows[i] of shard shard_of[i] (the ExtractTask chunks of
+ * src/service/service.cpp:729-740 of all partitions in one call). */
+int rsbwt_set_extract(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *rows, size_t n, char *out, uint32_t stride,
+                      uint32_t *len, uint32_t *prefix_len);
+/* rsbwt_query over every shard = find_reads of a short query (service.cpp:714-743) in every partition, the lists
+ * concatenated as the front-end does: k-mer q's reads are first[q] .. first[q+1], shard 0's first, each shard's in
+ * SA-row order; read_shard[r] (optional) names the shard.  cap_reads = 0 sizes the buffers (RSBWT_ERANGE, *nreads set). */
+int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
+                    uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
+                    size_t *nreads);
+/* Device-resident forms, for a set on ONE device (one process per GPU: bench.py --mode 1mm|extract).
+ * d_hits [num_shards][cap_per_shard] x 32-byte records (rsbwt_hits_1mm_dev's), d_totals u64[num_shards];
+ * d_rows [num_shards][n] (row numbers are per shard), d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]. */
+size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k);
+int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,
+                           size_t cap_per_shard, void *d_totals, void *d_scratch, void *stream);
+int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
+                          void *d_prefix_len, void *stream);
 int rsbwt_rccl_available(void); /* 1 when librccl could be bound at run time */
 /* measurement hooks of a set's fused launches (first device): as the per-handle ones */
 int rsbwt_set_set_counting(rsbwt_set_t *s, int on);

@@ -367,6 +367,56 @@ class ShardSet:
         check(lib().rsbwt_set_count(self._s, _ptr(a), a.shape[0], k, max(k, 1), _ptr(out)))
         return out
 
+    # -- BASELINE configs[3] / configs[4] over the set: per-shard results side by side, the way the front-end
+    # concatenates its partitions' replies (src/service/server.cpp:199-261)
+    def hits_1mm(self, kmers):
+        """Every shard's 1-mismatch hit list: (HIT_1MM array, first) with shard i's hits at first[i]:first[i+1]."""
+        a, k = _kmer_matrix(kmers)
+        Q, S = a.shape[0], len(self.shards)
+        cap = max(1024, 4 * Q * S)
+        first = np.zeros(S + 1, np.uint64)
+        while True:
+            out = np.zeros(cap, HIT_1MM)
+            n = C.c_size_t()
+            rc = lib().rsbwt_set_hits_1mm(self._s, _ptr(a), Q, k, max(k, 1), _ptr(out), cap, _ptr(first), C.byref(n))
+            if rc == -7 and n.value > cap:
+                cap = n.value
+                continue
+            check(rc)
+            return out[:n.value], first
+
+    def extract(self, shard_of, rows, stride=512):
+        """Reads at (shard, row) pairs: (list of strings, prefix lengths)."""
+        sh = np.ascontiguousarray(shard_of, dtype=np.uint32)
+        r = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((r.size, stride), np.uint8)
+        ln, pl = np.empty(r.size, np.uint32), np.empty(r.size, np.uint32)
+        check(lib().rsbwt_set_extract(self._s, _ptr(sh), _ptr(r), r.size, _ptr(out), stride, _ptr(ln), _ptr(pl)))
+        if (ln == 0xFFFFFFFF).any():
+            raise RsbwtError(-1, "a read does not fit the stride / a row is out of range")
+        return [out[i, :ln[i]].tobytes().decode() for i in range(r.size)], pl
+
+    def query(self, kmers, read_stride=256):
+        """query() in every shard (query.cpp:87-100): per k-mer a list of (shard, read), shard 0's reads first."""
+        a, k = _kmer_matrix(kmers)
+        Q = a.shape[0]
+        first = np.zeros(Q + 1, np.uint64)
+        n = C.c_size_t()
+        rc = lib().rsbwt_set_query(self._s, _ptr(a), Q, k, max(k, 1), _ptr(first), None, None, read_stride, None, 0, C.byref(n))
+        if rc not in (0, -7):
+            check(rc)
+        total = n.value
+        reads = np.zeros((max(total, 1), read_stride), np.uint8)
+        ln = np.zeros(max(total, 1), np.uint32)
+        sh = np.zeros(max(total, 1), np.uint32)
+        if total:
+            check(lib().rsbwt_set_query(self._s, _ptr(a), Q, k, max(k, 1), _ptr(first), _ptr(sh), _ptr(reads), read_stride,
+                                        _ptr(ln), total, C.byref(n)))
+            if (ln[:total] == 0xFFFFFFFF).any():
+                raise RsbwtError(-1, "a read does not fit read_stride")
+        return [[(int(sh[r]), reads[r, :ln[r]].tobytes().decode()) for r in range(int(first[q]), int(first[q + 1]))]
+                for q in range(Q)]
+
 
 def write_bpi2(bwt_path, bpi2_path=None):
     """src/util/index_rlebwt.cpp:19-22: writes the reference's FM-index file for a .bwt (default

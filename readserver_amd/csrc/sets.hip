@@ -572,6 +572,198 @@ int rsbwt_set_gather_intervals_dev(rsbwt_set_t *s, const void *const *d_blocks, 
 }
 
 
+// ---- configs[3] / configs[4] over a set that may span devices -------------------------------------------
+// The reference's front-end sends every request to every partition and CONCATENATES the per-partition
+// read lists (src/service/server.cpp:124,199-261); a partition answers with what ITS BWT holds.  So the
+// set-level forms of the 1-mismatch search and of locate + extract are per-shard results laid side by
+// side: the devices work concurrently (one host thread each), a device's shards take turns on it, and
+// what crosses PCIe is each device's own lists / reads, straight to the caller's host buffers.
+
+// every shard's rsbwt_hits_1mm list, in shard order: hits[first[i] .. first[i+1]) are shard i's
+static int rsbwt_set_hits_1mm_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride,
+                                   rsbwt_hit_1mm *hits, size_t cap, uint64_t *first, size_t *nhits) {
+    if (!s || !nhits || !first) return fail(RSBWT_EINVAL, "null argument");
+    const size_t S = s->shards.size();
+    *nhits = 0;
+    for (size_t i = 0; i <= S; ++i) first[i] = 0;
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers || (!hits && cap)) return fail(RSBWT_EINVAL, "null argument");
+    std::vector<std::vector<rsbwt_hit_1mm>> part(S);
+    int rc = for_each_group(s, [&](size_t gi) -> int {
+        dev_group *g = s->groups[gi];
+        for (size_t i : g->idx) {
+            std::vector<rsbwt_hit_1mm> &v = part[i];
+            v.resize(std::max<size_t>(4 * Q, 1024));
+            size_t n = 0;
+            int r = rsbwt_hits_1mm(s->shards[i], kmers, Q, k, stride, v.data(), v.size(), &n);
+            if (r == RSBWT_ERANGE && n > v.size()) {  // (k out of range also says ERANGE: n stays 0)
+                v.resize(n);
+                r = rsbwt_hits_1mm(s->shards[i], kmers, Q, k, stride, v.data(), v.size(), &n);
+            }
+            if (r) return r;
+            v.resize(n);
+        }
+        return RSBWT_OK;
+    });
+    if (rc) return rc;
+    size_t total = 0;
+    for (size_t i = 0; i < S; ++i) {
+        first[i] = total;
+        total += part[i].size();
+    }
+    first[S] = total;
+    *nhits = total;
+    if (total > cap) return fail(RSBWT_ERANGE, "%zu hits over the set, room for %zu", total, cap);
+    for (size_t i = 0; i < S; ++i)
+        if (!part[i].empty()) memcpy(hits + first[i], part[i].data(), part[i].size() * sizeof(rsbwt_hit_1mm));
+    return RSBWT_OK;
+}
+int rsbwt_set_hits_1mm(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
+                       size_t cap, uint64_t *first, size_t *nhits) {
+    return guarded("rsbwt_set_hits_1mm", [&]() -> int { return rsbwt_set_hits_1mm_body(s, kmers, Q, k, stride, hits, cap, first, nhits); });
+}
+
+// row i = SA row rows[i] of shard shard_of[i]
+static int rsbwt_set_extract_body(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *rows, size_t n, char *out,
+                                  uint32_t stride, uint32_t *len, uint32_t *prefix_len) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (n == 0) return RSBWT_OK;
+    if (!shard_of || !rows || !out) return fail(RSBWT_EINVAL, "null argument");
+    const size_t S = s->shards.size();
+    std::vector<std::vector<size_t>> where(S);
+    for (size_t i = 0; i < n; ++i) {
+        if (shard_of[i] >= S) return fail(RSBWT_EINVAL, "row %zu names shard %u of %zu", i, shard_of[i], S);
+        where[shard_of[i]].push_back(i);
+    }
+    return for_each_group(s, [&](size_t gi) -> int {
+        dev_group *g = s->groups[gi];
+        for (size_t si : g->idx) {
+            const std::vector<size_t> &w = where[si];
+            if (w.empty()) continue;
+            const size_t m = w.size();
+            std::vector<uint64_t> r(m);
+            std::vector<char> o(m * (size_t)stride);
+            std::vector<uint32_t> ln(m), pl(m);
+            for (size_t j = 0; j < m; ++j) r[j] = rows[w[j]];
+            const int rc = rsbwt_extract(s->shards[si], r.data(), m, o.data(), stride, ln.data(), pl.data());
+            if (rc) return rc;
+            for (size_t j = 0; j < m; ++j) {
+                const uint32_t keep = ln[j] == 0xFFFFFFFFu ? 0u : ln[j];
+                if (keep) memcpy(out + w[j] * (size_t)stride, o.data() + j * (size_t)stride, keep);
+                if (len) len[w[j]] = ln[j];
+                if (prefix_len) prefix_len[w[j]] = pl[j];
+            }
+        }
+        return RSBWT_OK;
+    });
+}
+int rsbwt_set_extract(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *rows, size_t n, char *out, uint32_t stride,
+                      uint32_t *len, uint32_t *prefix_len) {
+    return guarded("rsbwt_set_extract", [&]() -> int { return rsbwt_set_extract_body(s, shard_of, rows, n, out, stride, len, prefix_len); });
+}
+
+// query() of every shard (query.cpp:87-100), k-mer by k-mer: k-mer q's reads are first[q] .. first[q+1],
+// shard 0's first (each shard's in SA-row order), read_shard[r] naming the shard read r came from
+static int rsbwt_set_query_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
+                                uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
+                                size_t *nreads) {
+    if (!s || !nreads || (!first && Q)) return fail(RSBWT_EINVAL, "null argument");
+    *nreads = 0;
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers) return fail(RSBWT_EINVAL, "null argument");
+    const size_t S = s->shards.size();
+    struct part_t {
+        std::vector<uint64_t> first;
+        std::vector<char> reads;
+        std::vector<uint32_t> len;
+    };
+    std::vector<part_t> part(S);
+    const bool sizing = cap_reads == 0;  // the caller only wants the number: nothing is extracted
+    int rc = for_each_group(s, [&](size_t gi) -> int {
+        dev_group *g = s->groups[gi];
+        for (size_t i : g->idx) {
+            part_t &p = part[i];
+            p.first.assign(Q + 1, 0);
+            size_t n = 0;
+            int r = rsbwt_query(s->shards[i], kmers, Q, k, stride, p.first.data(), nullptr, read_stride, nullptr, 0, &n);
+            if (r != RSBWT_OK && r != RSBWT_ERANGE) return r;
+            if (n == 0 || sizing) continue;
+            p.reads.resize(n * (size_t)read_stride);
+            p.len.resize(n);
+            r = rsbwt_query(s->shards[i], kmers, Q, k, stride, p.first.data(), p.reads.data(), read_stride, p.len.data(), n, &n);
+            if (r) return r;
+        }
+        return RSBWT_OK;
+    });
+    if (rc) return rc;
+    size_t total = 0;
+    for (size_t q = 0; q < Q; ++q) {
+        first[q] = total;
+        for (size_t i = 0; i < S; ++i) total += (size_t)(part[i].first[q + 1] - part[i].first[q]);
+    }
+    first[Q] = total;
+    *nreads = total;
+    if (total > cap_reads) return fail(RSBWT_ERANGE, "%zu reads over the set, room for %zu", total, cap_reads);
+    if (total && (!reads || !read_len)) return fail(RSBWT_EINVAL, "null argument");
+    size_t at = 0;
+    for (size_t q = 0; q < Q; ++q)
+        for (size_t i = 0; i < S; ++i) {
+            const part_t &p = part[i];
+            for (uint64_t r = p.first[q]; r < p.first[q + 1]; ++r, ++at) {
+                const uint32_t ln = p.len[r];
+                if (ln != 0xFFFFFFFFu && ln) memcpy(reads + at * (size_t)read_stride, p.reads.data() + r * (size_t)read_stride, ln);
+                read_len[at] = ln;
+                if (read_shard) read_shard[at] = (uint32_t)i;
+            }
+        }
+    return RSBWT_OK;
+}
+int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
+                    uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
+                    size_t *nreads) {
+    return guarded("rsbwt_set_query", [&]() -> int {
+        return rsbwt_set_query_body(s, kmers, Q, k, stride, first, read_shard, reads, read_stride, read_len, cap_reads, nreads);
+    });
+}
+
+// Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
+// The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
+size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
+    size_t need = 0;
+    if (s)
+        for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_hits_1mm_scratch_bytes(h, m, k));
+    return need;
+}
+
+// d_hits: [num_shards][cap_per_shard] records of 32 B (rsbwt_hits_1mm_dev's), d_totals: u64[num_shards]
+int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,
+                           size_t cap_per_shard, void *d_totals, void *d_scratch, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    if (!d_totals || (!d_hits && cap_per_shard)) return fail(RSBWT_EINVAL, "null argument");
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        const int rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32,
+                                          cap_per_shard, (uint8_t *)d_totals + i * 8, d_scratch, stream);
+        if (rc) return rc;
+    }
+    return RSBWT_OK;
+}
+
+// d_rows: [num_shards][n] SA rows (row numbers are per shard); d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]
+int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
+                          void *d_prefix_len, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    if (n == 0) return RSBWT_OK;
+    if (!d_rows || !d_out || !d_len || !d_prefix_len) return fail(RSBWT_EINVAL, "null argument");
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        const int rc = rsbwt_extract_dev(s->shards[i], (const uint8_t *)d_rows + i * n * 8, n, (uint8_t *)d_out + i * n * (size_t)stride,
+                                         stride, (uint8_t *)d_len + i * n * 4, (uint8_t *)d_prefix_len + i * n * 4, stream);
+        if (rc) return rc;
+    }
+    return RSBWT_OK;
+}
+
 int rsbwt_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
 // measurement hooks of the set's first device group (bench.py)

@@ -1,0 +1,154 @@
+"""GPU suite (-m gpu): BASELINE configs[3] / configs[4] over a shard set -- 1-mismatch hit lists, extraction
+of (shard, row) pairs and locate + extract (query) in every shard, the per-shard results laid side by side the
+way the reference's front-end concatenates its partitions' replies (src/service/server.cpp:199-261).  One
+device here; the same entry points drive the devices of a set concurrently (csrc/sets.hip)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def four_shards(rsb, oracle, tmp_path_factory):
+    d = tmp_path_factory.mktemp("set")
+    kw = dict(seed=31, genome_len=25000, haplotypes=6, snp_rate=0.004, read_len=70, coverage=3.0)
+    shards, oixs = [], []
+    for s in range(4):
+        p = str(d / f"s{s}.bwt")
+        rsb.synth_popbwt(p, None, shard=s, num_shards=4, **kw)
+        shards.append(rsb.GpuBWT(p, ktab_depth=(8 if s % 2 else 6)))
+        oixs.append(oracle.load(p))
+    rd = str(d / "whole.reads")
+    rsb.synth_popbwt(str(d / "whole.bwt"), rd, **kw)
+    reads = open(rd).read().split()
+    ss = rsb.ShardSet(shards)
+    yield ss, shards, oixs, reads
+    ss.close()
+    for g in shards:
+        g.close()
+
+
+def _kmers_from(reads, rng, n, k, mutate=0.0):
+    out = []
+    for _ in range(n):
+        r = reads[rng.integers(len(reads))]
+        s = rng.integers(0, len(r) - k + 1)
+        w = list(r[s:s + k])
+        if rng.random() < mutate:
+            p = rng.integers(k)
+            w[p] = "ACGT"[("ACGT".index(w[p]) + 1 + rng.integers(3)) % 4]
+        out.append("".join(w))
+    return out
+
+
+@pytest.mark.parametrize("k", [12, 31, 40])
+def test_gpu_set_hit_lists_are_the_shards_lists_side_by_side(rsb, four_shards, k):
+    ss, shards, oixs, reads = four_shards
+    rng = np.random.default_rng(k)
+    kmers = _kmers_from(reads, rng, 257, k, mutate=0.5) + ["N" * k]
+    hits, first = ss.hits_1mm(kmers)
+    assert first[0] == 0 and first[-1] == len(hits) and (np.diff(first.astype(np.int64)) >= 0).all()
+    for s, (g, oix) in enumerate(zip(shards, oixs)):
+        mine = hits[int(first[s]):int(first[s + 1])]
+        assert np.array_equal(mine, rsb.hits_1mm_batch(g, kmers))  # the shard's own list
+        # ... which is the oracle's exact search of every variant, for a sample of the k-mers
+        for qi in range(0, len(kmers) - 1, 16):
+            w = kmers[qi]
+            want = []
+            lo, up = oix.find_interval(w)
+            if up >= lo:
+                want.append((-1, b"", lo, up))
+            for pos in range(k):
+                for alt in [c for c in "ACGT" if c != w[pos]]:
+                    lo, up = oix.find_interval(w[:pos] + alt + w[pos + 1:])
+                    if up >= lo:
+                        want.append((pos, alt.encode(), lo, up))
+            got = [(int(h["pos"]), bytes(h["base"]), int(h["lower"]), int(h["upper"])) for h in mine[mine["query"] == qi]]
+            assert got == want, (s, qi)
+    assert len(hits) > 4 * 100
+    # a buffer that is too short: nothing written, the sizes reported
+    L = rsb.lib()
+    a = np.frombuffer("".join(kmers).encode(), np.uint8)
+    n = C.c_size_t()
+    f2 = np.zeros(5, np.uint64)
+    assert L.rsbwt_set_hits_1mm(ss._s, a.ctypes.data, len(kmers), k, k, None, 0, f2.ctypes.data, C.byref(n)) == -7
+    assert n.value == len(hits) and np.array_equal(f2, first)
+
+
+def test_gpu_set_extract_rows_of_several_shards(rsb, four_shards):
+    ss, shards, oixs, reads = four_shards
+    rng = np.random.default_rng(3)
+    sh = rng.integers(0, 4, 3001).astype(np.uint32)
+    rows = np.array([rng.integers(0, oixs[s].bwlen()) for s in sh], dtype=np.uint64)
+    got, pl = ss.extract(sh, rows, stride=96)
+    for i in range(0, len(rows), 7):
+        pre, post = oixs[sh[i]].extract(int(rows[i]))
+        assert got[i] == pre + post and pl[i] == len(pre)
+    assert all(r in set(reads) for r in got[:200])
+    with pytest.raises(rsb.RsbwtError):
+        ss.extract([9], [0])
+
+
+def test_gpu_set_query_concatenates_the_partitions_reads(rsb, four_shards):
+    """find_reads of a short query in every partition (service.cpp:714-743), lists concatenated per query
+    (server.cpp:199-261): every read of the unsharded collection that contains the k-mer, exactly once."""
+    ss, shards, oixs, reads = four_shards
+    rng = np.random.default_rng(4)
+    kmers = _kmers_from(reads, rng, 150, 25) + ["ACGTACGTACGTACGTACGTACGTA", "N" * 25]
+    got = ss.query(kmers, read_stride=96)
+    for q, w in enumerate(kmers):
+        exp = []
+        for s, oix in enumerate(oixs):
+            lo, up = oix.find_interval(w) if "N" not in w else (1, 0)
+            for r in range(lo, up + 1):
+                pre, post = oix.extract(r)
+                exp.append((s, pre + post))
+        assert got[q] == exp, q
+        assert sorted(r for _, r in got[q]) == sorted(r for r in reads if w in r)
+    assert sum(len(x) for x in got) > 300
+
+
+def test_gpu_set_device_resident_forms(rsb, four_shards):
+    """rsbwt_set_hits_1mm_dev / rsbwt_set_extract_dev (what bench.py --mode 1mm|extract times) against the host forms."""
+    import torch
+    ss, shards, oixs, reads = four_shards
+    L = rsb.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(5)
+    k, m, S = 31, 500, 4
+    kmers = _kmers_from(reads, rng, m, k, mutate=0.5)
+    d_km = torch.from_numpy(np.frombuffer("".join(kmers).encode(), np.uint8).reshape(m, k).copy()).to(dev)
+    d_pk = torch.empty(m, dtype=torch.int64, device=dev)
+    d_ok = torch.empty(m, dtype=torch.uint8, device=dev)
+    assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+    cap = 8 * m
+    d_hits = torch.zeros((S, cap, 4), dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(S, dtype=torch.int64, device=dev)
+    d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device=dev)
+    assert L.rsbwt_set_hits_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_hits), cap, p(d_tot), p(d_scr), None) == 0
+    torch.cuda.synchronize()
+    hits, first = ss.hits_1mm(kmers)
+    V = 3 * k + 1
+    for s in range(S):
+        n = int(d_tot[s].item())
+        mine = hits[int(first[s]):int(first[s + 1])]
+        assert n == len(mine)
+        rec = d_hits[s, :n].cpu().numpy().view(np.uint64)
+        assert np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
+        assert np.array_equal(rec[:, 2] // V, mine["query"].astype(np.uint64))
+    n = 700
+    rows = np.stack([rng.integers(0, oixs[s].bwlen(), n) for s in range(S)]).astype(np.int64)
+    d_rows = torch.from_numpy(rows).to(dev)
+    d_out = torch.zeros((S, n, 96), dtype=torch.uint8, device=dev)
+    d_len = torch.zeros((S, n), dtype=torch.int32, device=dev)
+    d_pl = torch.zeros((S, n), dtype=torch.int32, device=dev)
+    assert L.rsbwt_set_extract_dev(ss._s, p(d_rows), n, p(d_out), 96, p(d_len), p(d_pl), None) == 0
+    torch.cuda.synchronize()
+    out, ln, pl = d_out.cpu().numpy(), d_len.cpu().numpy(), d_pl.cpu().numpy()
+    want, wpl = ss.extract(np.repeat(np.arange(S), n), rows.reshape(-1), stride=96)
+    for s in range(S):
+        for i in range(0, n, 5):
+            assert out[s, i, :ln[s, i]].tobytes().decode() == want[s * n + i] and pl[s, i] == wpl[s * n + i]
