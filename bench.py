@@ -49,12 +49,25 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--shards-per-gpu", type=int, default=8)
     ap.add_argument("--present-frac", type=float, default=0.5)
-    ap.add_argument("--same-shards", action="store_true",
-                    help="every shard of a rank holds the same stream, so a present k-mer is present in all of them "
-                         "(the work profile of a real population: each shard sees configs[1]'s mix)")
-    ap.add_argument("--stream", choices=["mixed", "long"], default="mixed",
-                    help="run-length mix of the synthetic stream: mixed = mean ~10.4 symbols per unit; "
-                         "long = mostly 31-symbol units of long runs (mean ~25), as in a deep population BWT")
+    ap.add_argument("--mode", choices=["exact", "1mm", "extract"], default="exact",
+                    help="exact = configs[1]/[2], the headline; 1mm = configs[3] (1-mismatch hit lists of every shard); "
+                         "extract = configs[4] (locate + read extraction in every shard)")
+    ap.add_argument("--mix", choices=["population", "disjoint"], default="population",
+                    help="population (headline): every shard holds the same stream, a present k-mer is present in every shard; "
+                         "disjoint: every shard its own stream, a present k-mer is in one shard only (round 2's default). "
+                         "A one-GPU run measures the other mix too (config.mixes) unless --no-second-mix")
+    ap.add_argument("--same-shards", action="store_true", help="(old name of --mix population)")
+    ap.add_argument("--no-second-mix", action="store_true", help="time only --mix (profile passes)")
+    ap.add_argument("--stream", choices=["mixed", "long", "pop"], default="pop",
+                    help="run-length mix of the synthetic stream: pop = the unit-length histogram measured on a valid population "
+                         "BWT (5.8 symbols per unit; tools/popbwt_gpu.py); mixed = ~10.4 symbols per unit; long = mostly "
+                         "31-symbol units of long runs (~25)")
+    ap.add_argument("--kmers", type=float, default=4e5, help="--mode 1mm: 31-mers per batch")
+    ap.add_argument("--rows", type=float, default=2e6, help="--mode extract: rows per shard and batch")
+    ap.add_argument("--row-run", type=int, default=8,
+                    help="--mode extract: rows come as runs of this many consecutive SA rows (the rows of an interval: "
+                         "query.cpp:94-96 extracts lower..upper; 8 = the final width measured on the valid popBWT)")
+    ap.add_argument("--stride", type=int, default=256, help="--mode extract: bytes per read buffer")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
@@ -82,7 +95,10 @@ def parse():
                     help="rehearsal aid: hold this much HBM while the k-mer tables are sized, as rank 0 of an N-GPU "
                          "job holds the gathered intervals (12.8 GB of 10-byte records at N = 8; 20.5 GB unpacked)")
     ap.add_argument("--seed", type=int, default=1)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.same_shards:
+        a.mix = "population"
+    return a
 
 
 def kernel_source_sha():
@@ -149,70 +165,171 @@ def self_launch(a, argv):
     sys.exit(rc if rc >= 0 else 128 - rc)
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(a, sys.argv[1:])
+class Ctx:
+    """What every leg of the bench shares: the library, this rank's place in the job, its device."""
+
+
+def setup(a):
     import torch
     import torch.distributed as dist
     import readserver_amd as rsb
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+    c = Ctx()
+    c.torch, c.dist, c.rsb = torch, dist, rsb
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.local = int(os.environ.get("LOCAL_RANK", "0"))
+    if c.world != a.gpus:
+        if c.rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={c.world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(1)
     if a.rehearse_on_one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    cdev = torch.device("cpu") if a.rehearse_on_one_gpu else dev  # where the collectives' tensors live
-    if world > 1:
+        c.local = 0
+    torch.cuda.set_device(c.local)
+    c.dev = torch.device("cuda", c.local)
+    c.cdev = torch.device("cpu") if a.rehearse_on_one_gpu else c.dev  # where the collectives' tensors live
+    if c.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=c.dev)
+    c.L = rsb.lib()
+    c.stream = torch.cuda.current_stream()
+    c.sp = C.c_void_p(c.stream.cuda_stream)
+    return c
 
-    L = rsb.lib()
-    R, Q, k, S = int(a.runs), int(a.queries), a.k, a.shards_per_gpu
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
-    ptr = lambda t: C.c_void_p(t.data_ptr())
 
-    def ok(rc):
-        if rc != 0:
-            raise RuntimeError(L.rsbwt_last_error().decode())
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
 
-    # ---- resident index: S shards per rank, each R run bytes synthesised in HBM ---------------
-    t_build0 = time.time()
+
+def ok(c, rc):
+    if rc != 0:
+        raise RuntimeError(c.L.rsbwt_last_error().decode())
+
+
+STREAM_STYLE = {"mixed": 0, "long": 1 << 63, "pop": 1 << 62}
+STREAM_NOTE = {
+    "mixed": "mixed = 20 % full units, 20 % 6..21, 60 % 1..4 symbols: 10.4 symbols per run byte",
+    "long": "long = mostly 31-symbol units of long runs: ~25 symbols per run byte",
+    "pop": "pop = the unit-length histogram measured on a valid 1.1e9-symbol population BWT (64 haplotypes, 64 suffix shards, "
+           "28x depth per shard, 1 % base errors: tools/popbwt_gpu.py, profiles/r03_popbwt_calibration.json): 5.8 symbols per run byte",
+}
+
+
+def shard_seed(a, mix, rank, S, s):
+    """population: every shard of the job holds the same stream, so that a present k-mer is present in every shard
+    (a valid popBWT holds a genomic 31-mer in 75 % of its 64 shards and keeps searching for most steps in the others:
+    profiles/r03_popbwt_calibration.json); disjoint: every shard its own stream (a present k-mer is in one shard only)."""
+    style = STREAM_STYLE[a.stream]
+    return style | (a.seed * 1000003 + (0 if mix == "population" else rank * S + s))
+
+
+def build_shards(a, c, mix, want_host_runs=False):
+    torch, L, rsb = c.torch, c.L, c.rsb
+    R, S = int(a.runs), a.shards_per_gpu
     shards, host_runs = [], None
-    style = (1 << 63) if a.stream == "long" else 0
     for s in range(S):
-        seed = style | (a.seed * 1000003 + (rank * S + (0 if a.same_shards else s)))
-        d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
-        ok(L.rsbwt_synth_runs_dev(ptr(d_runs), R, seed, local, sp))
+        d_runs = torch.empty(R, dtype=torch.uint8, device=c.dev)
+        ok(c, L.rsbwt_synth_runs_dev(ptr(d_runs), R, shard_seed(a, mix, c.rank, S, s), c.local, c.sp))
         torch.cuda.synchronize()
         # tables are sized afterwards, for all shards of the GPU together (explicit depth: now)
-        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=local,
+        g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=c.local,
                        ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span)
-        if rank == 0 and world == 1 and s == 0 and a.cpu_sample > 0:  # the CPU baseline is an N = 1 leg
+        if want_host_runs and s == 0:
             host_runs = d_runs.cpu().numpy()
         del d_runs
         torch.cuda.empty_cache()
         shards.append(g)
-    sset = rsb.ShardSet(shards)
+    return shards, rsb.ShardSet(shards), host_runs
+
+
+def size_tables(a, c, sset, shards, S):
+    """One k-mer table depth for every shard of the job, out of the HBM that is free once every buffer of the
+    job exists (rank 0's gathered results included), less an 8 GB reserve."""
+    torch, dist, L = c.torch, c.dist, c.L
+    if a.ktab_depth != 0:
+        return
+    n_sym = shards[0].getBWLen()
+    T = L.rsbwt_set_auto_ktab_depth(sset._s)
+    free_b = torch.cuda.mem_get_info(c.dev)[0]
+    if a.rehearse_on_one_gpu:  # the ranks share one GPU: each sizes its tables out of its share
+        if c.world > 1:
+            dist.barrier()  # every rank's buffers exist before anyone looks at what is free
+            free_b = torch.cuda.mem_get_info(c.dev)[0]
+        free_b //= c.world
+        while T >= 2 and S * 8 * 4 ** T > free_b // 2:
+            T -= 1
+    while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
+        T += 1
+    if c.world > 1:
+        tt = torch.tensor([T], dtype=torch.int64, device=c.cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        T = int(tt.item())
+    if T >= 2:
+        ok(c, L.rsbwt_set_attach_ktabs(sset._s, T))
+
+
+def make_batch(a, c, shards, mix, Q, k, d_kmers):
+    """The query batch, identical on every rank: uniform random k-mers with `present_frac` of them replaced by
+    k-mers drawn from the index by LF walks (all k - 1 steps in the shards that hold them)."""
+    torch, dist, L = c.torch, c.dist, c.L
+    S = len(shards)
+    gen = torch.Generator(device=c.dev)
+    gen.manual_seed(a.seed + 12345)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=c.dev)
+    for i in range(0, Q, 1 << 22):
+        j = min(Q, i + (1 << 22))
+        d_kmers[i:j] = lut[torch.randint(0, 4, (j - i, k), generator=gen, device=c.dev, dtype=torch.uint8).long()]
+    n_present = int(Q * a.present_frac)
+    if not n_present:
+        return
+    if mix == "population":  # every shard of the job is the same stream: drawn once, the same on every rank
+        mine = torch.empty((n_present, k), dtype=torch.uint8, device=c.dev)
+        ok(c, L.rsbwt_sample_present_kmers_dev(shards[0].handle, n_present, k, k, a.seed + 7, ptr(mine), c.sp))
+        torch.cuda.synchronize()
+    else:  # every rank draws its share evenly from its shards; shares are concatenated
+        share = n_present // c.world
+        if not share:
+            return
+        per = [share // S + (1 if i < share % S else 0) for i in range(S)]
+        parts = []
+        for s, m in enumerate(per):
+            if m:
+                t = torch.empty((m, k), dtype=torch.uint8, device=c.dev)
+                ok(c, L.rsbwt_sample_present_kmers_dev(shards[s].handle, m, k, k, a.seed + 7 + c.rank * S + s, ptr(t), c.sp))
+                parts.append(t)
+        torch.cuda.synchronize()
+        mine = torch.cat(parts, 0)
+        mine = mine[torch.randperm(mine.shape[0], device=c.dev, generator=gen)]  # the shards' k-mers interleaved
+        if c.world > 1:
+            mine_c = mine.to(c.cdev)
+            allp = [torch.empty_like(mine_c) for _ in range(c.world)]
+            dist.all_gather(allp, mine_c)
+            mine = torch.cat(allp, 0).to(c.dev)
+    # interleave present and random k-mers so every wave sees the mix
+    idx = torch.arange(mine.shape[0], device=c.dev) * (Q // mine.shape[0])
+    d_kmers[idx] = mine
+
+
+def run_exact(a, c, mix, steps, warmup, headline):
+    """One mix of the exact search (configs[1] / configs[2]): builds the resident shards, times `steps` batches."""
+    torch, dist, L, rsb = c.torch, c.dist, c.L, c.rsb
+    from readserver_amd import sharded
+    rank, world, local, dev, cdev, sp = c.rank, c.world, c.local, c.dev, c.cdev, c.sp
+    R, Q, k, S = int(a.runs), int(a.queries), a.k, a.shards_per_gpu
+    t_build0 = time.time()
+    want_cpu = headline and rank == 0 and world == 1 and a.cpu_sample > 0  # the CPU baseline is an N = 1 leg
+    shards, sset, host_runs = build_shards(a, c, mix, want_host_runs=want_cpu)
     n_sym = shards[0].getBWLen()
     # the batch's buffers first (rank 0 also holds the gathered intervals of all ranks), then the k-mer
     # tables out of what HBM is left: one depth for every shard of the job
     wpq = (k + 31) // 32
-    from readserver_amd import sharded
     d_packed = torch.empty((Q, wpq), dtype=torch.int64, device=dev)
     d_valid = torch.empty(Q, dtype=torch.uint8, device=dev)
     d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
@@ -223,61 +340,9 @@ def main():
     gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev)
     d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
     hold = torch.empty(int(a.hold_gb * (1 << 30)), dtype=torch.uint8, device=dev) if a.hold_gb > 0 else None
-    if a.ktab_depth == 0:
-        # The library's own rule leaves two thirds of the free HBM to a caller it knows nothing about.
-        # Here every buffer of the job already exists (rank 0's gathered intervals included), so the
-        # tables may take what is left but a reserve for the search's start records (1.4 GB), the
-        # single-shard check and RCCL's own buffers: the same depth then fits rank 0 of an 8-GPU job
-        # (13-20 GB of gathered intervals) and a lone GPU, and the scaling curve compares like with like.
-        T = L.rsbwt_set_auto_ktab_depth(sset._s)
-        free_b = torch.cuda.mem_get_info(dev)[0]
-        if a.rehearse_on_one_gpu:  # the ranks share one GPU: each sizes its tables out of its share
-            if world > 1:
-                dist.barrier()  # every rank's buffers exist before anyone looks at what is free
-                free_b = torch.cuda.mem_get_info(dev)[0]
-            free_b //= world
-            while T >= 2 and S * 8 * 4 ** T > free_b // 2:
-                T -= 1
-        while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
-            T += 1
-        if world > 1:
-            tt = torch.tensor([T], dtype=torch.int64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-            T = int(tt.item())
-        if T >= 2:
-            ok(L.rsbwt_set_attach_ktabs(sset._s, T))
+    size_tables(a, c, sset, shards, S)
     t_build = time.time() - t_build0
-
-    # ---- the query batch (identical on every rank) ----------------------------------------------
-    n_present = int(Q * a.present_frac)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(a.seed + 12345)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    for i in range(0, Q, 1 << 22):
-        j = min(Q, i + (1 << 22))
-        d_kmers[i:j] = lut[torch.randint(0, 4, (j - i, k), generator=gen, device=dev, dtype=torch.uint8).long()]
-    # present k-mers: every rank draws its share evenly from its shards; shares are concatenated
-    share = n_present // world
-    if share:
-        per = [share // S + (1 if i < share % S else 0) for i in range(S)]
-        parts = []
-        for s, m in enumerate(per):
-            if m:
-                t = torch.empty((m, k), dtype=torch.uint8, device=dev)
-                ok(L.rsbwt_sample_present_kmers_dev(shards[s].handle, m, k, k, a.seed + 7 + rank * S + s, ptr(t), sp))
-                parts.append(t)
-        torch.cuda.synchronize()
-        mine = torch.cat(parts, 0)
-        mine = mine[torch.randperm(mine.shape[0], device=dev, generator=gen)]  # the shards' k-mers interleaved
-        if world > 1:
-            mine_c = mine.to(cdev)
-            allp = [torch.empty_like(mine_c) for _ in range(world)]
-            dist.all_gather(allp, mine_c)
-            mine = torch.cat(allp, 0).to(dev)
-        # interleave present and random k-mers so every wave sees the mix
-        idx = torch.arange(mine.shape[0], device=dev) * (Q // mine.shape[0])
-        d_kmers[idx] = mine
-        del mine, idx, parts
+    make_batch(a, c, shards, mix, Q, k, d_kmers)
 
     step_no = [0]
     d_counts = None
@@ -285,6 +350,7 @@ def main():
         if world != 1 or a.separate_arrays:
             raise SystemExit("bench.py --counts: one GPU, default result layout")
         a.cpu_sample, a.no_single_check = 0, True
+        want_cpu = False
         d_counts = torch.empty((S, Q), dtype=torch.int64, device=dev)
 
     def step():
@@ -294,13 +360,13 @@ def main():
         host_pair = None
         if d_res is not None:  # rehearsal: search into HBM, gather from a host copy
             host_pair, pair = pair, d_res[i % 2]
-        ok(L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
+        ok(c, L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
         if a.counts:
-            ok(L.rsbwt_set_count_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(d_counts), sp))
+            ok(c, L.rsbwt_set_count_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(d_counts), sp))
         elif a.separate_arrays:
-            ok(L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
+            ok(c, L.rsbwt_set_find_intervals_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair[0]), ptr(pair[1]), sp))
         else:
-            ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair), sp))
+            ok(c, L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pair), sp))
         if host_pair is not None and not wire_packed:
             host_pair.copy_(pair)
         gat.submit(i, source=pair if wire_packed else None)
@@ -313,30 +379,30 @@ def main():
         torch.cuda.synchronize()
 
     # ---- exact work of one step (counting mode, untimed) -----------------------------------------
-    ok(L.rsbwt_set_set_counting(sset._s, 1))
+    ok(c, L.rsbwt_set_set_counting(sset._s, 1))
     step()
     torch.cuda.synchronize()
     w = (C.c_uint64 * 16)()
-    ok(L.rsbwt_set_last_search_counters(sset._s, w))
-    ok(L.rsbwt_set_set_counting(sset._s, 0))
+    ok(c, L.rsbwt_set_last_search_counters(sset._s, w))
+    ok(c, L.rsbwt_set_set_counting(sset._s, 0))
     lf, oc, ln, kt, hops, npass = w[0], w[1], w[2], w[3], w[11], w[10]
     phases = {"passes": npass, "cycles_per_pass": [round(w[4 + i] / max(npass, 1)) for i in range(6)],
               "names": ["setup", "issue", "wait", "rank", "exchange", "update"]}
 
     if a.counts:  # the counts of a launch against the interval pairs of the same batch
         pr = gat.pair(0)
-        ok(L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr), sp))
+        ok(c, L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr), sp))
         step()
         torch.cuda.synchronize()
         want = torch.where(pr[..., 1] >= pr[..., 0], pr[..., 1] - pr[..., 0] + 1, torch.zeros_like(pr[..., 0]))
         if not torch.equal(want, d_counts):
             raise SystemExit("bench.py --counts: counts differ from upper - lower + 1 of the same batch")
         del pr, want
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
@@ -344,7 +410,7 @@ def main():
     # launch stream around every search launch (it keeps the last 64 pairs)
     buf = (C.c_float * 64)()
     cnt = C.c_size_t()
-    ok(L.rsbwt_set_search_history_ms(sset._s, buf, min(a.steps, 64), C.byref(cnt)))
+    ok(c, L.rsbwt_set_search_history_ms(sset._s, buf, min(steps, 64), C.byref(cnt)))
     k_ms = list(buf[:cnt.value])
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -371,9 +437,9 @@ def main():
             got = gat.result(last)
             gather_verified = bool(exact.item()) and all(int(got[r].sum(dtype=torch.int64).item()) == int(sums[r].item()) for r in range(world))
 
-    searches = world * S * Q * a.steps
+    searches = world * S * Q * steps
     value = searches / dt
-    ms_per_step = dt / a.steps * 1e3
+    ms_per_step = dt / steps * 1e3
     avg_kernel_ms = float(np.mean(k_ms))
     alg_bytes = ln * LINE_BYTES + S * Q * SEARCH_BYTES  # per launch, the search kernel's own reads and writes
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
@@ -384,72 +450,47 @@ def main():
 
     # ---- configs[1] on the same resident data: shard 0 alone (same kernel, one shard) -----------
     single = None
-    if S > 1 and not a.no_single_check:
+    if headline and S > 1 and not a.no_single_check:
         g0 = shards[0]
         lo1 = torch.empty(Q, dtype=torch.int64, device=dev)
         up1 = torch.empty(Q, dtype=torch.int64, device=dev)
-        ok(L.rsbwt_set_counting(g0.handle, 1))
-        ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+        ok(c, L.rsbwt_set_counting(g0.handle, 1))
+        ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
         torch.cuda.synchronize()
         w1 = (C.c_uint64 * 16)()
-        ok(L.rsbwt_last_search_counters(g0.handle, w1))
-        ok(L.rsbwt_set_counting(g0.handle, 0))
+        ok(c, L.rsbwt_last_search_counters(g0.handle, w1))
+        ok(c, L.rsbwt_set_counting(g0.handle, 0))
         for _ in range(2):
-            ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+            ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n1 = 10
         for _ in range(n1):
-            ok(L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+            ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
         torch.cuda.synchronize()
         d1 = (time.perf_counter() - t1) / n1
         b1 = (C.c_float * 64)()
-        ok(L.rsbwt_search_history_ms(g0.handle, b1, n1, C.byref(cnt)))
+        ok(c, L.rsbwt_search_history_ms(g0.handle, b1, n1, C.byref(cnt)))
         km1 = float(np.mean(list(b1[:cnt.value])))
         single = {"searches_per_s": Q / d1, "kernel": search_kernel_name(1, int(g0.getBWLen()), g0.ktab_depth(), g0.window_span()), "kernel_ms": km1, "mean_lf_steps_per_search": w1[0] / Q,
                   "roofline_frac": (w1[2] * LINE_BYTES + Q * SEARCH_BYTES) / (km1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del lo1, up1
 
-    out = {
-        "metric": "31-mer backward-search queries/sec on popBWT",
-        "value": value,
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": a.steps,
-        "warmup": a.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {
-            "workload": ("configs[1]: single BWT shard resident in one MI355X's HBM, batched 31-mer exact backward search"
-                         if world == 1 and S == 1 else
-                         f"configs[2]: {world * S} of 64 suffix-shards over {world} GPU(s), {S} per GPU, exact match, "
-                         "one fused launch per GPU and batch" + (", RCCL gather of intervals to rank 0" if world > 1 else
-                                                                 " (one GPU: no gather)")),
-            "value_counts": "S/s = (query x shard) searches per second; Q/s = value / shards",
-            "queries_per_s_all_shards": value / (world * S),
-            "shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": R, "symbols_per_shard": int(n_sym),
-            "stream": a.stream + (", the same in every shard of a GPU" if a.same_shards else ""),
-            "queries_per_batch": Q, "k": k, "present_fraction": a.present_frac,
-            "mean_lf_steps_per_search": lf / (S * Q), "ktab_depth": shards[0].ktab_depth(),
-            "window_span": shards[0].window_span(), "far_lines_per_shard": int(shards[0].far_lines()),
-            "spilled_position_fraction": shards[0].spilled_symbols() / max(int(n_sym), 1),
-            "index_hbm_bytes_per_gpu": hbm, "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
-            "index_build_s": round(t_build, 2),
-            "gather_verified": gather_verified,
-            "gathered_as": (None if world == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact"
-                            if wire_packed else "16-byte pairs"),
-            "results": ("counts[S][Q] (rsbwt_set_count_dev: the service's count path, NOT the headline)" if a.counts else
-                        "lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
-            "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
-            "single_shard_check": single,
-        },
+    res = {
+        "mix": mix, "value": value, "queries_per_s_all_shards": value / (world * S), "ms_per_step": ms_per_step,
+        "steps": steps, "warmup": warmup,
+        "mean_lf_steps_per_search": lf / (S * Q), "lines_per_lf_step": ln / max(lf, 1),
+        "ktab_depth": shards[0].ktab_depth(), "window_span": shards[0].window_span(),
+        "symbols_per_shard": int(n_sym), "far_lines_per_shard": int(shards[0].far_lines()),
+        "spilled_position_fraction": shards[0].spilled_symbols() / max(int(n_sym), 1),
+        "index_hbm_bytes_per_gpu": hbm,
+        "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
+        "index_build_s": round(t_build, 2), "gather_verified": gather_verified, "wire_packed": wire_packed,
+        "single_shard_check": single,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(R, Q, S, k, a.stream),
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": _pmc_traffic(R, Q, S, k, a.stream, mix) if headline else None,
             "kernel": search_kernel_name(S, int(n_sym), shards[0].ktab_depth(), shards[0].window_span()), "kernel_ms": avg_kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "line_reads_per_launch": ln,
             "continuation_line_reads_per_launch": hops, "occ_lookups_per_launch": oc,
@@ -457,26 +498,317 @@ def main():
             "frac_of_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
     }
-
-    if rank == 0 and host_runs is not None:
+    if want_cpu and host_runs is not None:
         pair = gat.pair(step_no[0] - 1).to(dev)
         lo0, up0 = (pair[0][0], pair[1][0]) if a.separate_arrays else (pair[0, :, 0], pair[0, :, 1])
-        out["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, lo0, up0, Q, k)
-    elif rank == 0:
-        out["cpu_baseline"] = None  # timed at N = 1 only (or switched off with --cpu-sample 0)
-    if rank == 0 and a.verify_all_shards:
-        out["config"]["shards_matching_oracle"] = verify_shards(a, L, gat.pair(step_no[0] - 1).to(dev), d_kmers, S, R, Q, k, style,
-                                                              rank, local, dev, sp)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        res["cpu_baseline"] = cpu_baseline(a, host_runs, d_kmers, lo0, up0, Q, k)
+    else:
+        res["cpu_baseline"] = None  # timed at N = 1 only (or switched off with --cpu-sample 0)
+    if headline and rank == 0 and a.verify_all_shards:
+        res["shards_matching_oracle"] = verify_shards(a, L, gat.pair(step_no[0] - 1).to(dev), d_kmers, S, R, Q, k, mix,
+                                                      rank, local, dev, sp)
     sset.close()
     for g in shards:
         g.close()
-    if world > 1:
-        dist.destroy_process_group()
+    del shards, sset, gat, d_res, d_kmers, d_packed, d_valid, hold, d_counts
+    torch.cuda.empty_cache()
+    return res
 
 
-def _pmc_traffic(R, Q, S, k, stream):
+MIX_NOTE = {
+    "population": "every shard of the job holds the same stream, so a 31-mer drawn from the index is present in EVERY shard and "
+                  "runs all its steps there (a valid 64-shard popBWT holds a genomic 31-mer in 75 % of its shards, final interval "
+                  "~8 rows, and the searches that end empty still run most of their steps: profiles/r03_popbwt_calibration.json)",
+    "disjoint": "every shard its own stream: a 31-mer drawn from the index is present in ONE shard and dies within a few steps "
+                "of the k-mer table in the others (round 2's default; flatters S/s by ~2x)",
+}
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a, sys.argv[1:])
+    c = setup(a)
+    if a.mode != "exact":
+        out = run_rows(a, c)
+    else:
+        S, world = a.shards_per_gpu, c.world
+        head = run_exact(a, c, a.mix, a.steps, a.warmup, headline=True)
+        mixes = {a.mix: {k: head[k] for k in ("value", "queries_per_s_all_shards", "ms_per_step", "mean_lf_steps_per_search",
+                                                 "lines_per_lf_step", "ktab_depth")} | {"roofline_frac": head["roofline"]["frac"],
+                                                                                        "kernel_ms": head["roofline"]["kernel_ms"], "what": MIX_NOTE[a.mix]}}
+        other = "disjoint" if a.mix == "population" else "population"
+        if world == 1 and not a.no_second_mix and not a.counts and S > 1:
+            o = run_exact(a, c, other, max(3, a.steps // 2), 1, headline=False)
+            mixes[other] = {k: o[k] for k in ("value", "queries_per_s_all_shards", "ms_per_step", "mean_lf_steps_per_search",
+                                              "lines_per_lf_step", "ktab_depth")} | {"roofline_frac": o["roofline"]["frac"],
+                                                                                     "kernel_ms": o["roofline"]["kernel_ms"], "what": MIX_NOTE[other]}
+        out = {
+            "metric": "31-mer backward-search queries/sec on popBWT",
+            "value": head["value"],
+            "unit": "searches/s",
+            "queries_per_s": head["queries_per_s_all_shards"],
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]: single BWT shard resident in one MI355X's HBM, batched 31-mer exact backward search"
+                             if world == 1 and S == 1 else
+                             f"configs[2]: {world * S} of 64 suffix-shards over {world} GPU(s), {S} per GPU, exact match, "
+                             "one fused launch per GPU and batch" + (", RCCL gather of intervals to rank 0" if world > 1 else
+                                                                     " (one GPU: no gather)")),
+                "value_counts": "value = searches/s = (query x shard) backward searches per second (one findInterval each); "
+                                "queries_per_s = value / shards = queries resolved against every resident shard",
+                "queries_per_s_all_shards": head["queries_per_s_all_shards"],
+                "mix": a.mix + ": " + MIX_NOTE[a.mix],
+                "mixes": mixes,
+                "shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": int(a.runs), "symbols_per_shard": head["symbols_per_shard"],
+                "stream": STREAM_NOTE[a.stream],
+                "queries_per_batch": int(a.queries), "k": a.k, "present_fraction": a.present_frac,
+                "mean_lf_steps_per_search": head["mean_lf_steps_per_search"], "lines_per_lf_step": head["lines_per_lf_step"],
+                "ktab_depth": head["ktab_depth"],
+                "window_span": head["window_span"], "far_lines_per_shard": head["far_lines_per_shard"],
+                "spilled_position_fraction": head["spilled_position_fraction"],
+                "index_hbm_bytes_per_gpu": head["index_hbm_bytes_per_gpu"], "index_bytes_per_run_byte": head["index_bytes_per_run_byte"],
+                "index_build_s": head["index_build_s"],
+                "gather_verified": head["gather_verified"],
+                "gathered_as": (None if world == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact"
+                                if head["wire_packed"] else "16-byte pairs"),
+                "results": ("counts[S][Q] (rsbwt_set_count_dev: the service's count path, NOT the headline)" if a.counts else
+                            "lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
+                "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
+                "single_shard_check": head["single_shard_check"],
+            },
+            "roofline": head["roofline"],
+            "cpu_baseline": head["cpu_baseline"],
+        }
+        if "shards_matching_oracle" in head:
+            out["config"]["shards_matching_oracle"] = head["shards_matching_oracle"]
+    if c.rank == 0:
+        print(json.dumps(out), flush=True)
+    if c.world > 1:
+        c.dist.destroy_process_group()
+
+
+def run_rows(a, c):
+    """--mode 1mm (configs[3]) and --mode extract (configs[4]) over the shards of every GPU of the job: what
+    each rank's shards give is gathered on rank 0 and laid side by side in global shard order, the way the
+    reference's front-end concatenates its partitions' replies (src/service/server.cpp:199-261)."""
+    torch, dist, L, rsb = c.torch, c.dist, c.L, c.rsb
+    from readserver_amd import sharded
+    rank, world, local, dev, cdev, sp = c.rank, c.world, c.local, c.dev, c.cdev, c.sp
+    R, k, S = int(a.runs), a.k, a.shards_per_gpu
+    mix = a.mix
+    t0 = time.time()
+    shards, sset, _ = build_shards(a, c, mix)
+    n_sym = min(int(g.getBWLen()) for g in shards)
+    if a.mode == "extract":  # the select samples of every shard first (built by a shard's first extraction)
+        one = torch.zeros(1, dtype=torch.int64, device=dev)
+        o1 = torch.empty((1, 512), dtype=torch.uint8, device=dev)
+        l1 = torch.empty(2, dtype=torch.int32, device=dev)
+        for h in shards:
+            ok(c, L.rsbwt_extract_dev(h.handle, ptr(one), 1, ptr(o1), 512, ptr(l1), ptr(l1[1:]), sp))
+        torch.cuda.synchronize()
+    size_tables(a, c, sset, shards, S)
+    t_build = time.time() - t0
+    common = {"shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": R, "symbols_per_shard": n_sym,
+              "stream": STREAM_NOTE[a.stream], "mix": mix + ": " + MIX_NOTE[mix], "k": k, "ktab_depth": shards[0].ktab_depth(),
+              "window_span": shards[0].window_span(), "index_build_s": round(t_build, 2),
+              "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU")}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
+
+    if a.mode == "1mm":
+        M, V = int(a.kmers), 3 * k + 1
+        d_km = torch.empty((M, k), dtype=torch.uint8, device=dev)
+        make_batch(a, c, shards, mix, M, k, d_km)
+        d_pk = torch.empty(M, dtype=torch.int64, device=dev)
+        d_ok = torch.empty(M, dtype=torch.uint8, device=dev)
+        cap = 4 * M  # records per shard: a present 31-mer leaves itself and the odd variant
+        d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(sset._s, M, k), dtype=torch.uint8, device=dev)
+        # what travels at N > 1: every rank's [S][cap] record buffers and [S] counts (fixed size, so the gather is one
+        # collective issued behind the next batch's search); rank 0 lays the lists out in global shard order
+        gat_h = sharded.BlockGatherer((S, cap, 4), torch.int64, cdev, depth=2)
+        gat_t = sharded.BlockGatherer((S,), torch.int64, cdev, depth=2)
+        d_h = [torch.empty((S, cap, 4), dtype=torch.int64, device=dev) for _ in range(2)] if cdev != dev else None
+        d_t = [torch.empty(S, dtype=torch.int64, device=dev) for _ in range(2)] if cdev != dev else None
+        step_no = [0]
+
+        def step():
+            i = step_no[0]
+            step_no[0] += 1
+            hb, tb = gat_h.acquire(i), gat_t.acquire(i)
+            h_dev, t_dev = (d_h[i % 2], d_t[i % 2]) if d_h is not None else (hb, tb)
+            ok(c, L.rsbwt_pack_kmers_dev(ptr(d_km), M, k, k, ptr(d_pk), ptr(d_ok), local, sp))
+            ok(c, L.rsbwt_set_hits_1mm_dev(sset._s, ptr(d_pk), ptr(d_ok), M, k, ptr(h_dev), cap, ptr(t_dev), ptr(d_scr), sp))
+            if d_h is not None:
+                hb.copy_(h_dev)
+                tb.copy_(t_dev)
+            gat_h.submit(i)
+            gat_t.submit(i)
+
+        for h in shards:
+            ok(c, L.rsbwt_set_counting(h.handle, 1))
+        step()
+        torch.cuda.synchronize()
+        w = [0] * 16
+        for h in shards:
+            wi = (C.c_uint64 * 16)()
+            ok(c, L.rsbwt_last_search_counters(h.handle, wi))  # the resumed search of the variants, per shard
+            ok(c, L.rsbwt_set_counting(h.handle, 0))
+            w = [x + int(y) for x, y in zip(w, wi)]
+        for _ in range(a.warmup):
+            step()
+        gat_h.drain(); gat_t.drain(); barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        gat_h.drain(); gat_t.drain(); barrier()
+        dt = max_over_ranks(time.perf_counter() - t1)
+        kms = 0.0
+        for h in shards:  # traced + resumed search kernels of the timed calls
+            buf = (C.c_float * 64)()
+            cnt = C.c_size_t()
+            ok(c, L.rsbwt_search_history_ms(h.handle, buf, min(64, 2 * a.steps), C.byref(cnt)))
+            kms += sum(buf[:cnt.value]) / max(cnt.value / 2, 1)
+        last = step_no[0] - 1
+        tot_local = (d_t[last % 2] if d_t is not None else gat_t.result(last)[0] if world == 1 else gat_t.acquire(last)).clone()
+        hits_local = int(tot_local.sum().item())
+        verified = None
+        if world > 1:  # rank 0: the lists side by side in global shard order; every rank's checksum must be in it
+            sent_h = gat_h.acquire(last)
+            mine = torch.stack([sent_h.sum(dtype=torch.int64), tot_local.to(cdev).sum()]).to(cdev)
+            sums = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(sums, mine)
+            if rank == 0:
+                blocks, totals = gat_h.result(last), gat_t.result(last)
+                rec, first = sharded.concat_hit_lists(blocks, [t.cpu() for t in totals])
+                verified = (all(int(blocks[r].sum(dtype=torch.int64).item()) == int(sums[r][0].item()) for r in range(world))
+                            and int(first[-1]) == sum(int(x[1].item()) for x in sums) and rec.shape[0] == int(first[-1]))
+        alg = w[2] * LINE_BYTES + S * M * V * 24 + hits_local * 48
+        out = {
+            "metric": "31-mer 1-mismatch backward searches/sec on popBWT (BASELINE configs[3])",
+            "value": world * S * M / (dt / a.steps), "unit": "(31-mer x shard) 1-mismatch searches/s",
+            "kmers_per_s_all_shards": M / (dt / a.steps), "variant_searches_per_s": world * S * M * V / (dt / a.steps),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": dict(common, workload=f"configs[3]: 1-mismatch branching search of {M} 31-mers in each of {world * S} shards "
+                           f"({S} per GPU), {V} variants per 31-mer resumed from the k-mer's traced search; output = every shard's "
+                           "ordered hit list" + (", gathered on rank 0 and concatenated in shard order" if world > 1 else ""),
+                           kmers_per_batch=M, variants_per_kmer=V, hits_per_batch_this_rank=hits_local,
+                           lf_steps_per_variant=w[0] / (S * M * V), hit_lists_verified=verified,
+                           travels=(None if world == 1 else f"[{S}][{cap}] 32-byte records + {S} counts per rank and batch")),
+            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "search_lines_kernel (the k-mers traced, their variants resumed), summed over the rank's shards",
+                         "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": w[2]},
+            "cpu_baseline": None,
+        }
+    else:
+        NR, stride, run = int(a.rows), a.stride, max(1, a.row_run)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(a.seed + 99)
+        # rows as the reference extracts them: the rows of intervals (query.cpp:94-96 walks lower..upper), here runs
+        # of `run` consecutive SA rows at random places of every shard
+        starts = torch.randint(0, max(n_sym - run, 1), (S, (NR + run - 1) // run), generator=gen, device=dev, dtype=torch.int64)
+        rows = (starts[:, :, None] + torch.arange(run, device=dev)[None, None, :]).reshape(S, -1)[:, :NR].contiguous()
+        gat_o = sharded.BlockGatherer((S, NR, stride), torch.uint8, cdev, depth=2)
+        gat_l = sharded.BlockGatherer((S, NR), torch.int32, cdev, depth=2)
+        d_o = [torch.empty((S, NR, stride), dtype=torch.uint8, device=dev) for _ in range(2)] if cdev != dev else None
+        d_l = [torch.empty((S, NR), dtype=torch.int32, device=dev) for _ in range(2)] if cdev != dev else None
+        d_pl = torch.empty((S, NR), dtype=torch.int32, device=dev)
+        step_no = [0]
+
+        def step():
+            i = step_no[0]
+            step_no[0] += 1
+            ob, lb = gat_o.acquire(i), gat_l.acquire(i)
+            o_dev, l_dev = (d_o[i % 2], d_l[i % 2]) if d_o is not None else (ob, lb)
+            ok(c, L.rsbwt_set_extract_dev(sset._s, ptr(rows), NR, ptr(o_dev), stride, ptr(l_dev), ptr(d_pl), sp))
+            if d_o is not None:
+                ob.copy_(o_dev)
+                lb.copy_(l_dev)
+            gat_o.submit(i)
+            gat_l.submit(i)
+
+        ok(c, L.rsbwt_set_counting(shards[0].handle, 1))
+        step()
+        torch.cuda.synchronize()
+        xw = (C.c_uint64 * 16)()
+        ok(c, L.rsbwt_last_search_counters(shards[0].handle, xw))  # the walk kernels' counters of the last shard that ran with counting on
+        ok(c, L.rsbwt_set_counting(shards[0].handle, 0))
+        names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "wrong_first_window"]
+        walk = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
+        lens0 = (d_l[0] if d_l is not None else gat_l.acquire(0)).to(dev).reshape(-1)
+        ln = lens0.cpu().numpy().view(np.uint32)
+        fits = ln != 0xFFFFFFFF
+        bases = int(ln[fits].astype(np.int64).sum())
+        # one line per symbol and the two '$' steps of every read that fits; walks cut at the buffer's end took `stride` steps
+        steps_alg = bases + 2 * int(fits.sum()) + int((~fits).sum()) * stride
+        for _ in range(a.warmup):
+            step()
+        gat_o.drain(); gat_l.drain(); barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        ev0.record()
+        for _ in range(a.steps):
+            step()
+        ev1.record()
+        gat_o.drain(); gat_l.drain(); barrier()
+        dt = max_over_ranks(time.perf_counter() - t1)
+        k_ms = ev0.elapsed_time(ev1) / a.steps  # the walk kernels of one batch (current stream; the gather runs beside them)
+        verified = None
+        if world > 1:
+            last = step_no[0] - 1
+            mine = torch.stack([gat_o.acquire(last).sum(dtype=torch.int64), gat_l.acquire(last).sum(dtype=torch.int64)]).to(cdev)
+            sums = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(sums, mine)
+            if rank == 0:
+                reads_all, lens_all = sharded.concat_reads(gat_o.result(last), gat_l.result(last))
+                verified = (reads_all.shape[0] == world * S and int(reads_all.sum(dtype=torch.int64).item()) == sum(int(x[0].item()) for x in sums)
+                            and int(lens_all.sum(dtype=torch.int64).item()) == sum(int(x[1].item()) for x in sums))
+        out = {
+            "metric": "reads located and extracted per second on popBWT (BASELINE configs[4])",
+            "value": world * S * NR / (dt / a.steps), "unit": "reads/s",
+            "bases_per_s": world * bases / (dt / a.steps),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": dict(common, workload=f"configs[4]: extractPrefix + extractPostfix (query.cpp:43-85) of {NR} SA rows of each of "
+                           f"{world * S} shards ({S} per GPU), rows in runs of {run} consecutive rows (the rows of an interval)"
+                           + (", reads gathered on rank 0 and concatenated in shard order" if world > 1 else ""),
+                           rows_per_shard=NR, row_run=run, stride=stride, rows_fitting_stride=int(fits.sum()) / max(ln.size, 1),
+                           mean_read_length=bases / max(int(fits.sum()), 1), reads_verified=verified, walk_counters_one_shard=walk,
+                           travels=(None if world == 1 else f"[{S}][{NR}][{stride}] read bytes + lengths per rank and batch")),
+            "roofline": {"bound": "hbm", "achieved": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel, over the rank's shards",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": steps_alg * LINE_BYTES, "lf_and_psi_steps": steps_alg},
+            "cpu_baseline": None,
+        }
+    sset.close()
+    for g in shards:
+        g.close()
+    return out
+
+
+def _pmc_traffic(R, Q, S, k, stream, mix):
     """HBM bytes per search launch from the committed rocprofv3 PMC pass of this same command
     (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes) -- only if that pass
     was measured on this very kernel and layout source; otherwise None."""
@@ -485,14 +817,14 @@ def _pmc_traffic(R, Q, S, k, stream):
         d = json.load(open(p))
         if (d["kernel_source_sha"] == kernel_source_sha() and int(d["run_bytes_per_shard"]) == R
                 and int(d["queries_per_batch"]) == Q and int(d["shards_per_gpu"]) == S and int(d["k"]) == k
-                and d.get("stream", "mixed") == stream):
+                and d.get("stream", "mixed") == stream and d.get("mix", "disjoint") == mix):
             return d["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
 
 
-def verify_shards(a, L, pair, d_kmers, S, R, Q, k, style, rank, local, dev, sp):
+def verify_shards(a, L, pair, d_kmers, S, R, Q, k, mix, rank, local, dev, sp):
     """Every resident shard against the oracle: [true/false per shard] on 1e5 evenly spaced k-mers."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
@@ -504,7 +836,7 @@ def verify_shards(a, L, pair, d_kmers, S, R, Q, k, style, rank, local, dev, sp):
     km = d_kmers[sel_t].cpu().numpy()
     res = []
     for s in range(S):
-        seed = style | (a.seed * 1000003 + (rank * S + (0 if a.same_shards else s)))
+        seed = shard_seed(a, mix, rank, S, s)
         d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
         assert L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, seed, local, sp) == 0
         torch.cuda.synchronize()

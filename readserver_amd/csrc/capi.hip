@@ -1346,8 +1346,10 @@ int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count) {
 
 int meter_work(search_meter &m, uint64_t *words, size_t nwords) {
     std::lock_guard<std::mutex> lock(m.mu);
-    if (!m.launches) return fail(RSBWT_EINVAL, "no search has been launched through this handle");
-    HIP_OK(hipEventSynchronize(m.ev_stop[(m.launches - 1) % search_meter::RING]));
+    // (the walk kernels of an extraction leave their counters here too, without a search launch: the copy
+    // below runs on the null stream, which waits for whatever the caller's streams have enqueued)
+    if (m.launches) HIP_OK(hipEventSynchronize(m.ev_stop[(m.launches - 1) % search_meter::RING]));
+    else HIP_OK(hipDeviceSynchronize());
     unsigned long long w[WORK_WORDS];
     HIP_OK(hipMemcpy(w, m.d_work, sizeof w, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nwords && i < (size_t)WORK_WORDS; ++i) words[i] = w[i];

@@ -204,3 +204,68 @@ class IntervalGatherer:
     def unpack_block(self, block):
         """One gathered 10-byte block back into [S_local, Q, 2] pairs."""
         return unpack_pairs(block, self.n_pairs).reshape(self._pairs[0].shape)
+
+
+class BlockGatherer:
+    """Fixed-size blocks of every rank gathered on rank `dst`, pipelined behind the next batch's work: the same
+    double-buffered, asynchronous dist.gather as IntervalGatherer, for any shape and dtype (the reads of an
+    extraction batch, the hit-list buffers of a 1-mismatch batch with their counts)."""
+
+    def __init__(self, shape, dtype, device, depth=2, dst=0, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dst, self.group, self.depth = dst, group, depth
+        self._mine = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self._out = None
+        if self.world > 1 and self.rank == dst:
+            self._out = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)] for _ in range(depth)]
+        self._work = [None] * depth
+
+    def acquire(self, i):
+        """The buffer batch i is written into; waits for the gather that last used it."""
+        j = i % self.depth
+        if self._work[j] is not None:
+            self._work[j].wait()
+            self._work[j] = None
+        return self._mine[j]
+
+    def submit(self, i):
+        if self.world == 1:
+            return
+        j = i % self.depth
+        self._work[j] = dist.gather(self._mine[j], self._out[j] if self.rank == self.dst else None, dst=self.dst,
+                                    group=self.group, async_op=True)
+
+    def drain(self):
+        for j, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[j] = None
+
+    def result(self, i):
+        """Rank dst: the `world` blocks of batch i, rank by rank."""
+        if self.world == 1:
+            return [self._mine[i % self.depth]]
+        return self._out[i % self.depth] if self.rank == self.dst else None
+
+
+def concat_hit_lists(blocks, totals):
+    """What the front-end does with its partitions' read lists (src/service/server.cpp:199-261), for 1-mismatch
+    hit lists: blocks[r] = rank r's [S_local, cap, W] record buffers, totals[r] = its [S_local] counts.  Returns
+    (records [sum, W], first [world * S_local + 1]): global shard g = r * S_local + s owns first[g]:first[g+1]."""
+    parts, first = [], [0]
+    for blk, tot in zip(blocks, totals):
+        for s in range(blk.shape[0]):
+            n = int(tot[s])
+            if n > blk.shape[1]:
+                raise ValueError(f"a shard left {n} hits in a buffer of {blk.shape[1]}")
+            parts.append(blk[s, :n])
+            first.append(first[-1] + n)
+    rec = torch.cat(parts, 0) if parts else torch.empty((0,))
+    return rec, torch.tensor(first, dtype=torch.int64)
+
+
+def concat_reads(blocks, lens):
+    """Reads of every rank's shards side by side: blocks[r] = [S_local, n, stride] uint8, lens[r] = [S_local, n];
+    returns ([world * S_local, n, stride], [world * S_local, n]) in global shard order."""
+    return torch.cat(list(blocks), 0), torch.cat(list(lens), 0)

@@ -188,3 +188,80 @@ def test_pack_pairs_check_refuses_what_the_record_cannot_carry():
         with pytest.raises(ValueError):
             sharded.pack_pairs(t, check=True)
         sharded.pack_pairs(t)  # unchecked: truncates, as documented
+
+
+def _concat_worker(rank, world, port, q):
+    """configs[3] / configs[4] at N > 1: what every rank's shards give is gathered on rank 0 (fixed-size blocks,
+    pipelined like the interval gather) and laid side by side in global shard order."""
+    import torch
+    import torch.distributed as dist
+    from readserver_amd import sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, cap, n, stride = 3, 50, 7, 16
+        gh = sharded.BlockGatherer((S, cap, 4), torch.int64, torch.device("cpu"), depth=2)
+        gt = sharded.BlockGatherer((S,), torch.int64, torch.device("cpu"), depth=2)
+        go = sharded.BlockGatherer((S, n, stride), torch.uint8, torch.device("cpu"), depth=2)
+        gl = sharded.BlockGatherer((S, n), torch.int32, torch.device("cpu"), depth=2)
+        ok = True
+        for i in range(5):  # more batches than buffers: acquire waits for the gather that used the buffer
+            hb, tb, ob, lb = gh.acquire(i), gt.acquire(i), go.acquire(i), gl.acquire(i)
+            hb.zero_()
+            for s in range(S):
+                cnt = (7 * rank + 3 * s + i) % cap
+                tb[s] = cnt
+                # record j of global shard g in batch i: {lower, upper, index, 0}
+                g = rank * S + s
+                hb[s, :cnt, 0] = 1000 * g + torch.arange(cnt) + i
+                hb[s, :cnt, 1] = hb[s, :cnt, 0] + 5
+                hb[s, :cnt, 2] = torch.arange(cnt)
+            ob.copy_(((torch.arange(S * n * stride).reshape(S, n, stride) + 31 * rank + i) % 251).to(torch.uint8))
+            lb.copy_(((torch.arange(S * n).reshape(S, n) + rank + i) % stride).to(torch.int32))
+            for gg in (gh, gt, go, gl):
+                gg.submit(i)
+            if i >= 1 and rank == 0:  # batch i - 1 has been waited for by nobody yet: drain, then look at it
+                pass
+        for gg in (gh, gt, go, gl):
+            gg.drain()
+        if rank == 0:
+            i = 4
+            rec, first = sharded.concat_hit_lists(gh.result(i), gt.result(i))
+            assert first.numel() == world * S + 1 and int(first[-1]) == rec.shape[0]
+            for r in range(world):
+                for s in range(S):
+                    g = r * S + s
+                    cnt = (7 * r + 3 * s + i) % cap
+                    blk = rec[int(first[g]):int(first[g + 1])]
+                    ok &= blk.shape[0] == cnt and bool((blk[:, 0] == 1000 * g + torch.arange(cnt) + i).all())
+                    ok &= bool((blk[:, 1] == blk[:, 0] + 5).all()) and bool((blk[:, 2] == torch.arange(cnt)).all())
+            reads, lens = sharded.concat_reads(go.result(i), gl.result(i))
+            ok &= tuple(reads.shape) == (world * S, n, stride) and tuple(lens.shape) == (world * S, n)
+            for r in range(world):
+                want = ((torch.arange(S * n * stride).reshape(S, n, stride) + 31 * r + i) % 251).to(torch.uint8)
+                ok &= bool(torch.equal(reads[r * S:(r + 1) * S], want))
+                ok &= bool(torch.equal(lens[r * S:(r + 1) * S], ((torch.arange(S * n).reshape(S, n) + r + i) % stride).to(torch.int32)))
+            try:
+                bad = [t.clone() for t in gt.result(i)]
+                bad[1][0] = cap + 1
+                sharded.concat_hit_lists(gh.result(i), bad)
+                ok = False
+            except ValueError:
+                pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_hit_lists_and_reads_are_concatenated_in_shard_order():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + 11) % 2000
+    procs = [ctx.Process(target=_concat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
