@@ -58,6 +58,9 @@ def parse():
                          "A one-GPU run measures the other mix too (config.mixes) unless --no-second-mix")
     ap.add_argument("--same-shards", action="store_true", help="(old name of --mix population)")
     ap.add_argument("--no-second-mix", action="store_true", help="time only --mix (profile passes)")
+    ap.add_argument("--piped-start", action="store_true",
+                    help="prepare batch i + 1 (packing, start records) on a second stream while batch i is searched, instead of "
+                         "pack, start records and search one after the other on one stream (measured slower on the headline mix)")
     ap.add_argument("--stream", choices=["mixed", "long", "pop"], default="pop",
                     help="run-length mix of the synthetic stream: pop = the unit-length histogram measured on a valid population "
                          "BWT (5.8 symbols per unit; tools/popbwt_gpu.py); mixed = ~10.4 symbols per unit; long = mostly "
@@ -340,12 +343,41 @@ def run_exact(a, c, mix, steps, warmup, headline):
     gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev)
     d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
     hold = torch.empty(int(a.hold_gb * (1 << 30)), dtype=torch.uint8, device=dev) if a.hold_gb > 0 else None
+    # --piped-start: a batch's packing and start records (they depend on the k-mers and the k-mer tables only) are
+    # computed on a second stream while the previous batch is searched, so a step of the main stream is the search
+    # kernel alone.  Measured (profiles/r03_piped_start.json): the search kernel is at the memory system's request
+    # ceiling, the start-record kernel beside it takes requests from it and the pair runs LONGER than one after the
+    # other on the population mix (24.3 vs 23.2 ms per step), a little shorter on the disjoint mix (12.0 vs 12.4):
+    # the default stays one stream.
+    piped = a.piped_start and not (a.counts or a.separate_arrays)
+    if piped:
+        side = torch.cuda.Stream(device=dev, priority=0)  # (the lowest priority there is; the search's stream is the default one)
+        side_p = C.c_void_p(side.cuda_stream)
+        d_packed2 = [d_packed, torch.empty_like(d_packed)]
+        d_valid2 = [d_valid, torch.empty_like(d_valid)]
+        d_rec2 = [torch.empty(L.rsbwt_set_records_bytes(sset._s, Q), dtype=torch.uint8, device=dev) for _ in range(2)]
+        prep_done = [torch.cuda.Event(), torch.cuda.Event()]
+        searched = [torch.cuda.Event(), torch.cuda.Event()]
+        prepared_for = [None, None]
     size_tables(a, c, sset, shards, S)
     t_build = time.time() - t_build0
     make_batch(a, c, shards, mix, Q, k, d_kmers)
+    torch.cuda.synchronize()
 
     step_no = [0]
     d_counts = None
+
+    def prepare(i):  # batch i's packed k-mers and start records, on the side stream
+        j = i % 2
+        if prepared_for[j] == i:
+            return
+        with torch.cuda.stream(side):
+            if i >= 2:
+                side.wait_event(searched[j])  # the search of batch i - 2 read these buffers
+            ok(c, L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed2[j]), ptr(d_valid2[j]), local, side_p))
+            ok(c, L.rsbwt_set_prepare_dev(sset._s, ptr(d_packed2[j]), ptr(d_valid2[j]), Q, k, ptr(d_rec2[j]), side_p))
+            prep_done[j].record(side)
+        prepared_for[j] = i
     if a.counts:
         if world != 1 or a.separate_arrays:
             raise SystemExit("bench.py --counts: one GPU, default result layout")
@@ -360,6 +392,18 @@ def run_exact(a, c, mix, steps, warmup, headline):
         host_pair = None
         if d_res is not None:  # rehearsal: search into HBM, gather from a host copy
             host_pair, pair = pair, d_res[i % 2]
+        if piped:
+            j = i % 2
+            prepare(i)  # (only the very first batch of a sequence is not prepared yet)
+            c.stream.wait_event(prep_done[j])
+            ok(c, L.rsbwt_set_find_interval_pairs_prepared_dev(sset._s, ptr(d_packed2[j]), ptr(d_valid2[j]), ptr(d_rec2[j]), Q, k,
+                                                               ptr(pair), sp))
+            searched[j].record(c.stream)
+            prepare(i + 1)
+            if host_pair is not None and not wire_packed:
+                host_pair.copy_(pair)
+            gat.submit(i, source=pair if wire_packed else None)
+            return
         ok(c, L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
         if a.counts:
             ok(c, L.rsbwt_set_count_dev(sset._s, ptr(d_packed), ptr(d_valid), Q, k, ptr(d_counts), sp))
@@ -487,6 +531,9 @@ def run_exact(a, c, mix, steps, warmup, headline):
         "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
         "index_build_s": round(t_build, 2), "gather_verified": gather_verified, "wire_packed": wire_packed,
         "single_shard_check": single,
+        "step": ("search kernel on the main stream; the next batch's packing and start records on a second stream beside it "
+                 "(rsbwt_set_prepare_dev / rsbwt_set_find_interval_pairs_prepared_dev)" if piped else
+                 "pack + start records + search, one after the other on one stream"),
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
@@ -511,6 +558,8 @@ def run_exact(a, c, mix, steps, warmup, headline):
     for g in shards:
         g.close()
     del shards, sset, gat, d_res, d_kmers, d_packed, d_valid, hold, d_counts
+    if piped:
+        del d_packed2, d_valid2, d_rec2
     torch.cuda.empty_cache()
     return res
 
@@ -584,6 +633,7 @@ def main():
                             "lower[S][Q], upper[S][Q]" if a.separate_arrays else "{lower, upper}[S][Q] pairs (BWTInterval)"),
                 "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU; the N > 1 gather path is covered by the gloo world-2 test only"),
                 "single_shard_check": head["single_shard_check"],
+                "step": head["step"],
             },
             "roofline": head["roofline"],
             "cpu_baseline": head["cpu_baseline"],

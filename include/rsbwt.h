@@ -305,6 +305,16 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
 /* 1-mismatch search (SURVEY 8 f3 / BASELINE configs[3]) of m packed k-mers in every shard of a one-device
  * set: d_lower/d_upper [num_shards][m][3k+1]; d_scratch: rsbwt_set_1mm_scratch_bytes(s, m, k) bytes, shared
  * by the shards' searches, which run one after the other on `stream`. */
+/* The pair search in two halves, for a pipelined caller: the start records of a batch ([num_shards][Q] x 16 B =
+ * rsbwt_set_records_bytes) depend on its k-mers and the k-mer tables only, so batch i + 1's can be computed on a
+ * second stream (rsbwt_set_prepare_dev) while batch i is searched; the caller orders the two (an event) and
+ * rsbwt_set_find_interval_pairs_prepared_dev then runs the search kernel alone.  Same answers as
+ * rsbwt_set_find_interval_pairs_dev (initInterval / the k-mer table: src/bwt/query.cpp:18-21). */
+size_t rsbwt_set_records_bytes(const rsbwt_set_t *s, size_t Q);
+int rsbwt_set_prepare_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_records,
+                          void *stream);
+int rsbwt_set_find_interval_pairs_prepared_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, const void *d_records,
+                                               size_t Q, uint32_t k, void *d_pairs, void *stream);
 size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k);
 int rsbwt_set_find_intervals_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k,
                                      void *d_lower, void *d_upper, void *d_scratch, void *stream);

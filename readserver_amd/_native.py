@@ -145,6 +145,9 @@ SIGNATURES = {
     "rsbwt_set_hits_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),
     "rsbwt_set_hits_1mm_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp, _vp, _vp]),
     "rsbwt_set_extract_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "rsbwt_set_records_bytes": (C.c_size_t, [_vp, C.c_size_t]),
+    "rsbwt_set_prepare_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "rsbwt_set_find_interval_pairs_prepared_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "rsbwt_rccl_available": (C.c_int, []),
     "rsbwt_set_set_counting": (C.c_int, [_vp, C.c_int]),
     "rsbwt_set_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -68,7 +68,13 @@ struct search_extra {
     // the k-mer table leaves intervals well inside a window (n / 4^T << S): most steps of a search find
     // both positions in one line, which is what the one-lane-per-search kernel is for (search_solo.h)
     bool narrow = false;
+    // start records computed ahead (launch_search_init, on any stream the caller orders before this launch):
+    // [nshards][Q] x 16 B in the caller's HBM; the launch then takes no scratch and runs no start-record kernel
+    const void *d_init = nullptr;
 };
+// the start-record kernel alone: d_init[s * Q + q] for every (query, shard) search of a batch
+hipError_t launch_search_init(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t Q,
+                              uint32_t k, void *d_init, hipStream_t stream);
 hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                          const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,

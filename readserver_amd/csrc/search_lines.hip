@@ -583,6 +583,16 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
                            pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
 }
 
+hipError_t launch_search_init(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t Q,
+                              uint32_t k, void *d_init, hipStream_t stream) {
+    if (Q == 0 || nshards == 0) return hipSuccess;
+    const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
+    const size_t nrec = Q * nshards;
+    hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, d_shards, nshards,
+                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, Q, k, wpq, (ulonglong2 *)d_init);
+    return hipGetLastError();
+}
+
 hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                          const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
@@ -627,8 +637,9 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     // start records of this batch + the shards' query counters: scratch of this launch sequence
     // alone, so concurrent calls do not share state
     const size_t nrec = Q * nshards;
+    const bool prepared = extra && extra->d_init;  // the start records exist already: only the counters are scratch
     scratch_cache::lease mem;
-    hipError_t e = scratch.take(nrec * sizeof(ulonglong2) + nshards * sizeof(unsigned long long), stream, &mem);
+    hipError_t e = scratch.take((prepared ? 0 : nrec * sizeof(ulonglong2)) + nshards * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
     if (counts_only) {  // counts: only the searches that find something store theirs
         e = hipMemsetAsync(d_lower, 0, nrec * sizeof(uint64_t), stream);
@@ -637,15 +648,17 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
             return e;
         }
     }
-    ulonglong2 *init = (ulonglong2 *)mem.p;
-    unsigned long long *ctr = (unsigned long long *)(init + nrec);
+    ulonglong2 *init = prepared ? (ulonglong2 *)extra->d_init : (ulonglong2 *)mem.p;
+    unsigned long long *ctr = prepared ? (unsigned long long *)mem.p : (unsigned long long *)(init + nrec);
     e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
         scratch.give(mem, stream);
         return e;
     }
     const unsigned ig = (unsigned)((nrec + 255) / 256);
-    if (extra && extra->d_trace_in)
+    if (prepared) {
+        // nothing to compute
+    } else if (extra && extra->d_trace_in)
         hipLaunchKernelGGL(search_init_1mm_kernel, dim3(ig), dim3(256), 0, stream, d_shards, pk, vd, Q, k, wpq,
                            extra->variants, (const ulonglong2 *)extra->d_trace_in, trace_n, init);
     else

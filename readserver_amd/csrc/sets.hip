@@ -495,6 +495,42 @@ int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, cons
                          false, (hipStream_t)stream, &ex);
 }
 
+// The same search in two halves, so that a pipelined caller can compute the start records of batch i + 1 on a
+// second stream while batch i is searched (they depend on the batch's k-mers and the k-mer tables only):
+// rsbwt_set_prepare_dev fills d_records ([num_shards][Q] x 16 B) on `stream`; the caller orders it before
+// rsbwt_set_find_interval_pairs_prepared_dev (an event, or the same stream), which runs the search kernel alone.
+size_t rsbwt_set_records_bytes(const rsbwt_set_t *s, size_t Q) { return s ? s->shards.size() * Q * 16 : 0; }
+
+int rsbwt_set_prepare_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_records,
+                          void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    if (Q == 0) return RSBWT_OK;
+    if (!d_packed || !d_valid || !d_records) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0 || k > 65535u) return fail(RSBWT_ERANGE, "k %u: 1..65535 symbols per k-mer", k);
+    dev_group *g = s->groups[0];
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    const hipError_t e = launch_search_init(g->d_views, (uint32_t)g->idx.size(), d_packed, d_valid, Q, k, d_records, (hipStream_t)stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "start-record kernel launch");
+}
+
+int rsbwt_set_find_interval_pairs_prepared_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, const void *d_records,
+                                               size_t Q, uint32_t k, void *d_pairs, void *stream) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
+    if (Q && !d_records) return fail(RSBWT_EINVAL, "null argument");
+    dev_group *g = s->groups[0];
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    search_extra ex;
+    ex.pairs = true;
+    ex.d_init = d_records;
+    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
+    return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_pairs, nullptr,
+                         false, (hipStream_t)stream, &ex);
+}
+
 int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t Q, uint32_t k,
                         void *d_counts, void *stream) {
     if (!s) return fail(RSBWT_EINVAL, "null set");

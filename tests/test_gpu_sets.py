@@ -152,3 +152,40 @@ def test_gpu_set_device_resident_forms(rsb, four_shards):
     for s in range(S):
         for i in range(0, n, 5):
             assert out[s, i, :ln[s, i]].tobytes().decode() == want[s * n + i] and pl[s, i] == wpl[s * n + i]
+
+
+def test_gpu_search_from_prepared_start_records(rsb, four_shards):
+    """rsbwt_set_prepare_dev + rsbwt_set_find_interval_pairs_prepared_dev (the start records of a batch computed
+    ahead, on another stream) give the pairs of rsbwt_set_find_interval_pairs_dev -- and the oracle's."""
+    import torch
+    ss, shards, oixs, reads = four_shards
+    L = rsb.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(8)
+    k, Q, S = 31, 5000, 4
+    kmers = _kmers_from(reads, rng, Q - 2, k, mutate=0.3) + ["N" * k, "A" * k]
+    d_km = torch.from_numpy(np.frombuffer("".join(kmers).encode(), np.uint8).reshape(Q, k).copy()).to(dev)
+    d_pk = torch.empty(Q, dtype=torch.int64, device=dev)
+    d_ok = torch.empty(Q, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(side.cuda_stream)
+    d_rec = torch.empty(L.rsbwt_set_records_bytes(ss._s, Q), dtype=torch.uint8, device=dev)
+    assert d_rec.numel() == S * Q * 16
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        assert L.rsbwt_pack_kmers_dev(p(d_km), Q, k, k, p(d_pk), p(d_ok), 0, sp) == 0
+        assert L.rsbwt_set_prepare_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(d_rec), sp) == 0
+        done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    a = torch.zeros((S, Q, 2), dtype=torch.int64, device=dev)
+    b = torch.zeros((S, Q, 2), dtype=torch.int64, device=dev)
+    assert L.rsbwt_set_find_interval_pairs_prepared_dev(ss._s, p(d_pk), p(d_ok), p(d_rec), Q, k, p(a), None) == 0
+    assert L.rsbwt_set_find_interval_pairs_dev(ss._s, p(d_pk), p(d_ok), Q, k, p(b), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    km = np.frombuffer("".join(kmers).encode(), np.uint8).reshape(Q, k)
+    for s in range(S):
+        elo, eup = oixs[s].find_intervals(km)
+        got = a[s].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[:, 0], elo) and np.array_equal(got[:, 1], eup)
