@@ -485,9 +485,9 @@ static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(h->mu);
     if (h->d_sel) return RSBWT_OK;
     const uint64_t words = 5 * select_sample_stride(h->view);
-    uint32_t *d = nullptr;
-    HIP_OK(hipMalloc(&d, words * sizeof(uint32_t)));
-    hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint32_t), stream);
+    uint64_t *d = nullptr;
+    HIP_OK(hipMalloc(&d, words * sizeof(uint64_t)));
+    hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint64_t), stream);
     if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
@@ -495,7 +495,7 @@ static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
         return fail_hip(e, "select sample kernel");
     }
     h->d_sel = d;
-    h->hbm_bytes += words * sizeof(uint32_t);
+    h->hbm_bytes += words * sizeof(uint64_t);
     return RSBWT_OK;
 }
 

@@ -81,7 +81,7 @@ struct rsbwt : rsb::search_meter {
     uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
     uint64_t far_lines = 0, chunk_windows = 0, far_windows = 0, spilled_symbols = 0;
     rsb::ctx_pool pool;
-    uint32_t *d_sel = nullptr;  // sampled select table, built on first use
+    uint64_t *d_sel = nullptr;  // sampled select table, built on first use
     bool ktab_owned = true;     // false: view.ktab points into a shard set's interleaved table
 };
 

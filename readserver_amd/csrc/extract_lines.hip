@@ -13,11 +13,11 @@
 //     look at the quarter's 24 pieces (rank_device.h, char_rank24: dword totals by v_dot4, only the
 //     dword holding the position is taken apart); a spilled position takes one more pass, the window
 //     line's four counts travelling with the lane;
-//   * psi step (postfix): sampled select (one sample per 256 occurrences) bounds the window; the
-//     window tried first is interpolated between the two samples and its line is fetched together
-//     with the next window's count word (8 bytes), which says at once whether the guess was right
-//     (count(w) < bc <= count(w + 1)) -- a wrong guess costs one more pass; then selected in: three
-//     quarter boundaries from the header and two v_dot4 sums, one quarter taken apart
+//   * psi step (postfix): one 8-byte select sample per 256 occurrences NAMES the window of the wanted
+//     occurrence (its window and how the block's occurrences spread over the following windows:
+//     kernels.h, sample_window), so the first line fetched is the right one -- round 2 interpolated between
+//     two bare window numbers and was wrong 31 % of the time, a second fetch and pass each; then selected
+//     in: three quarter boundaries from the header and two v_dot4 sums, one quarter taken apart
 //     (rank_device.h, select_in24).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -283,7 +283,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
 // ---------------------------------------------------------------------------------------------------
 template <bool COUNT_WORK>
 __global__ void __launch_bounds__(64 * WG_WAVES)
-extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
+extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t stride_m,
                             const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out, uint32_t stride,
                             const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen,
                             unsigned long long *__restrict__ pool, unsigned long long *__restrict__ work) {
@@ -304,7 +304,7 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
     // phase 0: F symbol + select samples; 3: the samples are in flight; 2: select in window wcur, which
     // lies between the samples' windows wlo and whi
     uint32_t phase = 0, wlo = 0, whi = 0, wcur = 0, tries = 0;
-    uint32_t samp_lo = 0, samp_hi = 0;
+    uint64_t samp = 0;
     uint32_t cont = 0, cblk = 0, cdw = 0;
     const uint32_t nwin = (uint32_t)ix.nwin;
     uint64_t t = 0;  // occurrences of f still to pass (select's running argument)
@@ -341,13 +341,24 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
             ++xw[XW_PASSES];
             xw[XW_ACTIVE] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
         }
-        // ---- the samples issued at the end of the last pass have landed: the bc-th f lies in a window
-        // between theirs.  Occurrences spread evenly between two samples more often than not, so the
-        // first window tried is the interpolated one; a wrong guess costs one more pass.
+        // ---- the sample issued at the end of the last pass has landed: it names the window of the bc-th f
+        // outright (kernels.h, sample_window: exact unless the block's 256 occurrences spread over more than
+        // five windows, then a lower bound the search below walks up from)
         if (have && phase == 3u) {
-            wlo = samp_lo;
-            whi = samp_hi < samp_lo ? samp_lo : samp_hi;
-            wcur = wlo + (((whi - wlo) * (((uint32_t)bc - 1u) & ((1u << SEL_SHIFT) - 1u)) + (1u << (SEL_SHIFT - 1u))) >> SEL_SHIFT);
+            bool exact;
+            wcur = sample_window(samp, bc, &exact);
+            if (wcur >= nwin) wcur = nwin - 1u;  // never for a sample this index built
+            wlo = whi = wcur;
+            if (!exact) {
+                // the block's occurrences spread over more than five windows (a stretch of the BWT nearly without
+                // f): the bc-th lies between w0 + 4 and the window the next block starts in -- a dependent load,
+                // taken by the few lanes that need it, and the bisection of the window headers below
+                const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
+                const uint64_t tf = f == 1u ? T1 : f == 2u ? T2 : f == 3u ? T3 : T4;
+                const uint32_t nxt = ((m + 1ull) << SEL_SHIFT) < tf ? (uint32_t)sel[f * stride_m + m + 1ull] : nwin - 1u;
+                whi = nxt > wlo ? (nxt < nwin ? nxt : nwin - 1u) : wlo;
+                wcur = wlo + ((whi - wlo) >> 1);
+            }
             phase = 2;
             cont = 0;
             tries = 0;
@@ -497,12 +508,10 @@ extract_postfix_wave_kernel(const shard_view ix, const uint32_t *__restrict__ se
                 have = false;
             } else {
                 const uint64_t cf = f == 1u ? C1 : f == 2u ? C2 : f == 3u ? C3 : C4;
-                const uint64_t tf = f == 1u ? T1 : f == 2u ? T2 : f == 3u ? T3 : T4;
                 bc = idx - cf + 1ull;
                 const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
-                samp_lo = sel[f * stride_m + m];
-                samp_hi = ((m + 1ull) << SEL_SHIFT) < tf ? sel[f * stride_m + m + 1ull] : (uint32_t)(ix.nwin - 1ull);
-                phase = 3;  // the samples are used from the next pass on
+                samp = sel[f * stride_m + m];
+                phase = 3;  // the sample is used from the next pass on
             }
         }
     }
@@ -534,7 +543,7 @@ move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *_
     }
 }
 
-hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint64_t *d_sel, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
                                hipStream_t stream, unsigned long long *d_work) {
     if (n == 0) return hipSuccess;

@@ -93,7 +93,7 @@ hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void
 hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n, void *d_out,
                              hipStream_t stream);
 // d_sel: the sampled select table (launch_select_samples)
-hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
+hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, const void *d_syms, const void *d_bc,
                                size_t n, void *d_out, hipStream_t stream);
 // The list of the set bits of `bits` (n_searches bits), in order: record i = {lower, upper, search index, 0}
 // (32 B) from sparse[index]; at most `cap` records are written, *d_total receives how many there are.
@@ -106,18 +106,27 @@ hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, vo
 hipError_t launch_unpack_pairs10(const void *d_packed, size_t n, void *d_pairs, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
-// read extraction: sampled select table (5 x stride u32: window of every 256th occurrence of each
-// symbol) and the walk kernel
+// read extraction: sampled select table (5 x stride u64: for every 256th occurrence of each symbol its
+// window and how the 256 occurrences from it on spread over the next windows -- kernels.hip) and the walk kernel
 hipError_t launch_debug_fast_window(const void *d_p, size_t n, uint32_t S, void *d_w, void *d_r, hipStream_t stream);
 uint64_t select_sample_stride(const shard_view &ix);
-hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream);
+hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStream_t stream);
 // extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
-hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint32_t *d_sel, const void *d_rows,
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint64_t *d_sel, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
                                hipStream_t stream, unsigned long long *d_work = nullptr);
 // d_work (counting mode): WORK_WORDS counters, zeroed by the caller: words 0-7 the prefix walk, 8-15 the
 // postfix walk (extract_lines.hip, XW_*)
-constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences: the window search spans a few windows
+constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences (its four count bytes assume exactly that)
+// the window of the bc-th occurrence from its block's sample; *exact = false: only a lower bound
+RSB_HD uint32_t sample_window(uint64_t word, uint64_t bc, bool *exact) {
+    const uint32_t r = (uint32_t)((bc - 1) & ((1u << SEL_SHIFT) - 1u));
+    const uint32_t k0 = (uint32_t)(word >> 32) & 0xFFu, k1 = (uint32_t)(word >> 40) & 0xFFu;
+    const uint32_t k2 = (uint32_t)(word >> 48) & 0xFFu, k3 = (uint32_t)(word >> 56);
+    *exact = r <= k3;
+    return (uint32_t)word + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u) + (r > k3 ? 1u : 0u);
+}
+
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
                               const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream);

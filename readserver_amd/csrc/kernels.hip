@@ -223,10 +223,16 @@ char_batch_kernel(const shard_view ix, const uint64_t *__restrict__ index, size_
     out[i] = (uint8_t)("$ACGT"[view_char(ix, p)]);
 }
 
-// Sampled select: sel[c][m] = window holding the (m << SEL_SHIFT) + 1 -th occurrence of symbol c.
+// Sampled select: sel[c][m] describes the block of 256 occurrences of symbol c that starts with occurrence
+// (m << SEL_SHIFT) + 1: bits 0..31 = the window w0 holding that first occurrence, then four bytes k0..k3 with
+// k_j + 1 = how many of the block's occurrences lie in windows <= w0 + j (capped at 256).  The window of the
+// block's r-th occurrence (r = 0..255) is then w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while
+// the block spans at most five windows' worth of knowledge (r <= k3), a lower bound beyond.  Round 2 kept the
+// bare window (4 bytes) and interpolated between two samples: 31 % of first guesses were wrong and cost a second
+// line fetch and a second pass (profiles/r02d_extract_profile.json).
 
 __global__ void __launch_bounds__(256)
-select_sample_kernel(const shard_view ix, uint32_t *__restrict__ sel, uint64_t stride_m) {
+select_sample_kernel(const shard_view ix, uint64_t *__restrict__ sel, uint64_t stride_m) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= ix.nwin) return;
     for (uint32_t c = 0; c <= 4; ++c) {
@@ -238,22 +244,41 @@ select_sample_kernel(const shard_view ix, uint32_t *__restrict__ sel, uint64_t s
         ce = ce < tc ? ce : tc;
         if (ce <= cb) continue;
         // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
-        for (uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT; (m << SEL_SHIFT) < ce; ++m)
-            sel[c * stride_m + m] = (uint32_t)w;
+        uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT;
+        if ((m << SEL_SHIFT) >= ce) continue;
+        uint64_t upto[4] = {ce, 0, 0, 0};
+        for (int j = 1; j < 4; ++j) {
+            const uint64_t x = count_before_window(ix, w + 1 + j, c);
+            upto[j] = x < tc ? x : tc;
+            if (upto[j] < upto[j - 1]) upto[j] = upto[j - 1];  // monotone whatever the lines say
+        }
+        for (; (m << SEL_SHIFT) < ce; ++m) {
+            const uint64_t before = m << SEL_SHIFT;  // occurrences before the block
+            uint64_t word = w & 0xFFFFFFFFull;
+            for (int j = 0; j < 4; ++j) {
+                uint64_t kj = upto[j] - before;  // >= 1 for j = 0
+                kj = kj > 256 ? 256 : kj;
+                word |= (kj - 1) << (32 + 8 * j);
+            }
+            sel[c * stride_m + m] = word;
+        }
     }
 }
 
-// getOccAt with the sample table bounding the header search (BPTree::select's role)
-__device__ uint64_t thread_occ_at_sampled(const shard_view &ix, const uint32_t *__restrict__ sel,
+// getOccAt with the sample table naming the window (BPTree::select's role)
+__device__ uint64_t thread_occ_at_sampled(const shard_view &ix, const uint64_t *__restrict__ sel,
                                           uint64_t stride_m, uint32_t b, uint64_t bc) {
     const uint64_t m = (bc - 1) >> SEL_SHIFT;
-    const uint64_t lo = sel[b * stride_m + m];
-    const uint64_t hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? sel[b * stride_m + m + 1] : ix.nwin - 1;
-    return view_occ_at(ix, b, bc, lo, hi);
+    bool exact;
+    const uint64_t lo = sample_window(sel[b * stride_m + m], bc, &exact);
+    uint64_t hi = lo;
+    if (!exact) hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? (uint32_t)sel[b * stride_m + m + 1] : ix.nwin - 1;
+    if (hi < lo) hi = lo;
+    return view_occ_at(ix, b, bc, lo < ix.nwin ? lo : ix.nwin - 1, hi < ix.nwin ? hi : ix.nwin - 1);
 }
 
 __global__ void __launch_bounds__(256)
-occ_at_batch_kernel(const shard_view ix, const uint32_t *__restrict__ sel, uint64_t stride_m,
+occ_at_batch_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t stride_m,
                     const uint8_t *__restrict__ syms, const uint64_t *__restrict__ bc, size_t n,
                     uint64_t *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,7 +727,7 @@ hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n
     return hipGetLastError();
 }
 
-hipError_t launch_occ_at_batch(const shard_view &ix, const uint32_t *d_sel, const void *d_syms, const void *d_bc,
+hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, const void *d_syms, const void *d_bc,
                                size_t n, void *d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
@@ -772,7 +797,7 @@ uint64_t select_sample_stride(const shard_view &ix) {
     return (mx >> SEL_SHIFT) + 2;
 }
 
-hipError_t launch_select_samples(const shard_view &ix, uint32_t *d_sel, hipStream_t stream) {
+hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStream_t stream) {
     if (ix.nwin == 0) return hipSuccess;
     hipLaunchKernelGGL(select_sample_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix));

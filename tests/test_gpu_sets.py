@@ -189,3 +189,45 @@ def test_gpu_search_from_prepared_start_records(rsb, four_shards):
         elo, eup = oixs[s].find_intervals(km)
         got = a[s].cpu().numpy().view(np.uint64)
         assert np.array_equal(got[:, 0], elo) and np.array_equal(got[:, 1], eup)
+
+
+def test_gpu_select_across_stretches_without_the_symbol(rsb, oracle):
+    """The select samples name a window exactly while a block of 256 occurrences spreads over at most five
+    windows; a stretch of the BWT (nearly) without a symbol makes blocks of that symbol span hundreds of windows,
+    where the sample gives a bracket and the walk bisects the window headers.  getOccAt at every occurrence of
+    the rare symbol and batched extraction against the oracle."""
+    rng = np.random.default_rng(77)
+    parts = []
+    for blk in range(12):  # alternating: every symbol / no T at all / T once in ~3000 symbols
+        R = 40000
+        if blk % 3 == 0:
+            sym = rng.integers(0, 5, R)
+        elif blk % 3 == 1:
+            sym = rng.integers(0, 4, R)
+        else:
+            sym = np.where(rng.random(R) < 0.002, 4, rng.integers(1, 4, R))
+        parts.append(((sym.astype(np.uint8)) << 5) | rng.integers(1, 9, R).astype(np.uint8))
+    runs = np.concatenate(parts)
+    oix = oracle.from_runs(runs)
+    n = oix.bwlen()
+    for span in (0, 64):
+        with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=None) as g:
+            tot = g.getOcc("T", n - 1)
+            bc = np.arange(1, tot + 1, 3, dtype=np.uint64)
+            idx = g.occ_at_batch("T", bc)
+            assert (g.char_batch(idx) == ord("T")).all() and np.array_equal(g.occ_batch("T", idx), bc)
+            for j in range(0, bc.size, 997):
+                assert int(idx[j]) == oix.occ_at("T", int(bc[j]))
+            rows = rng.integers(0, n, 20000).astype(np.uint64)
+            out = np.zeros((rows.size, 512), np.uint8)
+            ln, pl = np.empty(rows.size, np.uint32), np.empty(rows.size, np.uint32)
+            assert rsb.lib().rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 512, ln.ctypes.data,
+                                           pl.ctypes.data) == 0
+            checked = 0
+            for i in range(0, rows.size, 13):
+                if ln[i] == 0xFFFFFFFF:
+                    continue
+                pre, post = oix.extract(int(rows[i]), cap=4096)
+                assert out[i, :ln[i]].tobytes().decode() == pre + post and pl[i] == len(pre), (span, i)
+                checked += 1
+            assert checked > 500
