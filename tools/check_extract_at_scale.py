@@ -18,12 +18,12 @@ from readserver_amd import selfcheck  # noqa: E402
 
 R = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000000
 NR = int(float(sys.argv[2])) if len(sys.argv) > 2 else 2000000
-LONG = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+LONG = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # 1: the long-run stream, 2: the population stream
 SPAN = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 L = rsb.lib()
 dev = torch.device("cuda", 0)
 d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
-seed = ((1 << 63) if LONG else 0) | 1000003
+seed = ((1 << 63) if LONG == 1 else (1 << 62) if LONG == 2 else 0) | 1000003
 if L.rsbwt_synth_runs_dev(C.c_void_p(d_runs.data_ptr()), R, seed, 0, None) != 0:
     raise RuntimeError(L.rsbwt_last_error().decode())
 torch.cuda.synchronize()
