@@ -217,6 +217,8 @@ def main():
         t_bwt += time.time() - t1
         units_hist += torch.bincount((runs & 31).long(), minlength=32).cpu().numpy()
         runs_total += int(runs.numel())
+        if s == 0:
+            host_runs0 = runs.cpu().numpy()  # for the oracle, after the timed region
         g = rsb.GpuBWT(device_runs=(runs.data_ptr(), int(runs.numel())), num_strings=int(rs.shape[0]), ktab_depth=None)
         assert g.getBWLen() == n
         shards.append(g)
@@ -290,8 +292,17 @@ def main():
     kms = float(np.mean(list(buf[:cnt.value])))
     alg = ln * LINE_BYTES + S * Q * SEARCH_BYTES
     hbm = sum(int(g.hbm_bytes()) for g in shards)
-    # the oracle on a sample, shard 5 (its run bytes copied back: small enough)
+    # the oracle (CPU restatement of the reference algorithm: the checker) on a sample of the batch, shard 0
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_binding
+    oix = oracle_binding.load().from_runs(host_runs0, num_strings=nreads[0])
+    sel = torch.from_numpy(np.linspace(0, Q - 1, min(Q, 1000000)).astype(np.int64)).to(dev)
+    km = d_km[sel].cpu().numpy()
+    t2 = time.perf_counter()
+    elo, eup = oix.find_intervals(km, nthreads=len(os.sched_getaffinity(0)))
+    t_cpu = time.perf_counter() - t2
+    got = d_pairs[0][sel].cpu().numpy().view(np.uint64)
+    matches = bool(np.array_equal(got[:, 0], elo) and np.array_equal(got[:, 1], eup))
     units = units_hist[1:].sum()
     out = {
         "what": "bench.py's exact search on the 8 shards one GPU holds of a VALID 64-shard population BWT built on the GPU "
@@ -307,6 +318,8 @@ def main():
         "genomic_31mers": {"fraction_of_shards_holding_one": frac_shards, "final_width_mean": float(wpos.mean().item()),
                            "final_width_median": float(wpos.median().item())},
         "random_31mers_present_fraction": rand_present,
+        "oracle": {"shard": 0, "kmers": int(sel.numel()), "gpu_matches_oracle": matches,
+                   "oracle_queries_per_s": float(sel.numel() / t_cpu), "threads": len(os.sched_getaffinity(0))},
         "mean_lf_steps_per_search": lf / (S * Q), "lines_per_lf_step": ln / max(lf, 1), "occ_lookups": oc,
         "searches_per_s": S * Q / dt, "queries_per_s": Q / dt, "ms_per_step": dt * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
