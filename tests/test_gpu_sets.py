@@ -231,3 +231,67 @@ def test_gpu_select_across_stretches_without_the_symbol(rsb, oracle):
                 assert out[i, :ln[i]].tobytes().decode() == pre + post and pl[i] == len(pre), (span, i)
                 checked += 1
             assert checked > 500
+
+
+def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path):
+    """The cross-device paths of csrc/sets.hip: the same four shards as a set on ONE device and as a
+    set split over devices 0 and 1 must give the same intervals, the same summed counts (ncclReduce over the
+    per-device communicators), the same gathered blocks (ncclSend / ncclRecv onto the first device), hit lists,
+    reads and query lists.  Needs two GPUs: skipped on the one-GPU boxes this repo has been developed on -- no
+    RCCL collective of this library has run anywhere yet, and this is the test that will say when one has."""
+    import torch
+    L = rsb.lib()
+    if L.rsbwt_device_count() < 2:
+        pytest.skip("one GPU: the cross-device paths need two")
+    kw = dict(seed=41, genome_len=20000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=3.0)
+    paths = []
+    for s in range(4):
+        p_ = str(tmp_path / f"s{s}.bwt")
+        rsb.synth_popbwt(p_, None, shard=s, num_shards=4, **kw)
+        paths.append(p_)
+    rd = str(tmp_path / "w.reads")
+    rsb.synth_popbwt(str(tmp_path / "w.bwt"), rd, **kw)
+    reads = open(rd).read().split()
+    rng = np.random.default_rng(9)
+    kmers = _kmers_from(reads, rng, 3000, 31, mutate=0.3)
+    one = [rsb.GpuBWT(p_, device=0) for p_ in paths]
+    two = [rsb.GpuBWT(p_, device=(0 if s < 2 else 1)) for s, p_ in enumerate(paths)]
+    s1, s2 = rsb.ShardSet(one), rsb.ShardSet(two)
+    assert L.rsbwt_set_devices(s1._s) == 1 and L.rsbwt_set_devices(s2._s) == 2
+    lo1, up1 = s1.find_intervals(kmers)
+    lo2, up2 = s2.find_intervals(kmers)
+    assert np.array_equal(lo1, lo2) and np.array_equal(up1, up2)
+    assert np.array_equal(s1.count(kmers), s2.count(kmers))  # the RCCL reduce when librccl is there
+    h1, f1 = s1.hits_1mm(kmers[:300])
+    h2, f2 = s2.hits_1mm(kmers[:300])
+    assert np.array_equal(h1, h2) and np.array_equal(f1, f2)
+    assert s1.query(kmers[:200], read_stride=96) == s2.query(kmers[:200], read_stride=96)
+    sh = rng.integers(0, 4, 2000).astype(np.uint32)
+    rows = np.array([rng.integers(0, one[s].getBWLen()) for s in sh], dtype=np.uint64)
+    assert s1.extract(sh, rows, stride=96)[0] == s2.extract(sh, rows, stride=96)[0]
+    if L.rsbwt_rccl_available():
+        # per-device interval blocks gathered onto device 0: [2][Q] x {lower, upper} from each device
+        Q = len(kmers)
+        blocks, streams, nbytes = [], [], []
+        a = np.frombuffer("".join(kmers).encode(), np.uint8).reshape(Q, 31)
+        for dv, ss in ((0, [0, 1]), (1, [2, 3])):
+            torch.cuda.set_device(dv)
+            pr = torch.empty((2, Q, 2), dtype=torch.int64, device=f"cuda:{dv}")
+            pr[..., 0] = torch.from_numpy(lo2[ss].astype(np.int64)).to(pr.device)
+            pr[..., 1] = torch.from_numpy(up2[ss].astype(np.int64)).to(pr.device)
+            blocks.append(pr)
+            nbytes.append(pr.numel() * 8)
+            streams.append(torch.cuda.current_stream(dv).cuda_stream)
+        torch.cuda.set_device(0)
+        root = torch.zeros((4, Q, 2), dtype=torch.int64, device="cuda:0")
+        bp = (C.c_void_p * 2)(*[b.data_ptr() for b in blocks])
+        nb = (C.c_size_t * 2)(*nbytes)
+        st = (C.c_void_p * 2)(*streams)
+        assert L.rsbwt_set_gather_intervals_dev(s2._s, bp, nb, C.c_void_p(root.data_ptr()), st) == 0, L.rsbwt_last_error()
+        for dv in (0, 1):
+            torch.cuda.synchronize(dv)
+        got = root.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[..., 0], lo2) and np.array_equal(got[..., 1], up2)
+    s1.close(); s2.close()
+    for g in one + two:
+        g.close()

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential campaign on the GPU box (not part of the suite: it runs for as long as it is
 told to): random run streams x layouts (window span, k-mer table depth) x query lengths, the HIP path
-against the oracle -- intervals, counts, the 1-mismatch hit list against the dense matrices, read
-extraction row by row.  Test infrastructure: the oracle is the checker, as in tests/.
+against the oracle -- intervals, counts, the 1-mismatch hit list against the dense matrices, getOccAt, read
+extraction row by row, and (two-shard sets) the set-level hit lists and query lists.  Test infrastructure: the oracle is the checker, as in tests/.
 Prints a progress line per configuration and one JSON line at the end; exit code 1 on any difference.
 usage: tools/fuzz_parity.py [seconds=300] [seed=1]"""
 import json
@@ -41,7 +41,8 @@ def make_runs(R, shape):
         sym = np.where(rng.random(R) < 0.995, 1 + (np.arange(R) // 5000) % 4, sym)
     elif shape == 5:  # the library's own generators
         runs = np.empty(R, np.uint8)
-        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, int(rng.integers(1, 1 << 30)) | (int(rng.integers(0, 2)) << 63)) == 0
+        style = [0, 1 << 63, 1 << 62][int(rng.integers(0, 3))]  # mixed, long-run, population stream
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, int(rng.integers(1, 1 << 30)) | style) == 0
         return runs
     return ((sym << 5) | ln).astype(np.uint8)
 
@@ -91,6 +92,30 @@ while time.time() < t_end:
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
                     ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
                            np.array_equal(slo[1], e2lo) and np.array_equal(sup[1], e2up))
+                    # configs[3] / configs[4] over the set: every shard's own list / reads, side by side
+                    if k <= 40:
+                        sh, first = ss.hits_1mm(km[:60])
+                        ok2 = ok2 and np.array_equal(sh[int(first[0]):int(first[1])], rsb.hits_1mm_batch(g, km[:60]))
+                        ok2 = ok2 and np.array_equal(sh[int(first[1]):int(first[2])], rsb.hits_1mm_batch(g2, km[:60]))
+                    try:  # (rows of an interval are extracted: keep it small; streams with hardly any '$' have reads longer than any buffer)
+                        qs = ss.query(km[:300:2], read_stride=2048) if n < 3000000 else None
+                    except rsb.RsbwtError:
+                        qs = None
+                    if qs is not None:
+                        for qi, lst in zip(range(0, 300, 2), qs):
+                            exp = []
+                            for si, (ox, lo_, up_) in enumerate(((oix, elo, eup), (oix2, e2lo, e2up))):
+                                if up_[qi] >= lo_[qi] and up_[qi] - lo_[qi] < 64:
+                                    try:
+                                        exp += [(si, "".join(ox.extract(int(r), cap=2000))) for r in range(int(lo_[qi]), int(up_[qi]) + 1)]
+                                    except AssertionError:
+                                        exp = None
+                                        break
+                                elif up_[qi] >= lo_[qi]:
+                                    exp = None
+                                    break
+                            if exp is not None and all(len(t) <= 2048 for _, t in exp):
+                                ok2 = ok2 and lst == exp
                     ss.close()
                 oix2.close()
                 assert ok2, "shard set"
@@ -106,6 +131,14 @@ while time.time() < t_end:
                 assert got == want, "1-mismatch hit list"
                 vlo, vup = oix.find_intervals(np.array([list(km[0])], np.uint8))
                 assert (int(dlo[0, 0]), int(dup[0, 0])) == (int(vlo[0]), int(vup[0])), "1-mismatch column 0"
+            # getOccAt (select) at random occurrences of every symbol: the select samples name the window
+            for ch in "ACGT$":
+                tot = oix.occ(ch, n - 1)
+                if tot:
+                    bcs = rng.integers(1, tot + 1, 300).astype(np.uint64)
+                    gi = g.occ_at_batch(ch, bcs)
+                    assert all(int(gi[i]) == oix.occ_at(ch, int(bcs[i])) for i in range(0, 300, 7)), "getOccAt"
+                    assert np.array_equal(g.occ_batch(ch, gi), bcs), "getOcc(getOccAt)"
             stride = 2048
             out = np.zeros((rows.size, stride), np.uint8)
             ln = np.empty(rows.size, np.uint32)
