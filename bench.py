@@ -804,7 +804,7 @@ def run_rows(a, c):
         xw = (C.c_uint64 * 16)()
         ok(c, L.rsbwt_last_search_counters(shards[0].handle, xw))  # the walk kernels' counters of the last shard that ran with counting on
         ok(c, L.rsbwt_set_counting(shards[0].handle, 0))
-        names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "wrong_first_window"]
+        names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "steps_from_line_hint"]
         walk = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
         lens0 = (d_l[0] if d_l is not None else gat_l.acquire(0)).to(dev).reshape(-1)
         ln = lens0.cpu().numpy().view(np.uint32)
@@ -845,6 +845,7 @@ def run_rows(a, c):
                            + (", reads gathered on rank 0 and concatenated in shard order" if world > 1 else ""),
                            rows_per_shard=NR, row_run=run, stride=stride, rows_fitting_stride=int(fits.sum()) / max(ln.size, 1),
                            mean_read_length=bases / max(int(fits.sum()), 1), reads_verified=verified, walk_counters_one_shard=walk,
+                           window_lines_with_a_psi_hint=int(L.rsbwt_psi_hint_lines(shards[0].handle)) / max(int(shards[0].num_lines()) * 16 // 17, 1),
                            travels=(None if world == 1 else f"[{S}][{NR}][{stride}] read bytes + lengths per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

@@ -106,6 +106,7 @@ uint32_t rsbwt_window_span(const rsbwt_t *h);     /* symbols per window */
 uint64_t rsbwt_far_lines(const rsbwt_t *h);       /* lines that continue windows of > 120 pieces */
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h); /* positions one request past their window's line */
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h);       /* lines + tables */
+uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi hint (0 before the first extraction / getOccAt) */
 /* Builds the k-mer table of depth T (2..16) of an open handle that has none. */
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 int rsbwt_device(const rsbwt_t *h);

@@ -442,6 +442,7 @@ uint32_t rsbwt_window_span(const rsbwt_t *h) { return h->view.n ? h->view.sp.S :
 uint64_t rsbwt_far_lines(const rsbwt_t *h) { return h->far_lines; }
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h) { return h->spilled_symbols; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
+uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h) { return h->psi_hint_lines; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
 // Test hook: w[i] = p[i] / S, r[i] = p[i] % S as the KERNELS compute them (fast_window); host buffers.
@@ -489,11 +490,23 @@ static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
     HIP_OK(hipMalloc(&d, words * sizeof(uint64_t)));
     hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint64_t), stream);
     if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
+    // and the psi hints, into the window lines that have room for one (line_format.h): extraction's select then
+    // needs no sample for the rows of those windows.  Searches that run meanwhile are not disturbed: a hint sits
+    // where a line of at most 88 pieces holds none, and the flag is a header bit no search reads.
+    unsigned long long *d_made = nullptr, made = 0;
+    if (e == hipSuccess && getenv("RSBWT_NO_PSI_HINTS") == nullptr) {
+        e = hipMalloc(&d_made, sizeof made);
+        if (e == hipSuccess) e = hipMemsetAsync(d_made, 0, sizeof made, stream);
+        if (e == hipSuccess) e = launch_psi_hints(h->view, d, d_made, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&made, d_made, sizeof made, hipMemcpyDeviceToHost, stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (d_made) (void)hipFree(d_made);
     if (e != hipSuccess) {
         (void)hipFree(d);
         return fail_hip(e, "select sample kernel");
     }
+    h->psi_hint_lines = made;
     h->d_sel = d;
     h->hbm_bytes += words * sizeof(uint64_t);
     return RSBWT_OK;

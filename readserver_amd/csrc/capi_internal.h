@@ -82,6 +82,7 @@ struct rsbwt : rsb::search_meter {
     uint64_t far_lines = 0, chunk_windows = 0, far_windows = 0, spilled_symbols = 0;
     rsb::ctx_pool pool;
     uint64_t *d_sel = nullptr;  // sampled select table, built on first use
+    uint64_t psi_hint_lines = 0;  // window lines that carry a psi hint (written when the samples are built)
     bool ktab_owned = true;     // false: view.ktab points into a shard set's interleaved table
 };
 

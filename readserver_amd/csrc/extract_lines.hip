@@ -97,8 +97,8 @@ __device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, si
 // ---------------------------------------------------------------------------------------------------
 // COUNT_WORK (both walk kernels): work[] receives, summed over the waves, 0 passes, 1 lanes holding a
 // row over those passes, 2 steps completed, 3 lanes on a continuation line, 4 lanes that fetched a line,
-// 5 cycles in all, 6 cycles from issuing the fetches until they have landed, 7 (postfix) lanes whose
-// window guess was wrong (one more pass each).
+// 5 cycles in all, 6 cycles from issuing the fetches until they have landed, 7 (postfix) steps whose window
+// came from the psi hint of the line the previous step landed in (no sample read).
 enum { XW_PASSES = 0, XW_ACTIVE = 1, XW_STEPS = 2, XW_CONT = 3, XW_FETCHED = 4, XW_CYCLES = 5, XW_WAIT = 6, XW_PROBES = 7, XW_WORDS = 8 };
 
 template <bool COUNT_WORK>
@@ -387,6 +387,9 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             xw[XW_WAIT] += __builtin_amdgcn_s_memtime() - t_fetch;
         }
         bool stepped = false, moved = false;
+        // the psi hint of the window the step lands in (line_format.h), taken while its line is staged
+        bool hint_here = false, hinted_now = false;
+        uint32_t hint_w0 = 0, hint_kk = 0, hint_win = 0;
         if (selecting) {
             bool found = false;
             uint64_t pos = 0;
@@ -418,6 +421,12 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                 } else if (left == 0u && start + p < h.span) {
                     found = true;
                     pos = posbase + start + p;
+                    if (cont == 0u && ((L.dword(1) >> (8u + HINT_META0_BIT)) & 1u) != 0u) {
+                        hint_here = true;
+                        hint_w0 = L.dword(LINE_DWORDS - 2u);
+                        hint_kk = L.dword(LINE_DWORDS - 1u);
+                        hint_win = wcur;
+                    }
                 } else if (h.kind == KIND_FAR) {
                     cblk = L.dword(LINE_DWORDS - 1u);
                     if (cblk >= nlines) cblk = 0;
@@ -492,7 +501,7 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
         }
         if (COUNT_WORK) {
             xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(stepped));
-            xw[XW_PROBES] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(moved));
+            (void)moved;
         }
         // ---- phase 0 (rows that just arrived or just stepped): getF (rlebwt.cpp:307-314) and the select
         // samples around the bc-th f; the sample loads fly with the next pass's fetches
@@ -509,11 +518,33 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             } else {
                 const uint64_t cf = f == 1u ? C1 : f == 2u ? C2 : f == 3u ? C3 : C4;
                 bc = idx - cf + 1ull;
-                const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
-                samp = sel[f * stride_m + m];
-                phase = 3;  // the sample is used from the next pass on
+                // The line this row was found in may say where psi takes the rows of its window: then the next
+                // window is known now, with no sample read and no round trip for it.  The hint speaks of the F
+                // symbol of the window's first row: it holds for this row when that row lies in f's block too.
+                bool via_hint = false;
+                if (hint_here) {
+                    const uint64_t r0 = (uint64_t)hint_win * S;
+                    if (r0 >= cf && idx >= r0) {
+                        bool exact;
+                        const uint32_t wn = hint_window(hint_w0, hint_kk, (uint32_t)(idx - r0), &exact);
+                        if (exact && wn < nwin) {
+                            wcur = wlo = whi = wn;
+                            phase = 2;
+                            cont = 0;
+                            tries = 0;
+                            via_hint = true;
+                        }
+                    }
+                }
+                hinted_now = via_hint;
+                if (!via_hint) {
+                    const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
+                    samp = sel[f * stride_m + m];
+                    phase = 3;  // the sample is used from the next pass on
+                }
             }
         }
+        if (COUNT_WORK) xw[XW_PROBES] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hinted_now));
     }
     if (COUNT_WORK && lane == 0u) {
         xw[XW_CYCLES] = __builtin_amdgcn_s_memtime() - t_begin;

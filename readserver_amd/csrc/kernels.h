@@ -111,6 +111,9 @@ hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, 
 hipError_t launch_debug_fast_window(const void *d_p, size_t n, uint32_t S, void *d_w, void *d_r, hipStream_t stream);
 uint64_t select_sample_stride(const shard_view &ix);
 hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStream_t stream);
+// psi hints inside the window lines that have room for one (line_format.h); after the samples.  *d_made (optional,
+// zeroed by the caller) counts the lines that got one
+hipError_t launch_psi_hints(const shard_view &ix, const uint64_t *d_sel, unsigned long long *d_made, hipStream_t stream);
 // extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
 hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint64_t *d_sel, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,

@@ -265,6 +265,53 @@ select_sample_kernel(const shard_view ix, uint64_t *__restrict__ sel, uint64_t s
     }
 }
 
+// psi hints (line_format.h): one thread per window.  Needs the select samples (the window of an occurrence).
+__global__ void __launch_bounds__(256)
+psi_hint_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t stride_m, uint32_t *__restrict__ lines,
+                unsigned long long *__restrict__ made) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ix.nwin) return;
+    const uint32_t S = ix.sp.S;
+    uint32_t *Ln = lines + line_of_window(w) * LINE_DWORDS;
+    const line_meta m = parse_line(Ln);
+    if (m.kind != KIND_WHOLE || m.hint) return;
+    uint32_t np = 0;  // pieces the line holds: a hint needs the last 8 piece bytes free
+    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
+        if ((dword_piece(Ln + HDR_DWORDS, i) & 31u) == 0u) break;
+        ++np;
+    }
+    if (np > HINT_PIECES) return;
+    const uint64_t r0 = w * (uint64_t)S;
+    uint32_t f = 0;
+    while (f < 4u && ix.C[f + 1] <= r0) ++f;  // F symbol of row r0 (getF, rlebwt.cpp:307-314)
+    if (f == 0u) return;                       // '$' rows end a walk: nobody takes psi of them
+    const uint64_t tot = ix.total[f];
+    const uint64_t bc0 = r0 - ix.C[f] + 1ull;  // row r0 is the bc0-th f
+    if (bc0 < 1ull || bc0 > tot) return;
+    uint64_t seff = tot - bc0 + 1ull;          // rows of this window that belong to f's block
+    if (seff > S) seff = S;
+    if (r0 + seff > ix.n) seff = ix.n - r0;
+    bool exact;
+    const uint32_t w0 = sample_window(sel[f * stride_m + ((bc0 - 1ull) >> SEL_SHIFT)], bc0, &exact);
+    if (!exact || w0 >= ix.nwin) return;
+    // the sample must be right: count(w0) < bc0 <= count(w0 + 1)
+    if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, (uint64_t)w0 + 1, f))) return;
+    uint32_t kk = 0;
+    uint64_t upto = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t c = count_before_window(ix, (uint64_t)w0 + 1 + j, f);
+        upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
+        if (upto > seff) upto = seff;
+        if (j < 3) kk |= (uint32_t)((upto ? upto : 1ull) - 1ull) << (10u * j);
+    }
+    if (upto >= seff) kk |= 1u << 30;  // none past w0 + 3
+    Ln[LINE_DWORDS - 2] = w0;
+    Ln[LINE_DWORDS - 1] = kk;
+    __threadfence();
+    Ln[1] |= 1u << (8u + HINT_META0_BIT);  // the flag last: a reader that sees it sees the hint
+    if (made) atomicAdd(made, 1ull);
+}
+
 // getOccAt with the sample table naming the window (BPTree::select's role)
 __device__ uint64_t thread_occ_at_sampled(const shard_view &ix, const uint64_t *__restrict__ sel,
                                           uint64_t stride_m, uint32_t b, uint64_t bc) {
@@ -801,6 +848,13 @@ hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStrea
     if (ix.nwin == 0) return hipSuccess;
     hipLaunchKernelGGL(select_sample_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel,
                        select_sample_stride(ix));
+    return hipGetLastError();
+}
+
+hipError_t launch_psi_hints(const shard_view &ix, const uint64_t *d_sel, unsigned long long *d_made, hipStream_t stream) {
+    if (ix.nwin == 0 || ix.sp.S > HINT_MAX_SPAN) return hipSuccess;
+    hipLaunchKernelGGL(psi_hint_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel, select_sample_stride(ix),
+                       const_cast<uint32_t *>(ix.lines), d_made);
     return hipGetLastError();
 }
 

@@ -31,6 +31,13 @@
 //                  continues the window (more than 120 pieces, or the spill line was full)
 //   dwords 8..31   96 piece bytes (unused = 0; a valid piece has len >= 1)
 //   $ before the window = w*S - (A + C + G + T).
+//   PSI HINT (bit 21 of meta_0 set; only kind = 0 lines with at most 88 pieces, S <= 1024): dwords 30 and 31
+//   do not hold pieces but where psi takes the ROWS w*S .. w*S + S - 1 (read extraction's select,
+//   src/bwt/query.cpp:72-80): those rows are consecutive occurrences of one symbol f (the F symbol of row
+//   w*S), which lie in a few consecutive windows of the BWT: dword 30 = the window w0 of the first of them,
+//   dword 31 = k0 | k1 << 10 | k2 << 20 | last << 30 with k_j + 1 = how many of them lie in windows <= w0 + j
+//   and last = 1 when none lies past w0 + 3.  Written by a pass of its own once a shard's select samples exist
+//   (kernels.hip, psi_hint_kernel); no search ever looks at it (a lookup never reads past its window's pieces).
 //
 // SPILL LINE (line 17g + 16 of group g) = chunks at even dwords, each
 //   dword 0   totA | totC << 12 | (csym & 0xFF) << 24      tot_x = # of x in the 96 own pieces of
@@ -74,6 +81,9 @@ constexpr uint32_t CHUNK_MAX_PIECES = 24;
 constexpr uint32_t GROUP_SHIFT = 4;    // 16 window lines + 1 spill line
 constexpr uint32_t GROUP = 1u << GROUP_SHIFT;
 constexpr uint32_t KIND_WHOLE = 0, KIND_CHUNK = 1, KIND_FAR = 2;
+constexpr uint32_t HINT_PIECES = 88;       // own pieces of a line whose last two dwords are a psi hint
+constexpr uint32_t HINT_META0_BIT = 21;    // bit of meta_0 (= bit 29 of dword 1) saying so
+constexpr uint32_t HINT_MAX_SPAN = 1024;   // k_j fit 10 bits
 constexpr uint32_t COUNT_BITS = 40;
 constexpr uint64_t COUNT_MASK = (1ull << COUNT_BITS) - 1;
 constexpr uint64_t MAX_SYMBOLS = 1ull << 40;  // per shard; counts are 40-bit
@@ -109,7 +119,7 @@ RSB_HD uint64_t spill_line_of_window(uint64_t w) { return ((w >> GROUP_SHIFT) * 
 
 struct line_meta {
     uint64_t cnt[4];
-    uint32_t s1, s2, s3, span, kind, cdw;
+    uint32_t s1, s2, s3, span, kind, cdw, hint;
     uint32_t half[4];
 };
 
@@ -122,6 +132,7 @@ RSB_HD line_meta parse_line(const uint32_t *L) {
     }
     m.s1 = meta[0] & 0x3FFu;
     m.s2 = (meta[0] >> 10) & 0x7FFu;
+    m.hint = (meta[0] >> HINT_META0_BIT) & 1u;
     m.s3 = m.s2 + (meta[1] & 0x3FFu);
     m.span = m.s3 + ((meta[1] >> 10) & 0x3FFu);
     m.kind = (meta[1] >> 20) & 3u;
@@ -143,7 +154,7 @@ RSB_HD void walk_window(const shard_view &v, uint64_t w, F &&f) {
     for (uint32_t guard = 0; guard < 64; ++guard) {  // a window has at most S <= 2944 pieces = 33 lines
         const uint32_t *L = v.lines + line * LINE_DWORDS;
         const line_meta m = parse_line(L);
-        const uint32_t own = m.kind == KIND_FAR ? FAR_PIECES : LINE_PIECES;
+        const uint32_t own = m.kind == KIND_FAR ? FAR_PIECES : m.hint ? HINT_PIECES : LINE_PIECES;
         for (uint32_t i = 0; i < own; ++i) {
             const uint32_t u = dword_piece(L + HDR_DWORDS, i);
             if ((u & 31u) == 0u) break;
@@ -176,6 +187,14 @@ RSB_HD uint64_t count_before_window(const shard_view &v, uint64_t w, uint32_t b)
     uint64_t s = 0;
     for (int t = 0; t < 4; ++t) s += (((uint64_t)(L[2 * t + 1] & 0xFFu)) << 32) | L[2 * t];
     return w * v.sp.S - s;
+}
+
+// psi hint (above): the window of the r-th row of the hinted window (r = 0 .. S-1); *exact = false: beyond what
+// the hint knows (more than four target windows, r past the third boundary)
+RSB_HD uint32_t hint_window(uint32_t w0, uint32_t kk, uint32_t r, bool *exact) {
+    const uint32_t k0 = kk & 0x3FFu, k1 = (kk >> 10) & 0x3FFu, k2 = (kk >> 20) & 0x3FFu;
+    *exact = r <= k2 || ((kk >> 30) & 1u) != 0u;
+    return w0 + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u);
 }
 
 // RLEBWT::getOcc (src/bwt/rlebwt.cpp:268-301): # of symbol b in BWT[0..p], p < n.

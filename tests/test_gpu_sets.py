@@ -295,3 +295,82 @@ def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path)
     s1.close(); s2.close()
     for g in one + two:
         g.close()
+
+
+@pytest.mark.parametrize("style,span", [("pop", 0), ("pop", 300), ("mixed", 0), ("mixed", 1024), ("dense", 90), ("long", 0)])
+def test_gpu_psi_hints_change_nothing_but_the_requests(rsb, oracle, style, span):
+    """Window lines with room for it carry a psi hint (where psi takes the rows of the window: csrc/line_format.h),
+    written into the resident index when a shard's select samples are built.  It must (1) leave every other answer
+    as it was -- Occ at every position, getChar, getOccAt, findInterval with and without the table, the 1-mismatch
+    matrices: the hint sits in piece bytes and behind a header bit no reader may take for data; (2) give the same
+    reads as the walk without hints (RSBWT_NO_PSI_HINTS) and as the oracle."""
+    import os
+    L = rsb.lib()
+    rng = np.random.default_rng(len(style) * 31 + span)
+    R = 250000
+    if style in ("pop", "mixed"):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 4242 | ((1 << 62) if style == "pop" else 0)) == 0
+    elif style == "dense":
+        runs = (rng.integers(0, 5, R).astype(np.uint8) << 5) | 1
+    else:
+        runs = (np.where(rng.random(R) < 0.02, 0, rng.integers(1, 5, R)).astype(np.uint8) << 5) | 31
+    oix = oracle.from_runs(runs)
+    n = oix.bwlen()
+    rows = rng.integers(0, n, 30000).astype(np.uint64)
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (20000, 14))]
+    elo, eup = oix.find_intervals(km)
+
+    def extract(g):
+        out = np.zeros((rows.size, 1024), np.uint8)
+        ln, pl = np.empty(rows.size, np.uint32), np.empty(rows.size, np.uint32)
+        assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
+        return out, ln, pl
+
+    os.environ["RSBWT_NO_PSI_HINTS"] = "1"
+    try:
+        with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as plain:
+            o0, l0, p0 = extract(plain)
+            assert L.rsbwt_psi_hint_lines(plain.handle) == 0
+    finally:
+        del os.environ["RSBWT_NO_PSI_HINTS"]
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as g:
+        before = rsb.find_intervals(g, km)
+        o1, l1, p1 = extract(g)  # builds the samples and writes the hints
+        hints = L.rsbwt_psi_hint_lines(g.handle)
+        S = g.window_span()
+        if S <= 1024 and style != "dense":
+            assert hints > 0, (hints, g.num_lines())
+            if span == 0:  # the span the builder chooses leaves ~88 pieces per window: about half the lines have room
+                assert hints > 0.2 * (g.num_lines() * 16 // 17), (hints, g.num_lines())
+        assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
+        fit = l1 != 0xFFFFFFFF
+        for i in np.nonzero(fit)[0][::1]:
+            assert np.array_equal(o0[i, :l0[i]], o1[i, :l1[i]]), i
+        for i in np.nonzero(fit)[0][::29]:
+            pre, post = oix.extract(int(rows[i]), cap=4096)
+            assert o1[i, :l1[i]].tobytes().decode() == pre + post and p1[i] == len(pre)
+        # every other reader, after the hints are in the lines
+        after = rsb.find_intervals(g, km)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+        assert np.array_equal(after[0], elo) and np.array_equal(after[1], eup)
+        pos = np.arange(0, n, 1, dtype=np.uint64) if n < 3000000 else np.arange(0, n, 3, dtype=np.uint64)
+        tot = np.zeros(pos.size, np.uint64)
+        for ch in "$ACGT":
+            tot += g.occ_batch(ch, pos)
+        assert np.array_equal(tot, pos + 1)
+        for ch in "ACGT":
+            t = oix.occ(ch, n - 1)
+            if t:
+                bc = rng.integers(1, t + 1, 3000).astype(np.uint64)
+                idx = g.occ_at_batch(ch, bc)
+                assert (g.char_batch(idx) == ord(ch)).all() and np.array_equal(g.occ_batch(ch, idx), bc)
+                assert all(int(idx[j]) == oix.occ_at(ch, int(bc[j])) for j in range(0, 3000, 101))
+        samp = pos[::max(1, pos.size // 20000)]
+        assert all(int(o) == oix.occ("G", int(p_)) for o, p_ in zip(g.occ_batch("G", samp)[::40], samp[::40]))
+        lo1, up1 = rsb.find_intervals_1mm(g, km[:200])
+        assert np.array_equal(lo1[:, 0], elo[:200]) and np.array_equal(up1[:, 0], eup[:200])
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=None) as g2:  # no table: every step through the lines
+        extract(g2)
+        lo, up = rsb.find_intervals(g2, km)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)

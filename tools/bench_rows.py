@@ -175,7 +175,7 @@ torch.cuda.synchronize()
 xw = (C.c_uint64 * 16)()
 ok(L.rsbwt_last_search_counters(g.handle, xw))
 ok(L.rsbwt_set_counting(g.handle, 0))
-names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "count_word_probes"]
+names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "steps_from_line_hint"]
 walk_counters = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
 if STRIDE != 512:  # walks are cut at the buffer's end: the steps actually taken, from the kernels' counters
     steps = S * (walk_counters["prefix"]["steps"] + walk_counters["postfix"]["steps"])

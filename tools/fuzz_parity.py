@@ -97,23 +97,24 @@ while time.time() < t_end:
                         sh, first = ss.hits_1mm(km[:60])
                         ok2 = ok2 and np.array_equal(sh[int(first[0]):int(first[1])], rsb.hits_1mm_batch(g, km[:60]))
                         ok2 = ok2 and np.array_equal(sh[int(first[1]):int(first[2])], rsb.hits_1mm_batch(g2, km[:60]))
-                    try:  # (rows of an interval are extracted: keep it small; streams with hardly any '$' have reads longer than any buffer)
-                        qs = ss.query(km[:300:2], read_stride=2048) if n < 3000000 else None
+                    # query() in every shard, lists concatenated per k-mer -- for k-mers whose intervals are narrow in
+                    # both shards (every row of an interval is extracted into a 2 KB buffer: a 1-mer's would be gigabytes)
+                    w1 = np.where(eup[:5000] >= elo[:5000], eup[:5000] - elo[:5000] + 1, 0)
+                    w2 = np.where(e2up >= e2lo, e2up - e2lo + 1, 0)
+                    narrow = np.nonzero((w1 <= 32) & (w2 <= 32))[0][:150]
+                    try:  # (streams with hardly any '$' have reads longer than any buffer)
+                        qs = ss.query(km[narrow], read_stride=2048) if narrow.size else None
                     except rsb.RsbwtError:
                         qs = None
                     if qs is not None:
-                        for qi, lst in zip(range(0, 300, 2), qs):
+                        for qi, lst in zip(narrow, qs):
                             exp = []
                             for si, (ox, lo_, up_) in enumerate(((oix, elo, eup), (oix2, e2lo, e2up))):
-                                if up_[qi] >= lo_[qi] and up_[qi] - lo_[qi] < 64:
+                                if exp is not None and up_[qi] >= lo_[qi]:
                                     try:
                                         exp += [(si, "".join(ox.extract(int(r), cap=2000))) for r in range(int(lo_[qi]), int(up_[qi]) + 1)]
                                     except AssertionError:
                                         exp = None
-                                        break
-                                elif up_[qi] >= lo_[qi]:
-                                    exp = None
-                                    break
                             if exp is not None and all(len(t) <= 2048 for _, t in exp):
                                 ok2 = ok2 and lst == exp
                     ss.close()
