@@ -430,6 +430,14 @@ void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6);
 int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
                                uint64_t *stats6, uint64_t *first_bad);
 
+/* Test hook (host only, answers no query): the select samples and psi hints of read extraction -- the code the
+ * builder kernels and the walk kernels share with the host (csrc/line_format.h) -- built over a host-side layout of
+ * `runs` and held to the naive select at EVERY occurrence and EVERY row, then every scalar reader again over the
+ * lines that now carry hints.  stats4 = {sample words, occurrences whose sample is only a bound, lines with a
+ * hint, rows answered by a hint}; *first_bad as above. */
+int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span, uint64_t *stats4,
+                                   uint64_t *first_bad);
+
 /* Test hook (answers no query): overwrites n bytes of the index in HBM -- region 0: the window lines,
  * 1: the handle's own k-mer table -- so that tests can hold the kernels to what they do with a DAMAGED
  * index: no read outside the index, every wave drains, a table entry that is not an interval of this BWT

@@ -154,6 +154,7 @@ SIGNATURES = {
     "rsbwt_set_search_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_last_search_counters": (C.c_int, [_vp, _u64p]),
     "rsbwt_layout_selftest_host": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u64p, _u64p]),
+    "rsbwt_layout_selftest_psi_host": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u64p, _u64p]),
     "rsbwt_debug_fast_window": (C.c_int, [_vp, C.c_size_t, C.c_uint32, _vp, _vp, C.c_int]),
     "rsbwt_debug_poke": (C.c_int, [_vp, C.c_int, C.c_uint64, _vp, C.c_size_t]),
     "rsbwt_set_shard": (_vp, [_vp, C.c_size_t]),

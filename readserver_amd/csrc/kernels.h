@@ -120,16 +120,7 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, con
                                hipStream_t stream, unsigned long long *d_work = nullptr);
 // d_work (counting mode): WORK_WORDS counters, zeroed by the caller: words 0-7 the prefix walk, 8-15 the
 // postfix walk (extract_lines.hip, XW_*)
-constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences (its four count bytes assume exactly that)
-// the window of the bc-th occurrence from its block's sample; *exact = false: only a lower bound
-RSB_HD uint32_t sample_window(uint64_t word, uint64_t bc, bool *exact) {
-    const uint32_t r = (uint32_t)((bc - 1) & ((1u << SEL_SHIFT) - 1u));
-    const uint32_t k0 = (uint32_t)(word >> 32) & 0xFFu, k1 = (uint32_t)(word >> 40) & 0xFFu;
-    const uint32_t k2 = (uint32_t)(word >> 48) & 0xFFu, k3 = (uint32_t)(word >> 56);
-    *exact = r <= k3;
-    return (uint32_t)word + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u) + (r > k3 ? 1u : 0u);
-}
-
+// (SEL_SHIFT, sample_window, window_samples, window_psi_hint: line_format.h -- shared with the host-side layout test)
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
                               const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream);

@@ -235,34 +235,8 @@ __global__ void __launch_bounds__(256)
 select_sample_kernel(const shard_view ix, uint64_t *__restrict__ sel, uint64_t stride_m) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= ix.nwin) return;
-    for (uint32_t c = 0; c <= 4; ++c) {
-        // (held to the symbol's total: the sample index below is then inside the table whatever the lines
-        // say -- a damaged count word would otherwise send this loop writing far outside it)
-        const uint64_t tc = ix.total[c];
-        uint64_t cb = count_before_window(ix, w, c);
-        uint64_t ce = count_before_window(ix, w + 1, c);
-        ce = ce < tc ? ce : tc;
-        if (ce <= cb) continue;
-        // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
-        uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT;
-        if ((m << SEL_SHIFT) >= ce) continue;
-        uint64_t upto[4] = {ce, 0, 0, 0};
-        for (int j = 1; j < 4; ++j) {
-            const uint64_t x = count_before_window(ix, w + 1 + j, c);
-            upto[j] = x < tc ? x : tc;
-            if (upto[j] < upto[j - 1]) upto[j] = upto[j - 1];  // monotone whatever the lines say
-        }
-        for (; (m << SEL_SHIFT) < ce; ++m) {
-            const uint64_t before = m << SEL_SHIFT;  // occurrences before the block
-            uint64_t word = w & 0xFFFFFFFFull;
-            for (int j = 0; j < 4; ++j) {
-                uint64_t kj = upto[j] - before;  // >= 1 for j = 0
-                kj = kj > 256 ? 256 : kj;
-                word |= (kj - 1) << (32 + 8 * j);
-            }
-            sel[c * stride_m + m] = word;
-        }
-    }
+    for (uint32_t c = 0; c <= 4; ++c)
+        window_samples(ix, w, c, [&](uint64_t m, uint64_t word) { sel[c * stride_m + m] = word; });
 }
 
 // psi hints (line_format.h): one thread per window.  Needs the select samples (the window of an occurrence).
@@ -271,40 +245,9 @@ psi_hint_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t 
                 unsigned long long *__restrict__ made) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= ix.nwin) return;
-    const uint32_t S = ix.sp.S;
+    uint32_t w0, kk;
+    if (!window_psi_hint(ix, sel, stride_m, w, &w0, &kk)) return;
     uint32_t *Ln = lines + line_of_window(w) * LINE_DWORDS;
-    const line_meta m = parse_line(Ln);
-    if (m.kind != KIND_WHOLE || m.hint) return;
-    uint32_t np = 0;  // pieces the line holds: a hint needs the last 8 piece bytes free
-    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
-        if ((dword_piece(Ln + HDR_DWORDS, i) & 31u) == 0u) break;
-        ++np;
-    }
-    if (np > HINT_PIECES) return;
-    const uint64_t r0 = w * (uint64_t)S;
-    uint32_t f = 0;
-    while (f < 4u && ix.C[f + 1] <= r0) ++f;  // F symbol of row r0 (getF, rlebwt.cpp:307-314)
-    if (f == 0u) return;                       // '$' rows end a walk: nobody takes psi of them
-    const uint64_t tot = ix.total[f];
-    const uint64_t bc0 = r0 - ix.C[f] + 1ull;  // row r0 is the bc0-th f
-    if (bc0 < 1ull || bc0 > tot) return;
-    uint64_t seff = tot - bc0 + 1ull;          // rows of this window that belong to f's block
-    if (seff > S) seff = S;
-    if (r0 + seff > ix.n) seff = ix.n - r0;
-    bool exact;
-    const uint32_t w0 = sample_window(sel[f * stride_m + ((bc0 - 1ull) >> SEL_SHIFT)], bc0, &exact);
-    if (!exact || w0 >= ix.nwin) return;
-    // the sample must be right: count(w0) < bc0 <= count(w0 + 1)
-    if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, (uint64_t)w0 + 1, f))) return;
-    uint32_t kk = 0;
-    uint64_t upto = 0;
-    for (uint32_t j = 0; j < 4; ++j) {
-        const uint64_t c = count_before_window(ix, (uint64_t)w0 + 1 + j, f);
-        upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
-        if (upto > seff) upto = seff;
-        if (j < 3) kk |= (uint32_t)((upto ? upto : 1ull) - 1ull) << (10u * j);
-    }
-    if (upto >= seff) kk |= 1u << 30;  // none past w0 + 3
     Ln[LINE_DWORDS - 2] = w0;
     Ln[LINE_DWORDS - 1] = kk;
     __threadfence();
@@ -838,11 +781,7 @@ hipError_t launch_debug_fast_window(const void *d_p, size_t n, uint32_t S, void 
     return hipGetLastError();
 }
 
-uint64_t select_sample_stride(const shard_view &ix) {
-    uint64_t mx = 0;
-    for (int c = 0; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
-    return (mx >> SEL_SHIFT) + 2;
-}
+uint64_t select_sample_stride(const shard_view &ix) { return select_stride(ix); }
 
 hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStream_t stream) {
     if (ix.nwin == 0) return hipSuccess;

@@ -268,6 +268,107 @@ RSB_HD uint64_t view_occ_at(const shard_view &v, uint32_t b, uint64_t bc, uint64
 }
 
 // ---------------------------------------------------------------------------------------------
+// Select samples and psi hints (read extraction's getOccAt, src/bwt/rlebwt.cpp:233-266): what the builder
+// kernels write (kernels.hip) and the host-side layout test checks, one piece of code for both.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences (its four count bytes assume exactly that)
+
+// entries per symbol of the sample table
+RSB_HD uint64_t select_stride(const shard_view &ix) {
+    uint64_t mx = 0;
+    for (int c = 0; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
+    return (mx >> SEL_SHIFT) + 2;
+}
+
+// Sample word of the block of 256 occurrences of a symbol that starts with occurrence (m << SEL_SHIFT) + 1:
+// bits 0..31 = the window w0 holding that first occurrence, then four bytes k0..k3 with k_j + 1 = how many of
+// the block's occurrences lie in windows <= w0 + j (capped at 256).  The window of the block's r-th occurrence
+// (r = 0..255) is w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while r <= k3, a lower bound beyond
+// (the block spreads over more than five windows).
+RSB_HD uint32_t sample_window(uint64_t word, uint64_t bc, bool *exact) {
+    const uint32_t r = (uint32_t)((bc - 1) & ((1u << SEL_SHIFT) - 1u));
+    const uint32_t k0 = (uint32_t)(word >> 32) & 0xFFu, k1 = (uint32_t)(word >> 40) & 0xFFu;
+    const uint32_t k2 = (uint32_t)(word >> 48) & 0xFFu, k3 = (uint32_t)(word >> 56);
+    *exact = r <= k3;
+    return (uint32_t)word + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u) + (r > k3 ? 1u : 0u);
+}
+
+// The sample words of the blocks of symbol c whose first occurrence lies in window w: emit(m, word).
+template <class E>
+RSB_HD void window_samples(const shard_view &ix, uint64_t w, uint32_t c, E &&emit) {
+    // (held to the symbol's total: the sample index is then inside the table whatever the lines say -- a
+    // damaged count word would otherwise send the caller writing far outside it)
+    const uint64_t tc = ix.total[c];
+    const uint64_t cb = count_before_window(ix, w, c);
+    uint64_t ce = count_before_window(ix, w + 1, c);
+    ce = ce < tc ? ce : tc;
+    if (ce <= cb) return;
+    // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
+    uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT;
+    if ((m << SEL_SHIFT) >= ce) return;
+    uint64_t upto[4] = {ce, 0, 0, 0};
+    for (int j = 1; j < 4; ++j) {
+        const uint64_t x = count_before_window(ix, w + 1 + j, c);
+        upto[j] = x < tc ? x : tc;
+        if (upto[j] < upto[j - 1]) upto[j] = upto[j - 1];  // monotone whatever the lines say
+    }
+    for (; (m << SEL_SHIFT) < ce; ++m) {
+        const uint64_t before = m << SEL_SHIFT;  // occurrences before the block
+        uint64_t word = w & 0xFFFFFFFFull;
+        for (int j = 0; j < 4; ++j) {
+            uint64_t kj = upto[j] - before;  // >= 1 for j = 0
+            kj = kj > 256 ? 256 : kj;
+            word |= (kj - 1) << (32 + 8 * j);
+        }
+        emit(m, word);
+    }
+}
+
+// The psi hint of window w (above, WINDOW LINE): true when the line may carry one, with its two dwords.
+RSB_HD bool window_psi_hint(const shard_view &ix, const uint64_t *sel, uint64_t stride_m, uint64_t w, uint32_t *w0_out,
+                            uint32_t *kk_out) {
+    const uint32_t S = ix.sp.S;
+    if (S > HINT_MAX_SPAN) return false;
+    const uint32_t *Ln = ix.lines + line_of_window(w) * LINE_DWORDS;
+    const line_meta m = parse_line(Ln);
+    if (m.kind != KIND_WHOLE || m.hint) return false;
+    uint32_t np = 0;  // pieces the line holds: a hint needs the last 8 piece bytes free
+    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
+        if ((dword_piece(Ln + HDR_DWORDS, i) & 31u) == 0u) break;
+        ++np;
+    }
+    if (np > HINT_PIECES) return false;
+    const uint64_t r0 = w * (uint64_t)S;
+    uint32_t f = 0;
+    while (f < 4u && ix.C[f + 1] <= r0) ++f;  // F symbol of row r0 (getF, rlebwt.cpp:307-314)
+    if (f == 0u) return false;                 // '$' rows end a walk: nobody takes psi of them
+    const uint64_t tot = ix.total[f];
+    if (r0 < ix.C[f]) return false;
+    const uint64_t bc0 = r0 - ix.C[f] + 1ull;  // row r0 is the bc0-th f
+    if (bc0 > tot) return false;
+    uint64_t seff = tot - bc0 + 1ull;          // rows of this window that belong to f's block
+    if (seff > S) seff = S;
+    if (r0 + seff > ix.n) seff = ix.n - r0;
+    bool exact;
+    const uint32_t w0 = sample_window(sel[f * stride_m + ((bc0 - 1ull) >> SEL_SHIFT)], bc0, &exact);
+    if (!exact || w0 >= ix.nwin) return false;
+    // the sample must be right: count(w0) < bc0 <= count(w0 + 1)
+    if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, (uint64_t)w0 + 1, f))) return false;
+    uint32_t kk = 0;
+    uint64_t upto = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t c = count_before_window(ix, (uint64_t)w0 + 1 + j, f);
+        upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
+        if (upto > seff) upto = seff;
+        if (j < 3) kk |= (uint32_t)((upto ? upto : 1ull) - 1ull) << (10u * j);
+    }
+    if (upto >= seff) kk |= 1u << 30;  // none past w0 + 3
+    *w0_out = w0;
+    *kk_out = kk;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The builder's core, shared by the GPU kernels (build_lines.hip) and the host-side layout test.
 // ---------------------------------------------------------------------------------------------
 

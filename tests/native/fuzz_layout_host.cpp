@@ -13,6 +13,8 @@
 
 extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
                                           uint64_t *stats6, uint64_t *first_bad);
+extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
+                                              uint64_t *stats4, uint64_t *first_bad);
 
 static uint64_t s = 0xD1B54A32D192ED03ull;
 static uint64_t rnd() {
@@ -23,6 +25,7 @@ static uint64_t rnd() {
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 60;
     const uint32_t spans[] = {0, 2, 3, 17, 64, 300, 915, 2233, 2944};
+    uint64_t hint_lines = 0, hinted_rows = 0;
     for (int it = 0; it < iters; ++it) {
         const uint64_t R = 1 + rnd() % 30000;
         const int shape = it % 6;
@@ -44,7 +47,18 @@ int main(int argc, char **argv) {
                     (unsigned long long)R, span, rc, (unsigned long long)bad);
             return 1;
         }
+        // the select samples and psi hints over the same stream: every occurrence, every row, every reader again
+        uint64_t st4[4] = {0, 0, 0, 0};
+        const int rc2 = rsbwt_layout_selftest_psi_host(runs.data(), R, span, st4, &bad);
+        if (rc2 != RSBWT_OK) {
+            fprintf(stderr, "iteration %d (samples / hints): shape %d, %llu runs, span %u: rc %d, first bad %llu\n", it, shape,
+                    (unsigned long long)R, span, rc2, (unsigned long long)bad);
+            return 1;
+        }
+        hint_lines += st4[2];
+        hinted_rows += st4[3];
     }
-    printf("%d run streams laid out and checked at every position\n", iters);
+    printf("%d run streams laid out and checked at every position; %llu lines with a psi hint answered %llu rows\n", iters,
+           (unsigned long long)hint_lines, (unsigned long long)hinted_rows);
     return 0;
 }

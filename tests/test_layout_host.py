@@ -76,3 +76,33 @@ def test_layout_code_under_address_and_ub_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr
     r = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("style,R,span", [("synth", 60000, 0), ("pop", 80000, 0), ("pop", 80000, 300), ("pop", 60000, 1024),
+                                          ("dense", 30000, 90), ("long", 30000, 0), ("mixed", 60000, 0), ("rand", 40000, 0),
+                                          ("desert", 60000, 0), ("rand", 1, 0), ("rand", 97, 5), ("rand", 3000, 2)])
+def test_select_samples_and_psi_hints_are_exact(rsb, style, R, span):
+    """The select samples name the window of EVERY occurrence (or bound it from below where they say so), a psi hint
+    that claims to be exact names the window psi takes EVERY row of its window to, and the lines that carry hints
+    still answer Occ / getChar / getOccAt like the naive BWT at every position -- host run of the code the GPU runs."""
+    L = rsb.lib()
+    rng = np.random.default_rng(R * 7 + span)
+    if style == "pop":
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 77 | (1 << 62)) == 0
+    elif style == "desert":  # stretches without one symbol: sample blocks spread over many windows
+        sym = np.where((np.arange(R) // 7000) % 2 == 0, rng.integers(0, 5, R), rng.integers(0, 4, R))
+        runs = ((sym.astype(np.uint8)) << 5) | rng.integers(1, 9, R).astype(np.uint8)
+    else:
+        runs = _runs(style, R, rng, L)
+    st = (C.c_uint64 * 4)()
+    bad = C.c_uint64()
+    rc = L.rsbwt_layout_selftest_psi_host(runs.ctypes.data, R, span, st, C.byref(bad))
+    assert rc == 0, f"first disagreement at {bad.value}"
+    words, inexact, hint_lines, by_hint = list(st)
+    n = int((runs & 31).astype(np.int64).sum())
+    assert words >= n // 256
+    if style == "desert":
+        assert inexact > 0
+    if style == "pop" and span == 0:
+        assert hint_lines > 0.3 * (n // 500) and by_hint > 0.2 * n
