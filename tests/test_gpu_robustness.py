@@ -127,7 +127,9 @@ def test_gpu_wild_counts_do_not_leave_the_index(rsb, kernel, depth):
     all over [0, 2^64) -- the class of failure behind the fault recorded in round 2.  Both search kernels
     must drain and stay inside the index.  A child process, so that a fault cannot take the suite down."""
     lib = os.path.join(ROOT, "tools", "bin", "librsbwt_wildocc.so")
-    assert os.path.exists(lib), "build() makes the fault-injection build; it travels with the snapshot"
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(rsb.lib_path()):
+        # build() makes the fault-injection build and it travels with the snapshot; a box that did not get it makes its own
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "wildocc", "-DRSB_FAULT_INJECT_WILD_OCC"])
     env = dict(os.environ, RSBWT_LIB=lib, RSBWT_SEARCH_KERNEL=kernel)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wildocc_probe.py"), str(depth)], env=env,
                          capture_output=True, text=True, timeout=600)
