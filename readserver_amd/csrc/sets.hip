@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -92,6 +93,22 @@ struct dev_group : search_meter {
     uint64_t *d_ktab = nullptr;      // the interleaved k-mer tables of the shards this set gave one
     ctx_pool pool;
     ncclComm_t comm = nullptr;
+    // side streams for calls that let the group's shards work side by side (small 1-mismatch batches: one shard's
+    // launch does not fill the GPU), forked from and joined to the caller's stream with events; made on first use
+    static constexpr int FORK = 8;
+    hipStream_t fork_st[FORK] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[FORK] = {};
+    std::mutex fork_mu;
+    int ensure_fork() {
+        if (fork_ev) return RSBWT_OK;
+        for (int i = 0; i < FORK; ++i) {
+            if (hipStreamCreateWithFlags(&fork_st[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming) != hipSuccess)
+                return fail(RSBWT_EHIP, "cannot create the side streams of a shard set");
+        }
+        if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return fail(RSBWT_EHIP, "cannot create an event");
+        return RSBWT_OK;
+    }
 };
 
 struct rsbwt_set {
@@ -196,6 +213,14 @@ void rsbwt_set_close(rsbwt_set_t *s) {
                 if (!s->owns && s->shards[i]) (void)detach_ktab(s->shards[i]);
             (void)hipFree(g->d_ktab);
         }
+        for (int i = 0; i < dev_group::FORK; ++i) {
+            if (g->fork_st[i]) {
+                (void)hipStreamSynchronize(g->fork_st[i]);
+                (void)hipStreamDestroy(g->fork_st[i]);
+            }
+            if (g->join_ev[i]) (void)hipEventDestroy(g->join_ev[i]);
+        }
+        if (g->fork_ev) (void)hipEventDestroy(g->fork_ev);
         if (g->d_views) (void)hipFree(g->d_views);
         if (g->d_work) (void)hipFree(g->d_work);
         g->scratch.destroy();
@@ -764,11 +789,22 @@ int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
 
 // Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
 // The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
-size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
+// A batch below this many variant searches per shard does not fill the GPU from one shard's launches: the shards
+// of the set then work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to
+// the caller's stream with events), instead of taking turns.
+static constexpr size_t SIDE_BY_SIDE_BELOW = (size_t)1 << 24;
+
+static size_t hits_1mm_scratch_one(const rsbwt_set_t *s, size_t m, uint32_t k) {
     size_t need = 0;
-    if (s)
-        for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_hits_1mm_scratch_bytes(h, m, k));
-    return need;
+    for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_hits_1mm_scratch_bytes(h, m, k));
+    return (need + 255) & ~(size_t)255;
+}
+
+size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
+    if (!s) return 0;
+    const size_t one = hits_1mm_scratch_one(s, m, k);
+    const bool side = s->shards.size() > 1 && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
+    return side ? one * s->shards.size() : one;
 }
 
 // d_hits: [num_shards][cap_per_shard] records of 32 B (rsbwt_hits_1mm_dev's), d_totals: u64[num_shards]
@@ -777,12 +813,41 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     if (!s) return fail(RSBWT_EINVAL, "null set");
     if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
     if (!d_totals || (!d_hits && cap_per_shard)) return fail(RSBWT_EINVAL, "null argument");
-    for (size_t i = 0; i < s->shards.size(); ++i) {
-        const int rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32,
-                                          cap_per_shard, (uint8_t *)d_totals + i * 8, d_scratch, stream);
-        if (rc) return rc;
+    dev_group *g = s->groups[0];
+    const size_t S = s->shards.size();
+    static const bool turns_only = getenv("RSBWT_SET_1MM_TURNS") != nullptr;  // A/B knob (tools/README.md)
+    const bool side = !turns_only && S > 1 && m && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
+    if (!side) {
+        for (size_t i = 0; i < S; ++i) {
+            const int rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32,
+                                              cap_per_shard, (uint8_t *)d_totals + i * 8, d_scratch, stream);
+            if (rc) return rc;
+        }
+        return RSBWT_OK;
     }
-    return RSBWT_OK;
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g->fork_mu);  // one fork / join sequence at a time uses the side streams' events
+    if ((rc = g->ensure_fork()) != RSBWT_OK) return rc;
+    const size_t one = hits_1mm_scratch_one(s, m, k);
+    HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));
+    for (size_t i = 0; i < S; ++i) {
+        hipStream_t st = g->fork_st[i % dev_group::FORK];
+        HIP_OK(hipStreamWaitEvent(st, g->fork_ev, 0));
+        rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32, cap_per_shard,
+                                (uint8_t *)d_totals + i * 8, (uint8_t *)d_scratch + (i % dev_group::FORK) * one, st);
+        if (rc) break;
+        if (i + dev_group::FORK >= S) {  // the last shard of each side stream: its event joins the caller's stream
+            HIP_OK(hipEventRecord(g->join_ev[i % dev_group::FORK], st));
+            HIP_OK(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0));
+        }
+    }
+    if (rc) {  // whatever was enqueued still finishes before the caller's stream goes on
+        for (int i = 0; i < dev_group::FORK; ++i) {
+            if (hipEventRecord(g->join_ev[i], g->fork_st[i]) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i], 0);
+        }
+    }
+    return rc;
 }
 
 // d_rows: [num_shards][n] SA rows (row numbers are per shard); d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]
