@@ -753,9 +753,9 @@ def run_rows(a, c):
                 verified = (all(int(blocks[r].sum(dtype=torch.int64).item()) == int(sums[r][0].item()) for r in range(world))
                             and int(first[-1]) == sum(int(x[1].item()) for x in sums) and rec.shape[0] == int(first[-1]))
         alg = w[2] * LINE_BYTES + S * M * V * 24 + hits_local * 48
-        # below 2^24 variant searches per shard the set's shards work side by side on streams of their own
+        # below 2^26 variant searches per shard the set's shards work side by side on streams of their own
         # (csrc/sets.hip): their kernels overlap, so the sum of their durations says nothing -- the step is priced
-        side_by_side = S > 1 and M * V < (1 << 24) and "RSBWT_SET_1MM_TURNS" not in os.environ
+        side_by_side = S > 1 and M * V < (1 << int(os.environ.get("RSBWT_SET_1MM_SIDE_LOG2", "26"))) and "RSBWT_SET_1MM_TURNS" not in os.environ
         if side_by_side:
             kms = dt / a.steps * 1e3
         out = {

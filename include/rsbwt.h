@@ -349,8 +349,7 @@ int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
 /* Device-resident forms, for a set on ONE device (one process per GPU: bench.py --mode 1mm|extract).
  * d_hits [num_shards][cap_per_shard] x 32-byte records (rsbwt_hits_1mm_dev's), d_totals u64[num_shards];
  * d_rows [num_shards][n] (row numbers are per shard), d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]. */
-/* (a batch of fewer than 2^24 variant searches per shard does not fill the GPU from one shard's launches: the
- * shards then work side by side on streams of the set, forked from and joined to `stream`, each with a scratch of its
+/* (below 2^26 variant searches per shard the shards work side by side on streams of the set, forked from and joined to `stream`, each with a scratch of its
  * own -- rsbwt_set_hits_1mm_scratch_bytes accounts for that) */
 size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k);
 int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,

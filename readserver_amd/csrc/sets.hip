@@ -789,10 +789,21 @@ int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
 
 // Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
 // The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
-// A batch below this many variant searches per shard does not fill the GPU from one shard's launches: the shards
-// of the set then work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to
-// the caller's stream with events), instead of taking turns.
-static constexpr size_t SIDE_BY_SIDE_BELOW = (size_t)1 << 24;
+// Below this many variant searches per shard (2^26 = 7e5 31-mers; a scratch per shard is what bounds it) the shards of
+// the set work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to the
+// caller's stream with events), instead of taking turns: a shard's own sequence -- variants, start records, the traced
+// and the resumed search, three small compaction launches -- leaves gaps and tails another shard's kernels fill
+// (8 resident 20 GB shards, per batch: 4e4 31-mers 5.7 -> 4.3 ms, 1e5 9.4 -> 7.8, 4e5 30.7 -> 27.9:
+// profiles/r03_set_side_by_side.json).
+static size_t side_by_side_below() {
+    static const size_t v = [] {
+        const char *e = getenv("RSBWT_SET_1MM_SIDE_LOG2");  // A/B knob (tools/README.md)
+        const int b = e ? atoi(e) : 0;
+        return (size_t)1 << (b >= 10 && b <= 40 ? b : 26);
+    }();
+    return v;
+}
+#define SIDE_BY_SIDE_BELOW side_by_side_below()
 
 static size_t hits_1mm_scratch_one(const rsbwt_set_t *s, size_t m, uint32_t k) {
     size_t need = 0;
@@ -850,19 +861,48 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     return rc;
 }
 
-// d_rows: [num_shards][n] SA rows (row numbers are per shard); d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]
+// d_rows: [num_shards][n] SA rows (row numbers are per shard); d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n].
+// The shards' walks run side by side on streams of the set (forked from and joined to `stream`): a walk kernel ends in
+// a tail -- the last rows of a launch are its longest reads -- that another shard's rows fill.
 int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
                           void *d_prefix_len, void *stream) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
     if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
     if (n == 0) return RSBWT_OK;
     if (!d_rows || !d_out || !d_len || !d_prefix_len) return fail(RSBWT_EINVAL, "null argument");
-    for (size_t i = 0; i < s->shards.size(); ++i) {
-        const int rc = rsbwt_extract_dev(s->shards[i], (const uint8_t *)d_rows + i * n * 8, n, (uint8_t *)d_out + i * n * (size_t)stride,
-                                         stride, (uint8_t *)d_len + i * n * 4, (uint8_t *)d_prefix_len + i * n * 4, stream);
-        if (rc) return rc;
+    dev_group *g = s->groups[0];
+    const size_t S = s->shards.size();
+    auto one = [&](size_t i, hipStream_t st) {
+        return rsbwt_extract_dev(s->shards[i], (const uint8_t *)d_rows + i * n * 8, n, (uint8_t *)d_out + i * n * (size_t)stride,
+                                 stride, (uint8_t *)d_len + i * n * 4, (uint8_t *)d_prefix_len + i * n * 4, st);
+    };
+    static const bool turns_only = getenv("RSBWT_SET_EXTRACT_TURNS") != nullptr;  // A/B knob (tools/README.md)
+    if (S == 1 || turns_only) {
+        for (size_t i = 0; i < S; ++i) {
+            const int rc = one(i, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        return RSBWT_OK;
     }
-    return RSBWT_OK;
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g->fork_mu);
+    if ((rc = g->ensure_fork()) != RSBWT_OK) return rc;
+    HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));
+    for (size_t i = 0; i < S; ++i) {
+        hipStream_t st = g->fork_st[i % dev_group::FORK];
+        HIP_OK(hipStreamWaitEvent(st, g->fork_ev, 0));
+        if ((rc = one(i, st)) != RSBWT_OK) break;
+        if (i + dev_group::FORK >= S) {
+            HIP_OK(hipEventRecord(g->join_ev[i % dev_group::FORK], st));
+            HIP_OK(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0));
+        }
+    }
+    if (rc) {
+        for (int i = 0; i < dev_group::FORK; ++i)
+            if (hipEventRecord(g->join_ev[i], g->fork_st[i]) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i], 0);
+    }
+    return rc;
 }
 
 int rsbwt_rccl_available(void) { return rccl().ok ? 1 : 0; }
