@@ -942,6 +942,7 @@ def cpu_baseline(a, host_runs, d_kmers, d_lower, d_upper, Q, k):
     lo, up = ix.find_intervals(km, nthreads=threads)
     dt = time.perf_counter() - t0
     match = bool(np.array_equal(lo, glo) and np.array_equal(up, gup))
+    ref = reference_beside_port(threads)
     return {
         "value": m / dt, "unit": "queries/s", "cores": threads, "kind": "port",
         "sample": f"{m} of the batch's {Q} k-mers (evenly spaced) on shard 0 (one of the resident shards: per-shard "
@@ -951,7 +952,53 @@ def cpu_baseline(a, host_runs, d_kmers, d_lower, d_upper, Q, k):
         "single_thread_sample": f"{m1} other k-mers, run first on the cold index",
         "host_cpus_visible": os.cpu_count(), "index_build_s": round(t_index, 2),
         "gpu_matches_oracle_on_sample": match,
+        "reference_beside_port": ref,
     }
+
+
+def reference_beside_port(threads):
+    """The REAL reference (oracle/_ref/libref_bwt.so: ReadServer's own src/bwt sources compiled in the build
+    container, shipped with the working tree) beside the port (oracle/rlebwt_oracle.c) on this host's cores: the
+    golden popBWT fixture (9.1e6 symbols, cache-resident: the reference is sound on it, tests/golden/make_golden.py),
+    4e5 31-mers, same answers required.  Relates the port's numbers above to the reference; None where the compiled
+    reference did not travel."""
+    import ctypes as C
+    import tempfile
+    lib = os.path.join(ROOT, "oracle", "_ref", "libref_bwt.so")
+    gold = os.path.join(ROOT, "tests", "golden")
+    if not os.path.exists(lib):
+        return None
+    try:
+        import oracle_binding
+        import readserver_amd as rsb
+        meta = json.load(open(os.path.join(gold, "popbwt_v1.json")))
+        g = np.load(os.path.join(gold, "popbwt_v1.npz"))
+        km = np.ascontiguousarray(np.tile(g["kmers31"][:10000], (40, 1)))
+        Q, k = km.shape
+        R = C.CDLL(lib)
+        R.ref_open.restype = C.c_void_p
+        R.ref_open.argtypes = [C.c_char_p]
+        R.ref_find_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        out = {"index": "tests/golden popBWT fixture, %d symbols" % meta["num_symbols"], "kmers": Q}
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "popbwt_v1.bwt")
+            rsb.synth_popbwt(path, None, **meta["synth"])
+            h = R.ref_open(path.encode())
+            oix = oracle_binding.load().load(path)
+            lo, up = np.empty(Q, np.uint64), np.empty(Q, np.uint64)
+            for t in (1, threads):
+                t0 = time.perf_counter()
+                R.ref_find_intervals(h, km.ctypes.data, Q, k, k, lo.ctypes.data, up.ctypes.data, t)
+                tr = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                olo, oup = oix.find_intervals(km, nthreads=t)
+                to = time.perf_counter() - t0
+                same = bool(np.array_equal(lo, olo) and np.array_equal(up, oup))
+                out["%d_threads" % t] = {"reference_queries_per_s": Q / tr, "port_queries_per_s": Q / to, "reference_over_port": to / tr,
+                                         "same_answers": same}
+        return out
+    except Exception as e:  # the checker's checker must not take the bench line down
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":
