@@ -786,24 +786,37 @@ def run_rows(a, c):
         # of `run` consecutive SA rows at random places of every shard
         starts = torch.randint(0, max(n_sym - run, 1), (S, (NR + run - 1) // run), generator=gen, device=dev, dtype=torch.int64)
         rows = (starts[:, :, None] + torch.arange(run, device=dev)[None, None, :]).reshape(S, -1)[:, :NR].contiguous()
-        gat_o = sharded.BlockGatherer((S, NR, stride), torch.uint8, cdev, depth=2)
-        gat_l = sharded.BlockGatherer((S, NR), torch.int32, cdev, depth=2)
-        d_o = [torch.empty((S, NR, stride), dtype=torch.uint8, device=dev) for _ in range(2)] if cdev != dev else None
-        d_l = [torch.empty((S, NR), dtype=torch.int32, device=dev) for _ in range(2)] if cdev != dev else None
+        if stride % 16:
+            raise SystemExit("bench.py --mode extract: --stride must be a multiple of 16")
+        # results stay in HBM as [S][NR][stride] ASCII + lengths; what travels at N > 1 is their 2-bit form
+        # (rsbwt_pack_reads_dev: a quarter of the bytes) + the lengths, gathered behind the next batch's walks
+        d_full = [torch.empty((S, NR, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_lenb = [torch.empty((S, NR), dtype=torch.int32, device=dev) for _ in range(2)]
+        gat_o = sharded.BlockGatherer((S, NR, stride // 4), torch.uint8, cdev, depth=2) if world > 1 else None
+        gat_l = sharded.BlockGatherer((S, NR), torch.int32, cdev, depth=2) if world > 1 else None
         d_pl = torch.empty((S, NR), dtype=torch.int32, device=dev)
         step_no = [0]
 
         def step():
             i = step_no[0]
             step_no[0] += 1
-            ob, lb = gat_o.acquire(i), gat_l.acquire(i)
-            o_dev, l_dev = (d_o[i % 2], d_l[i % 2]) if d_o is not None else (ob, lb)
+            o_dev, l_dev = d_full[i % 2], d_lenb[i % 2]
             ok(c, L.rsbwt_set_extract_dev(sset._s, ptr(rows), NR, ptr(o_dev), stride, ptr(l_dev), ptr(d_pl), sp))
-            if d_o is not None:
-                ob.copy_(o_dev)
-                lb.copy_(l_dev)
-            gat_o.submit(i)
-            gat_l.submit(i)
+            if world > 1:
+                ob, lb = gat_o.acquire(i), gat_l.acquire(i)
+                if cdev == dev:
+                    sharded.pack_reads(o_dev, l_dev, out=ob)
+                    lb.copy_(l_dev)
+                else:  # rehearsal: packed in HBM, gathered from host copies
+                    ob.copy_(sharded.pack_reads(o_dev, l_dev))
+                    lb.copy_(l_dev)
+                gat_o.submit(i)
+                gat_l.submit(i)
+
+        def drain():
+            if world > 1:
+                gat_o.drain()
+                gat_l.drain()
 
         ok(c, L.rsbwt_set_counting(shards[0].handle, 1))
         step()
@@ -813,7 +826,7 @@ def run_rows(a, c):
         ok(c, L.rsbwt_set_counting(shards[0].handle, 0))
         names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "steps_from_line_hint"]
         walk = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
-        lens0 = (d_l[0] if d_l is not None else gat_l.acquire(0)).to(dev).reshape(-1)
+        lens0 = d_lenb[0].reshape(-1)
         ln = lens0.cpu().numpy().view(np.uint32)
         fits = ln != 0xFFFFFFFF
         bases = int(ln[fits].astype(np.int64).sum())
@@ -821,25 +834,35 @@ def run_rows(a, c):
         steps_alg = bases + 2 * int(fits.sum()) + int((~fits).sum()) * stride
         for _ in range(a.warmup):
             step()
-        gat_o.drain(); gat_l.drain(); barrier()
+        drain(); barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter()
         ev0.record()
         for _ in range(a.steps):
             step()
         ev1.record()
-        gat_o.drain(); gat_l.drain(); barrier()
+        drain(); barrier()
         dt = max_over_ranks(time.perf_counter() - t1)
         k_ms = ev0.elapsed_time(ev1) / a.steps  # the walk kernels of one batch (current stream; the gather runs beside them)
         verified = None
         if world > 1:
             last = step_no[0] - 1
-            mine = torch.stack([gat_o.acquire(last).sum(dtype=torch.int64), gat_l.acquire(last).sum(dtype=torch.int64)]).to(cdev)
+            sent, sent_l = gat_o.acquire(last), gat_l.acquire(last)
+            # the 2-bit form carries this rank's reads exactly: unpacked, it is the ASCII bytes up to every read's length
+            full, ln_d = d_full[last % 2], d_lenb[last % 2]
+            back = sharded.unpack_reads(sent.to(dev), ln_d)
+            lnc = torch.where(ln_d < 0, torch.zeros_like(ln_d), ln_d).to(torch.int64)
+            masked = torch.where(torch.arange(stride, device=dev)[None, None, :] < lnc[..., None], full, torch.zeros_like(full))
+            exact = torch.tensor([int(torch.equal(back, masked))], dtype=torch.int64, device=cdev)
+            del back, masked
+            mine = torch.stack([sent.sum(dtype=torch.int64), sent_l.sum(dtype=torch.int64)]).to(cdev)
             sums = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(sums, mine)
+            dist.all_reduce(exact, op=dist.ReduceOp.MIN)
             if rank == 0:
                 reads_all, lens_all = sharded.concat_reads(gat_o.result(last), gat_l.result(last))
-                verified = (reads_all.shape[0] == world * S and int(reads_all.sum(dtype=torch.int64).item()) == sum(int(x[0].item()) for x in sums)
+                verified = (bool(exact.item()) and reads_all.shape[0] == world * S
+                            and int(reads_all.sum(dtype=torch.int64).item()) == sum(int(x[0].item()) for x in sums)
                             and int(lens_all.sum(dtype=torch.int64).item()) == sum(int(x[1].item()) for x in sums))
         out = {
             "metric": "reads located and extracted per second on popBWT (BASELINE configs[4])",
@@ -853,7 +876,7 @@ def run_rows(a, c):
                            rows_per_shard=NR, row_run=run, stride=stride, rows_fitting_stride=int(fits.sum()) / max(ln.size, 1),
                            mean_read_length=bases / max(int(fits.sum()), 1), reads_verified=verified, walk_counters_one_shard=walk,
                            window_lines_with_a_psi_hint=int(L.rsbwt_psi_hint_lines(shards[0].handle)) / max(int(shards[0].num_lines()) * 16 // 17, 1),
-                           travels=(None if world == 1 else f"[{S}][{NR}][{stride}] read bytes + lengths per rank and batch")),
+                           travels=(None if world == 1 else f"[{S}][{NR}][{stride // 4}] bytes of 2-bit bases (rsbwt_pack_reads_dev) + [{S}][{NR}] lengths per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel, over the rank's shards",

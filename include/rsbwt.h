@@ -191,6 +191,12 @@ int rsbwt_find_interval_pairs_dev(rsbwt_t *h, const void *d_packed, const void *
 size_t rsbwt_packed_pairs_bytes(size_t n);
 int rsbwt_pack_interval_pairs_dev(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, int device, void *stream);
 int rsbwt_unpack_interval_pairs_dev(const void *d_packed, size_t n, void *d_pairs, int device, void *stream);
+/* Extracted reads for the wire: [n][stride] ASCII bytes (rsbwt_extract_dev's d_out) + their lengths <-> [n][stride / 4]
+ * bytes, 2 bits per base (A, C, G, T = 0..3, base i at bits 2 (i % 4) of byte i / 4; zeros past a read's end and for a
+ * read marked UINT32_MAX).  stride % 16 == 0.  What a rank sends of an extraction batch at N > 1: a quarter of the
+ * bytes over xGMI; the lengths travel beside it.  Unpacking restores the bytes up to each read's length (NUL beyond). */
+int rsbwt_pack_reads_dev(const void *d_reads, const void *d_len, size_t n, uint32_t stride, void *d_packed, int device, void *stream);
+int rsbwt_unpack_reads_dev(const void *d_packed, const void *d_len, size_t n, uint32_t stride, void *d_reads, int device, void *stream);
 /* 1-mismatch search of m packed k-mers: d_lower/d_upper [m][3k+1] (rsbwt_find_intervals_1mm's layout);
  * d_scratch: rsbwt_1mm_scratch_bytes(h, m, k) bytes. */
 size_t rsbwt_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k);

@@ -85,6 +85,8 @@ SIGNATURES = {
     "rsbwt_packed_pairs_bytes": (C.c_size_t, [C.c_size_t]),
     "rsbwt_pack_interval_pairs_dev": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "rsbwt_unpack_interval_pairs_dev": (C.c_int, [_vp, C.c_size_t, _vp, C.c_int, _vp]),
+    "rsbwt_pack_reads_dev": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, C.c_int, _vp]),
+    "rsbwt_unpack_reads_dev": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, C.c_int, _vp]),
     "rsbwt_hits_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),
     "rsbwt_hits_1mm_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp, _vp, _vp]),
     "rsbwt_set_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),

@@ -899,6 +899,26 @@ int rsbwt_unpack_interval_pairs_dev(const void *d_packed, size_t n, void *d_pair
     return e == hipSuccess ? RSBWT_OK : fail_hip(e, "unpack kernel launch");
 }
 
+int rsbwt_pack_reads_dev(const void *d_reads, const void *d_len, size_t n, uint32_t stride, void *d_packed, int device, void *stream) {
+    if (n == 0) return RSBWT_OK;
+    if (!d_reads || !d_len || !d_packed) return fail(RSBWT_EINVAL, "null argument");
+    if (stride == 0 || stride % 16u) return fail(RSBWT_EINVAL, "stride %u: a multiple of 16 bytes", stride);
+    int rc = use_device(device);
+    if (rc) return rc;
+    const hipError_t e = launch_pack_reads2(d_reads, d_len, n, stride, d_packed, (hipStream_t)stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "read packing kernel launch");
+}
+
+int rsbwt_unpack_reads_dev(const void *d_packed, const void *d_len, size_t n, uint32_t stride, void *d_reads, int device, void *stream) {
+    if (n == 0) return RSBWT_OK;
+    if (!d_reads || !d_len || !d_packed) return fail(RSBWT_EINVAL, "null argument");
+    if (stride == 0 || stride % 16u) return fail(RSBWT_EINVAL, "stride %u: a multiple of 16 bytes", stride);
+    int rc = use_device(device);
+    if (rc) return rc;
+    const hipError_t e = launch_unpack_reads2(d_packed, d_len, n, stride, d_reads, (hipStream_t)stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "read unpacking kernel launch");
+}
+
 int rsbwt_find_intervals(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,
                          uint64_t *lower, uint64_t *upper) {
     return search_host(h, kmers, Q, k, stride, lower, upper, false);

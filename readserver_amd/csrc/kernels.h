@@ -104,6 +104,9 @@ hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t 
 // pairs that do not fit the record (none does for an interval findInterval produced)
 hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, hipStream_t stream);
 hipError_t launch_unpack_pairs10(const void *d_packed, size_t n, void *d_pairs, hipStream_t stream);
+// extracted reads <-> 2 bits per base ([n][stride] ASCII + lengths <-> [n][stride / 4] bytes; stride % 16 == 0)
+hipError_t launch_pack_reads2(const void *d_reads, const void *d_len, size_t n, uint32_t stride, void *d_packed, hipStream_t stream);
+hipError_t launch_unpack_reads2(const void *d_packed, const void *d_len, size_t n, uint32_t stride, void *d_reads, hipStream_t stream);
 hipError_t launch_variants(const void *d_packed, const void *d_valid, size_t Q, uint32_t k, void *d_vpacked,
                            void *d_vvalid, hipStream_t stream);
 // read extraction: sampled select table (5 x stride u64: for every 256th occurrence of each symbol its

@@ -738,6 +738,73 @@ hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t 
     return hipGetLastError();
 }
 
+// Extracted reads for the wire: [n][stride] ASCII bytes + lengths -> [n][stride / 4] bytes, 2 bits per base (A, C, G, T
+// = 0..3, base i at bits 2 * (i % 4) of byte i / 4), zeros past a read's end (and for a read marked as not fitting).
+// One thread per output dword = 16 bases; stride is a multiple of 16.
+__global__ void __launch_bounds__(256)
+pack_reads2_kernel(const uint8_t *__restrict__ reads, const uint32_t *__restrict__ len, size_t n, uint32_t stride,
+                   uint32_t *__restrict__ out) {
+    const uint32_t per = stride / 16u;  // dwords per read
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * per) return;
+    const size_t r = i / per;
+    const uint32_t d = (uint32_t)(i - r * per);
+    uint32_t ln = len[r];
+    if (ln == 0xFFFFFFFFu) ln = 0;
+    const uint4 v = *reinterpret_cast<const uint4 *>(reads + r * (size_t)stride + 16u * d);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t code = ((w[q] >> 1) ^ (w[q] >> 2)) & 0x03030303u;  // A 0, C 1, G 2, T 3 in every byte
+        const uint32_t c8 = (code | (code >> 6) | (code >> 12) | (code >> 18)) & 0xFFu;
+        o |= c8 << (8 * q);
+    }
+    const uint32_t base0 = 16u * d;  // first base this dword holds
+    const uint32_t keep = ln <= base0 ? 0u : ln - base0 >= 16u ? 32u : 2u * (ln - base0);  // bits of it inside the read
+    out[i] = keep >= 32u ? o : (o & ((1u << keep) - 1u));
+}
+
+__global__ void __launch_bounds__(256)
+unpack_reads2_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ len, size_t n, uint32_t stride,
+                     uint8_t *__restrict__ reads) {
+    const uint32_t per = stride / 16u;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * per) return;
+    const size_t r = i / per;
+    const uint32_t d = (uint32_t)(i - r * per);
+    uint32_t ln = len[r];
+    if (ln == 0xFFFFFFFFu) ln = 0;
+    const uint32_t x = in[i];
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t pos = 16u * d + 4u * q + b;
+            const uint32_t c = (x >> (8 * q + 2 * b)) & 3u;
+            const uint32_t ch = pos < ln ? ((0x54474341u >> (8u * c)) & 0xFFu) : 0u;  // "ACGT"[c], NUL past the end
+            o |= ch << (8 * b);
+        }
+        w[q] = o;
+    }
+    *reinterpret_cast<uint4 *>(reads + r * (size_t)stride + 16u * d) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+hipError_t launch_pack_reads2(const void *d_reads, const void *d_len, size_t n, uint32_t stride, void *d_packed, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_reads2_kernel, dim3(blocks256(n * (stride / 16u))), dim3(256), 0, stream, (const uint8_t *)d_reads,
+                       (const uint32_t *)d_len, n, stride, (uint32_t *)d_packed);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_reads2(const void *d_packed, const void *d_len, size_t n, uint32_t stride, void *d_reads, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_reads2_kernel, dim3(blocks256(n * (stride / 16u))), dim3(256), 0, stream, (const uint32_t *)d_packed,
+                       (const uint32_t *)d_len, n, stride, (uint8_t *)d_reads);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_pairs10_kernel, dim3(blocks256((n + 3) / 4)), dim3(256), 0, stream, (const ulonglong2 *)d_pairs, n,

@@ -269,3 +269,50 @@ def concat_reads(blocks, lens):
     """Reads of every rank's shards side by side: blocks[r] = [S_local, n, stride] uint8, lens[r] = [S_local, n];
     returns ([world * S_local, n, stride], [world * S_local, n]) in global shard order."""
     return torch.cat(list(blocks), 0), torch.cat(list(lens), 0)
+
+
+def pack_reads(reads, lens, out=None):
+    """[..., n, stride] uint8 ASCII reads + [..., n] int32 lengths -> [..., n, stride // 4] uint8, 2 bits per base
+    (include/rsbwt.h, rsbwt_pack_reads_dev: A, C, G, T = 0..3, zeros past a read's end).  On a GPU tensor the
+    library's kernel does it; the torch form serves host tensors (gloo tests, the one-GPU rehearsal)."""
+    stride = reads.shape[-1]
+    flat, fl = reads.reshape(-1, stride), lens.reshape(-1)
+    n = flat.shape[0]
+    if out is None or out.device != flat.device:
+        out = torch.empty(reads.shape[:-1] + (stride // 4,), dtype=torch.uint8, device=flat.device)
+    if flat.is_cuda:
+        from ._native import lib
+        import ctypes as C
+        rc = lib().rsbwt_pack_reads_dev(C.c_void_p(flat.data_ptr()), C.c_void_p(fl.data_ptr()), n, stride, C.c_void_p(out.data_ptr()),
+                                        flat.device.index or 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib().rsbwt_last_error().decode())
+        return out
+    ln = torch.where(fl < 0, torch.zeros_like(fl), fl).to(torch.int64)  # (UINT32_MAX reads as -1)
+    code = ((flat >> 1) ^ (flat >> 2)) & 3
+    code = torch.where(torch.arange(stride)[None, :] < ln[:, None], code, torch.zeros_like(code)).reshape(n, stride // 4, 4)
+    out.reshape(n, stride // 4).copy_(code[..., 0] | (code[..., 1] << 2) | (code[..., 2] << 4) | (code[..., 3] << 6))
+    return out
+
+
+def unpack_reads(packed, lens, out=None):
+    """The inverse: [..., n, stride] ASCII bytes up to each read's length, NUL beyond."""
+    stride = packed.shape[-1] * 4
+    flat, fl = packed.reshape(-1, stride // 4), lens.reshape(-1)
+    n = flat.shape[0]
+    if out is None:
+        out = torch.empty(packed.shape[:-1] + (stride,), dtype=torch.uint8, device=flat.device)
+    if flat.is_cuda:
+        from ._native import lib
+        import ctypes as C
+        rc = lib().rsbwt_unpack_reads_dev(C.c_void_p(flat.data_ptr()), C.c_void_p(fl.data_ptr()), n, stride, C.c_void_p(out.data_ptr()),
+                                          flat.device.index or 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib().rsbwt_last_error().decode())
+        return out
+    ln = torch.where(fl < 0, torch.zeros_like(fl), fl).to(torch.int64)
+    code = torch.stack([(flat >> (2 * b)) & 3 for b in range(4)], -1).reshape(n, stride).to(torch.int64)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+    ch = lut[code]
+    out.reshape(n, stride).copy_(torch.where(torch.arange(stride)[None, :] < ln[:, None], ch, torch.zeros_like(ch)))
+    return out

@@ -265,3 +265,28 @@ def test_world2_hit_lists_and_reads_are_concatenated_in_shard_order():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_read_packing_round_trips_on_the_host():
+    """2 bits per base for the wire (what a rank sends of an extraction batch): pack -> unpack gives the ASCII bytes up
+    to each read's length, NUL beyond; a read marked as not fitting (length -1 = UINT32_MAX) travels as nothing."""
+    import torch
+    from readserver_amd import sharded
+    g = torch.Generator().manual_seed(3)
+    n, stride = 500, 64
+    lens = torch.randint(0, stride + 1, (n,), generator=g, dtype=torch.int32)
+    lens[7] = -1
+    lens[8] = 0
+    lens[9] = stride
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+    reads = lut[torch.randint(0, 4, (n, stride), generator=g)]
+    reads[torch.arange(stride)[None, :] >= lens.clamp(min=0)[:, None].long()] = 0x7E  # garbage past the end must not travel
+    packed = sharded.pack_reads(reads, lens)
+    assert packed.shape == (n, stride // 4) and packed.dtype == torch.uint8
+    back = sharded.unpack_reads(packed, lens)
+    want = torch.where(torch.arange(stride)[None, :] < lens.clamp(min=0)[:, None].long(), reads, torch.zeros_like(reads))
+    assert torch.equal(back, want)
+    assert not packed[7].any() and not packed[8].any()
+    # shapes with leading dimensions ([S][n][stride], as bench.py holds them)
+    p3 = sharded.pack_reads(reads.reshape(5, 100, stride), lens.reshape(5, 100))
+    assert p3.shape == (5, 100, stride // 4) and torch.equal(p3.reshape(n, -1), packed)

@@ -374,3 +374,25 @@ def test_gpu_psi_hints_change_nothing_but_the_requests(rsb, oracle, style, span)
         extract(g2)
         lo, up = rsb.find_intervals(g2, km)
         assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+
+
+def test_gpu_read_packing_kernels_match_the_host_form(rsb):
+    """rsbwt_pack_reads_dev / rsbwt_unpack_reads_dev against the torch form of readserver_amd/sharded.py."""
+    import torch
+    from readserver_amd import sharded
+    g = torch.Generator().manual_seed(5)
+    for n, stride in ((1, 16), (777, 48), (4096, 256), (33, 512)):
+        lens = torch.randint(0, stride + 1, (n,), generator=g, dtype=torch.int32)
+        lens[0] = -1
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+        reads = lut[torch.randint(0, 4, (n, stride), generator=g)]
+        reads[torch.arange(stride)[None, :] >= lens.clamp(min=0)[:, None].long()] = 0x58
+        want = sharded.pack_reads(reads, lens)
+        got = sharded.pack_reads(reads.cuda(), lens.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want), (n, stride)
+        back = sharded.unpack_reads(got, lens.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(back.cpu(), sharded.unpack_reads(want, lens)), (n, stride)
+    L = rsb.lib()
+    assert L.rsbwt_pack_reads_dev(C.c_void_p(got.data_ptr()), C.c_void_p(got.data_ptr()), 4, 20, C.c_void_p(got.data_ptr()), 0, None) == -1
