@@ -131,7 +131,11 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
     // characters are produced right to left: four at a time go out as one aligned dword when the row
     // buffers allow it (a byte store per character is a request per character)
     const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
-    uint32_t chars = 0;
+    // ... and SIXTEEN at a time as one aligned 16-byte store when they allow that: every store is a request of its
+    // own (lanes write into rows of their own), and at a dword per four steps the stores were a fifth of this
+    // kernel's requests.  q0..q3 = the 16 most recent characters, the most recent in q0's low byte (lowest address).
+    const bool out16 = (stride & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
+    uint32_t chars = 0, q1 = 0, q2 = 0, q3 = 0;  // (chars doubles as q0)
     unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
@@ -142,6 +146,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
             len = 0;
             cont = 0;
             chars = 0;
+            q1 = q2 = q3 = 0;
             have = true;
             if (idx >= ix.n) {
                 plen[r] = 0xFFFFFFFFu;
@@ -243,9 +248,27 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
         bool done = false;
         if (scan) {
             if (c == 0u || c > 4u) {  // '$': the read starts here (query.cpp:52)
-                if (packed_out)  // the characters not yet written: the (len & 3) most recent ones
+                if (out16) {
+                    // the (len & 15) characters not yet written sit in q0..q3 from the low byte up, the oldest next to
+                    // the 16-byte boundary B: whole dwords go out aligned to B (a funnel shift lines them up), then
+                    // the (len & 3) most recent bytes
+                    const uint32_t rem = len & 15u, nd = rem >> 2, sh = rem & 3u;
+                    uint8_t *row = out + r * (size_t)stride;
+                    const uint32_t B = stride - (len - rem);
+                    for (uint32_t jj = 0; jj < nd; ++jj) {
+                        const uint32_t di = nd - 1u - jj;
+                        const uint32_t lo_d = di == 0u ? chars : di == 1u ? q1 : q2;
+                        const uint32_t hi_d = di == 0u ? q1 : di == 1u ? q2 : q3;
+                        const uint32_t v = sh == 0u ? lo_d : sh == 1u ? __builtin_amdgcn_alignbyte(hi_d, lo_d, 1u)
+                                                   : sh == 2u ? __builtin_amdgcn_alignbyte(hi_d, lo_d, 2u)
+                                                              : __builtin_amdgcn_alignbyte(hi_d, lo_d, 3u);
+                        *reinterpret_cast<uint32_t *>(row + B - 4u * (jj + 1u)) = v;
+                    }
+                    for (uint32_t t = 0; t < sh; ++t) row[stride - len + t] = (uint8_t)(chars >> (8u * t));
+                } else if (packed_out) {  // the characters not yet written: the (len & 3) most recent ones
                     for (uint32_t t = 0; t < (len & 3u); ++t)
                         out[r * (size_t)stride + (stride - len + t)] = (uint8_t)(chars >> (8u * t));
+                }
                 plen[r] = len;
                 have = false;
             } else if (len == stride) {  // the reference would spin (query.cpp:48)
@@ -253,7 +276,14 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
                 have = false;
             } else {
                 const uint32_t ch = (0x54474341u >> (8u * ci)) & 0xFFu;  // "ACGT"[c-1]
-                if (packed_out) {
+                if (out16) {
+                    q3 = __builtin_amdgcn_alignbyte(q3, q2, 3u);  // (q3:q2:q1:chars) <<= 8
+                    q2 = __builtin_amdgcn_alignbyte(q2, q1, 3u);
+                    q1 = __builtin_amdgcn_alignbyte(q1, chars, 3u);
+                    chars = (chars << 8) | ch;
+                    if ((len & 15u) == 15u)  // address stride-1-len is 16-aligned: the chunk's 16 characters at once
+                        *reinterpret_cast<uint4 *>(out + r * (size_t)stride + (stride - 1u - len)) = make_uint4(chars, q1, q2, q3);
+                } else if (packed_out) {
                     chars = (chars << 8) | ch;  // most recent character in the low byte = lowest address
                     if ((len & 3u) == 3u) {
                         // chars = [c(len-3) c(len-2) c(len-1) c(len)] high to low; memory order is the reverse of
@@ -311,7 +341,10 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
     // characters go out four at a time as aligned dwords when the row buffers allow it; `word` holds the
     // bytes of the dword being filled (low byte = lowest address), seeded with the prefix's last bytes
     const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
-    uint32_t word = 0;
+    // ... sixteen at a time where the buffers allow it (see the prefix kernel): word, w1, w2, w3 = the 16-byte chunk
+    // being filled, byte len & 15 next
+    const bool out16 = (stride & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
+    uint32_t word = 0, w1 = 0, w2 = 0, w3 = 0;
     unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
@@ -328,8 +361,20 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             } else {
                 // (the prefix was moved to the head of the row's buffer by move_prefix_kernel)
                 const uint8_t *buf = out + r * (size_t)stride;
-                word = 0;
-                if (packed_out && (pl & 3u)) word = *reinterpret_cast<const uint32_t *>(buf + (pl & ~3u)) & ((1u << (8u * (pl & 3u))) - 1u);
+                word = w1 = w2 = w3 = 0;
+                if (out16) {
+                    if (pl & 15u) {  // the chunk the prefix ends in: its bytes below pl & 15 are the prefix's
+                        const uint4 e = *reinterpret_cast<const uint4 *>(buf + (pl & ~15u));
+                        const uint32_t kb = pl & 15u;  // bytes to keep
+                        const uint32_t part = (1u << (8u * (kb & 3u))) - 1u;  // of the dword the boundary falls in
+                        word = kb >= 4u ? e.x : e.x & part;
+                        w1 = kb >= 8u ? e.y : kb > 4u ? e.y & part : 0u;
+                        w2 = kb >= 12u ? e.z : kb > 8u ? e.z & part : 0u;
+                        w3 = kb > 12u ? e.w & part : 0u;
+                    }
+                } else if (packed_out && (pl & 3u)) {
+                    word = *reinterpret_cast<const uint32_t *>(buf + (pl & ~3u)) & ((1u << (8u * (pl & 3u))) - 1u);
+                }
                 len = pl;
             }
         }
@@ -482,7 +527,17 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                     have = false;
                 } else {
                     const uint32_t ch = (0x54474341u >> (8u * (f - 1u))) & 0xFFu;  // "ACGT"[f-1]
-                    if (packed_out) {
+                    if (out16) {
+                        const uint32_t sb = ch << (8u * (len & 3u)), di = (len >> 2) & 3u;
+                        word |= di == 0u ? sb : 0u;
+                        w1 |= di == 1u ? sb : 0u;
+                        w2 |= di == 2u ? sb : 0u;
+                        w3 |= di == 3u ? sb : 0u;
+                        if ((len & 15u) == 15u) {
+                            *reinterpret_cast<uint4 *>(out + r * (size_t)stride + (len - 15u)) = make_uint4(word, w1, w2, w3);
+                            word = w1 = w2 = w3 = 0;
+                        }
+                    } else if (packed_out) {
                         word |= ch << (8u * (len & 3u));
                         if ((len & 3u) == 3u) {
                             *reinterpret_cast<uint32_t *>(out + r * (size_t)stride + (len - 3u)) = word;
@@ -508,7 +563,14 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
         if (have && phase == 0u) {
             f = (idx >= C1 ? 1u : 0u) + (idx >= C2 ? 1u : 0u) + (idx >= C3 ? 1u : 0u) + (idx >= C4 ? 1u : 0u);
             if (f == 0u) {  // '$': the read ends here (query.cpp:76)
-                if (packed_out)  // the bytes of the dword still being filled
+                if (out16) {  // the chunk still being filled: its whole dwords, then the last bytes
+                    uint8_t *row = out + r * (size_t)stride;
+                    const uint32_t base = len & ~15u, rem = len & 15u, nd = rem >> 2;
+                    for (uint32_t jj = 0; jj < nd; ++jj)
+                        *reinterpret_cast<uint32_t *>(row + base + 4u * jj) = jj == 0u ? word : jj == 1u ? w1 : w2;
+                    const uint32_t lastw = nd == 0u ? word : nd == 1u ? w1 : nd == 2u ? w2 : w3;
+                    for (uint32_t t = 0; t < (rem & 3u); ++t) row[base + 4u * nd + t] = (uint8_t)(lastw >> (8u * t));
+                } else if (packed_out)  // the bytes of the dword still being filled
                     for (uint32_t k = len & ~3u; k < len; ++k) out[r * (size_t)stride + k] = (uint8_t)(word >> (8u * (k & 3u)));
                 tlen[r] = len;
                 have = false;
