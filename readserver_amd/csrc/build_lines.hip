@@ -154,14 +154,16 @@ __device__ void seek_reader(const seek_index &sx, uint64_t P, run_reader &rd) {
 
 __global__ void __launch_bounds__(256)
 count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint64_t nwin, uint64_t ngroups,
-                    uint32_t *__restrict__ far_lines, unsigned long long *__restrict__ stats) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                    uint32_t *__restrict__ far_lines, unsigned long long *__restrict__ stats, uint64_t every) {
+    // every > 1: a SAMPLE of the groups (every `every`-th one), statistics only -- what the choice of S is tried on
+    // before the one full pass (a full pass reads all the run bytes: 1.2 s for a 20 GB shard)
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * every;
     group_stats st = {0, 0, 0, 0};
     if (g < ngroups) {
         run_reader rd;
         seek_reader(sx, g * GROUP * (uint64_t)sp.S, rd);
         st = build_group<false>(sp, n, nwin, g, rd, nullptr, 0);
-        far_lines[g] = st.far_lines;
+        if (far_lines) far_lines[g] = st.far_lines;
     }
     // statistics: one atomic set per wave
     unsigned long long v[4] = {st.far_lines, st.chunk_windows, st.far_windows, st.spilled_symbols};
@@ -304,6 +306,27 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
         span_params sp = make_span(want_span ? want_span : (uint32_t)(88.0 * L + 0.5));
         seek_index sx = {runs, R, d_chunk, d_tile, nchunks, ntiles};
         uint64_t nwin = 0, ngroups = 0, nsum = 0;
+        // S is first tried on a sample of the groups (one in 64, spread over the whole shard): the spans that
+        // would clearly spill too much are passed over without a full pass each.  The full pass below still
+        // decides: a span the sample let through is shrunk further if the whole shard says so.
+        constexpr uint64_t SAMPLE_EVERY = 64;
+        if (!want_span && (n + sp.S - 1) / sp.S / GROUP >= 64 * SAMPLE_EVERY) {
+            for (int attempt = 0; attempt < 4 && sp.S > 8u; ++attempt) {
+                const uint64_t nw = (n + sp.S - 1) / sp.S, ng = (nw + GROUP - 1) / GROUP, ns = (ng + SAMPLE_EVERY - 1) / SAMPLE_EVERY;
+                HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(count_groups_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, sx, sp, n, nw, ng,
+                                   (uint32_t *)nullptr, d_stats, SAMPLE_EVERY);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                // (held to the limits themselves: a sample within 5 % of them is left to the full pass)
+                const bool ok = stats[3] * SAMPLE_EVERY * 40 <= n + n / 20 && stats[2] * SAMPLE_EVERY * 200 <= (nw + nw / 20) * 3;
+                if (ok) break;
+                const span_params smaller = make_span((uint32_t)((double)sp.S * 0.95));
+                if (smaller.S >= sp.S) break;
+                sp = smaller;
+            }
+        }
         for (int attempt = 0;; ++attempt) {
             nwin = (n + sp.S - 1) / sp.S;
             ngroups = (nwin + GROUP - 1) / GROUP;
@@ -312,7 +335,7 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
             HIP_TRY(hipMalloc(&d_far, ngroups * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(count_groups_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, stream, sx, sp,
-                               n, nwin, ngroups, d_far, d_stats);
+                               n, nwin, ngroups, d_far, d_stats, (uint64_t)1);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
