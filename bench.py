@@ -57,7 +57,11 @@ def parse():
                          "disjoint: every shard its own stream, a present k-mer is in one shard only (round 2's default). "
                          "A one-GPU run measures the other mix too (config.mixes) unless --no-second-mix")
     ap.add_argument("--same-shards", action="store_true", help="(old name of --mix population)")
-    ap.add_argument("--no-second-mix", action="store_true", help="time only --mix (profile passes)")
+    ap.add_argument("--no-second-mix", action="store_true", help="time only --mix (profile passes; also skips the valid-popBWT leg)")
+    ap.add_argument("--valid-popbwt-symbols", type=float, default=-1,
+                    help="third leg of a one-GPU run: the same search on a VALID population BWT built on the GPU (tools/popbwt_bench.py), "
+                         "this many symbols per shard before dedup (8 shards); 0 = skip; default: 3e9 (1.7e10 symbols in all, ~80 s to "
+                         "build) on a full-size run, skipped when --runs is below 1e10")
     ap.add_argument("--piped-start", action="store_true",
                     help="prepare batch i + 1 (packing, start records) on a second stream while batch i is searched, instead of "
                          "pack, start records and search one after the other on one stream (measured slower on the headline mix)")
@@ -592,6 +596,29 @@ def main():
             mixes[other] = {k: o[k] for k in ("value", "queries_per_s_all_shards", "ms_per_step", "mean_lf_steps_per_search",
                                               "lines_per_lf_step", "ktab_depth")} | {"roofline_frac": o["roofline"]["frac"],
                                                                                      "kernel_ms": o["roofline"]["kernel_ms"], "what": MIX_NOTE[other]}
+        vsym = a.valid_popbwt_symbols if a.valid_popbwt_symbols >= 0 else (3e9 if a.runs >= 1e10 else 0)
+        if world == 1 and vsym > 0 and not a.no_second_mix and not a.counts and S > 1:
+            # the same search on a VALID population BWT (the shards above are a random run stream): reads of 64 haplotypes,
+            # RLO sort + dedup, suffix shards, per-shard suffix sort on the GPU -- and the oracle on a sample of it
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import popbwt_bench
+                va = argparse.Namespace(symbols_per_shard=vsym, depth=28.0, haplotypes=64, snp=1e-3, err=0.01, queries=a.queries,
+                                        steps=max(3, a.steps // 2), seed=11, check=False)
+                v = popbwt_bench.run(va)
+                mixes["valid_popbwt"] = {
+                    "value": v["searches_per_s"], "queries_per_s_all_shards": v["queries_per_s"], "ms_per_step": v["ms_per_step"],
+                    "mean_lf_steps_per_search": v["mean_lf_steps_per_search"], "lines_per_lf_step": v["lines_per_lf_step"],
+                    "ktab_depth": v["ktab_depth"], "roofline_frac": v["roofline"]["frac"], "kernel_ms": v["roofline"]["kernel_ms"],
+                    "symbols": v["symbols"], "run_bytes": v["run_bytes"], "index_hbm_bytes": v["index_hbm_bytes"],
+                    "fraction_of_shards_holding_a_genomic_31mer": v["genomic_31mers"]["fraction_of_shards_holding_one"],
+                    "gpu_matches_oracle_on_sample": v["oracle"]["gpu_matches_oracle"], "build_s": v["seconds"],
+                    "what": "8 shards of a VALID 64-shard population BWT built on the GPU (tools/popbwt_bench.py: 64 haplotypes, 28x per "
+                            "shard, 1 % base errors), the same fused search, half genomic / half random 31-mers; out of cache, a tenth of "
+                            "configs[2]'s size per shard",
+                }
+            except Exception as e:  # the headline stands whatever happens to this leg
+                mixes["valid_popbwt"] = {"error": repr(e)}
         out = {
             "metric": "31-mer backward-search queries/sec on popBWT",
             "value": head["value"],

@@ -193,6 +193,11 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--check", action="store_true", help="shard 0's run bytes against the unbucketed builder (small sizes)")
     a = ap.parse_args()
+    print(json.dumps(run(a)))
+
+
+def run(a, log=sys.stderr):
+    """a: symbols_per_shard, depth, haplotypes, snp, err, queries, steps, seed, check.  Returns the record."""
     S, H, k, Q = 8, a.haplotypes, 31, int(a.queries)
     reads_per_shard = int(a.symbols_per_shard / W)
     G = int(reads_per_shard * RL / a.depth)
@@ -226,7 +231,7 @@ def main():
         nreads.append(int(rs.shape[0]))
         del runs, rs
         torch.cuda.empty_cache()
-        print(f"popbwt_bench: shard {s}: {n} symbols, {shards[-1].num_runs()} run bytes, {time.time() - t1:.1f} s", file=sys.stderr, flush=True)
+        print(f"popbwt_bench: shard {s}: {n} symbols, {shards[-1].num_runs()} run bytes, {time.time() - t1:.1f} s", file=log, flush=True)
     del reads, keys
     torch.cuda.empty_cache()
     sset = rsb.ShardSet(shards)
@@ -326,10 +331,12 @@ def main():
                      "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "search_lines_kernel", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": ln},
     }
-    print(json.dumps(out))
     sset.close()
     for g in shards:
         g.close()
+    del d_pairs, d_km, d_pk, d_ok, genome
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
