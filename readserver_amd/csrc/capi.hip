@@ -1053,20 +1053,59 @@ size_t rsbwt_hits_1mm_scratch_bytes(const rsbwt_t *h, size_t m, uint32_t k) {
 }
 
 // the search half: variants -> sparse results + hit map (zeroed here)
+// d_variants != nullptr: the variants of this batch were expanded already (variants_of_batch_dev, by a caller that
+// searches them in several shards): they are read from there instead of being made again in this shard's scratch
 static int hits_search(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, uint8_t *scratch,
-                       hipStream_t stream) {
+                       hipStream_t stream, const void *d_variants = nullptr) {
     const hits_layout L = hits_scratch_layout(h, m, k);
     const size_t V = 3 * (size_t)k + 1, mv = m * V;
-    uint8_t *d_vpk = scratch, *d_vok = d_vpk + ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15), *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
+    const size_t a_vpk = (mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15;
+    uint8_t *d_vpk = scratch, *d_vok = d_vpk + a_vpk, *d_scr = d_vok + ((mv + 15) & ~(size_t)15);
     uint8_t *d_sparse = scratch + L.variants, *d_bits = d_sparse + L.sparse;
     HIP_OK(hipMemsetAsync(d_bits, 0, L.bits, stream));
-    hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, stream);
-    if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+    if (d_variants) {
+        d_vpk = (uint8_t *)d_variants;
+        d_vok = d_vpk + a_vpk;
+    } else {
+        hipError_t e = launch_variants(d_packed, d_valid, m, k, d_vpk, d_vok, stream);
+        if (e != hipSuccess) return fail_hip(e, "variant kernel launch");
+    }
     return search_variants(h, d_packed, d_valid, m, k, d_vpk, d_vok, d_sparse, nullptr, d_scr, stream, d_bits);
 }
 
+}  // extern "C"
+
+namespace rsb {
+// The 3k+1 variants of m packed k-mers (packed words, then validity bytes), for hits_1mm_dev_shared: they depend on
+// the batch alone, so a caller that searches several shards expands them once.
+size_t variants_bytes(size_t m, uint32_t k) {
+    const size_t mv = m * (3 * (size_t)k + 1);
+    return ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15) + ((mv + 15) & ~(size_t)15);
+}
+int variants_of_batch_dev(const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_variants, hipStream_t stream) {
+    const size_t mv = m * (3 * (size_t)k + 1);
+    const hipError_t e = launch_variants(d_packed, d_valid, m, k, d_variants, (uint8_t *)d_variants + ((mv * words_per_kmer(k) * 8 + 15) & ~(size_t)15), stream);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "variant kernel launch");
+}
+static int hits_1mm_dev_impl(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits, size_t cap,
+                             void *d_total, void *d_scratch, void *stream, const void *d_variants);
+int hits_1mm_dev_shared(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits, size_t cap,
+                        void *d_total, void *d_scratch, void *stream, const void *d_variants) {
+    return hits_1mm_dev_impl(h, d_packed, d_valid, m, k, d_hits, cap, d_total, d_scratch, stream, d_variants);
+}
+}  // namespace rsb
+
+extern "C" {
+
 int rsbwt_hits_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,
                        size_t cap, void *d_total, void *d_scratch, void *stream) {
+    return hits_1mm_dev_impl(h, d_packed, d_valid, m, k, d_hits, cap, d_total, d_scratch, stream, nullptr);
+}
+
+}  // extern "C"
+
+static int rsb::hits_1mm_dev_impl(rsbwt_t *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits, size_t cap,
+                                  void *d_total, void *d_scratch, void *stream, const void *d_variants) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
     if (!d_total || (!d_hits && cap)) return fail(RSBWT_EINVAL, "null argument");
     if (m == 0) {
@@ -1078,13 +1117,15 @@ int rsbwt_hits_1mm_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, si
     if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
     int rc = use_device(h->device);
     if (rc) return rc;
-    if ((rc = hits_search(h, d_packed, d_valid, m, k, (uint8_t *)d_scratch, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    if ((rc = hits_search(h, d_packed, d_valid, m, k, (uint8_t *)d_scratch, (hipStream_t)stream, d_variants)) != RSBWT_OK) return rc;
     const hits_layout L = hits_scratch_layout(h, m, k);
     uint8_t *d_sparse = (uint8_t *)d_scratch + L.variants, *d_bits = d_sparse + L.sparse, *d_blocks = d_bits + L.bits;
     const hipError_t e = launch_compact_hits(d_bits, d_sparse, m * (3 * (size_t)k + 1), d_hits, cap, d_total, d_blocks, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hit list kernels");
     return RSBWT_OK;
 }
+
+extern "C" {
 
 int rsbwt_hits_1mm(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride, rsbwt_hit_1mm *hits,
                    size_t cap, size_t *nhits) {

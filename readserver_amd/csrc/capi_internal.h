@@ -69,6 +69,10 @@ inline bool view_is_narrow(const shard_view &v, uint32_t k) {
     return v.ktab && v.ktab_depth >= 2u && k >= v.ktab_depth && ((v.n >> (2u * v.ktab_depth)) << 2) <= v.sp.S;
 }
 int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
+// 1-mismatch hit list of one shard from variants expanded once for the whole batch (sets.hip: every shard of a set
+// searches the same variants)
+size_t variants_bytes(size_t m, uint32_t k);
+int variants_of_batch_dev(const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_variants, hipStream_t stream);
 int meter_work(search_meter &m, uint64_t *words, size_t nwords);
 
 }  // namespace rsb
@@ -87,6 +91,8 @@ struct rsbwt : rsb::search_meter {
 };
 
 namespace rsb {
+int hits_1mm_dev_shared(rsbwt *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits, size_t cap,
+                        void *d_total, void *d_scratch, void *stream, const void *d_variants);
 // Builds h's k-mer table of depth T into d_table[c * stride] (memory owned by the caller).
 int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride);
 int detach_ktab(rsbwt *h);  // forgets a table it does not own

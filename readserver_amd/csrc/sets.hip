@@ -811,11 +811,14 @@ static size_t hits_1mm_scratch_one(const rsbwt_set_t *s, size_t m, uint32_t k) {
     return (need + 255) & ~(size_t)255;
 }
 
+// scratch of a set's hit-list search: the batch's variants, expanded ONCE for all shards (they depend on the k-mers
+// alone), then a slot per shard that works at the same time
 size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
     if (!s) return 0;
     const size_t one = hits_1mm_scratch_one(s, m, k);
     const bool side = s->shards.size() > 1 && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
-    return side ? one * s->shards.size() : one;
+    const size_t slots = side ? std::min<size_t>(s->shards.size(), dev_group::FORK) : 1;
+    return ((variants_bytes(m, k) + 255) & ~(size_t)255) + one * slots;
 }
 
 // d_hits: [num_shards][cap_per_shard] records of 32 B (rsbwt_hits_1mm_dev's), d_totals: u64[num_shards]
@@ -826,28 +829,35 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     if (!d_totals || (!d_hits && cap_per_shard)) return fail(RSBWT_EINVAL, "null argument");
     dev_group *g = s->groups[0];
     const size_t S = s->shards.size();
-    static const bool turns_only = getenv("RSBWT_SET_1MM_TURNS") != nullptr;  // A/B knob (tools/README.md)
-    const bool side = !turns_only && S > 1 && m && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
-    if (!side) {
-        for (size_t i = 0; i < S; ++i) {
-            const int rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32,
-                                              cap_per_shard, (uint8_t *)d_totals + i * 8, d_scratch, stream);
-            if (rc) return rc;
-        }
-        return RSBWT_OK;
-    }
     int rc = use_device(g->device);
     if (rc) return rc;
+    if (m == 0) {
+        HIP_OK(hipMemsetAsync(d_totals, 0, 8 * S, (hipStream_t)stream));
+        return RSBWT_OK;
+    }
+    if (!d_packed || !d_valid || !d_scratch) return fail(RSBWT_EINVAL, "null argument");
+    if (k == 0) return fail(RSBWT_EINVAL, "k must be at least 1");
+    static const bool turns_only = getenv("RSBWT_SET_1MM_TURNS") != nullptr;  // A/B knob (tools/README.md)
+    const bool side = !turns_only && S > 1 && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
+    const size_t one = hits_1mm_scratch_one(s, m, k);
+    uint8_t *d_var = (uint8_t *)d_scratch, *d_slots = d_var + ((variants_bytes(m, k) + 255) & ~(size_t)255);
+    if ((rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    auto one_shard = [&](size_t i, uint8_t *slot, hipStream_t st) {
+        return hits_1mm_dev_shared(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32, cap_per_shard,
+                                   (uint8_t *)d_totals + i * 8, slot, st, d_var);
+    };
+    if (!side) {
+        for (size_t i = 0; i < S; ++i)
+            if ((rc = one_shard(i, d_slots, (hipStream_t)stream)) != RSBWT_OK) return rc;
+        return RSBWT_OK;
+    }
     std::lock_guard<std::mutex> lock(g->fork_mu);  // one fork / join sequence at a time uses the side streams' events
     if ((rc = g->ensure_fork()) != RSBWT_OK) return rc;
-    const size_t one = hits_1mm_scratch_one(s, m, k);
-    HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));
+    HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));  // (behind the variants)
     for (size_t i = 0; i < S; ++i) {
         hipStream_t st = g->fork_st[i % dev_group::FORK];
         HIP_OK(hipStreamWaitEvent(st, g->fork_ev, 0));
-        rc = rsbwt_hits_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32, cap_per_shard,
-                                (uint8_t *)d_totals + i * 8, (uint8_t *)d_scratch + (i % dev_group::FORK) * one, st);
-        if (rc) break;
+        if ((rc = one_shard(i, d_slots + (i % dev_group::FORK) * one, st)) != RSBWT_OK) break;
         if (i + dev_group::FORK >= S) {  // the last shard of each side stream: its event joins the caller's stream
             HIP_OK(hipEventRecord(g->join_ev[i % dev_group::FORK], st));
             HIP_OK(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0));
