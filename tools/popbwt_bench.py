@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--check", action="store_true", help="shard 0's run bytes against the unbucketed builder (small sizes)")
+    ap.add_argument("--rows", type=float, default=0, help="also: extraction of this many rows per shard (the rows of the genomic 31-mers' intervals)")
+    ap.add_argument("--kmers-1mm", type=float, default=0, help="also: 1-mismatch hit lists of this many genomic 31-mers, half with a planted substitution")
     a = ap.parse_args()
     print(json.dumps(run(a)))
 
@@ -309,6 +311,101 @@ def run(a, log=sys.stderr):
     got = d_pairs[0][sel].cpu().numpy().view(np.uint64)
     matches = bool(np.array_equal(got[:, 0], elo) and np.array_equal(got[:, 1], eup))
     units = units_hist[1:].sum()
+    rows_rec = mm_rec = None
+    if getattr(a, "rows", 0):
+        # ---- configs[4] on the valid BWT: locate + extract = the reads of every row of the intervals of genomic 31-mers
+        # (query.cpp:87-100 over every shard): rows in interval order, NR per shard, 128-byte buffers (reads are 100 long)
+        NR, stride = int(a.rows), 128
+        lo_all, up_all = d_pairs[..., 0], d_pairs[..., 1]
+        rows_t = torch.empty((S, NR), dtype=torch.int64, device=dev)
+        for si in range(S):
+            wd = torch.clamp(up_all[si] - lo_all[si] + 1, min=0)
+            wd = torch.where(wd > 64, torch.zeros_like(wd), wd)  # (leave the few very wide intervals out)
+            first = torch.cumsum(wd, 0) - wd
+            total = int(wd.sum().item())
+            owner = torch.repeat_interleave(torch.arange(Q, device=dev), wd)
+            rr = lo_all[si][owner] + (torch.arange(total, device=dev) - first[owner])
+            reps = (NR + total - 1) // max(total, 1)
+            rows_t[si] = rr.repeat(reps)[:NR]
+            del wd, first, owner, rr
+        d_out = torch.empty((S, NR, stride), dtype=torch.uint8, device=dev)
+        d_len = torch.empty((S, NR), dtype=torch.int32, device=dev)
+        d_pl = torch.empty((S, NR), dtype=torch.int32, device=dev)
+        run_x = lambda: ok(L.rsbwt_set_extract_dev(sset._s, p(rows_t), NR, p(d_out), stride, p(d_len), p(d_pl), None))
+        run_x()  # builds the select samples and psi hints of every shard
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run_x()
+        ev0.record()
+        for _ in range(3):
+            run_x()
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 3
+        lens = d_len.cpu().numpy()
+        all100 = bool((lens == RL).all())
+        steps = int(lens.astype(np.int64).sum()) + 2 * lens.size
+        # the oracle's extraction of a sample of shard 0's rows
+        r0 = rows_t[0].cpu().numpy()
+        o0, p0 = d_out[0].cpu().numpy(), d_pl[0].cpu().numpy()
+        same = True
+        for i in range(0, NR, max(1, NR // 3000)):
+            pre, post = oix.extract(int(r0[i]), cap=512)
+            same = same and o0[i, :lens[0, i]].tobytes().decode() == pre + post and int(p0[i]) == len(pre)
+        rows_rec = {"rows_per_shard": NR, "stride": stride, "every_read_is_100_bases": all100, "reads_per_s": S * NR / (ms * 1e-3),
+                    "ms_per_batch": ms, "psi_hint_lines_fraction": int(L.rsbwt_psi_hint_lines(shards[0].handle)) / max(shards[0].num_lines() * 16 // 17, 1),
+                    "gpu_matches_oracle_on_sample": bool(same),
+                    "roofline": {"bound": "hbm", "achieved": steps * LINE_BYTES / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": steps * LINE_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "lf_and_psi_steps": steps}}
+        del rows_t, d_out, d_len, d_pl
+    if getattr(a, "kmers_1mm", 0):
+        # ---- configs[3] on the valid BWT: genomic 31-mers, half of them with one planted substitution
+        M, V = int(a.kmers_1mm), 3 * k + 1
+        km1 = d_km[0::2][:M].clone()
+        pos = torch.randint(0, k, (M,), generator=gen, device=dev)
+        flip = torch.rand(M, generator=gen, device=dev) < 0.5
+        cur = km1[torch.arange(M, device=dev), pos]
+        alt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[(torch.searchsorted(torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev), cur) + 1 + torch.randint(0, 3, (M,), generator=gen, device=dev)) % 4]
+        km1[torch.arange(M, device=dev)[flip], pos[flip]] = alt[flip]
+        pk1 = torch.empty(M, dtype=torch.int64, device=dev)
+        ok1 = torch.empty(M, dtype=torch.uint8, device=dev)
+        ok(L.rsbwt_pack_kmers_dev(p(km1), M, k, k, p(pk1), p(ok1), 0, None))
+        cap = 8 * M
+        d_hits = torch.empty((S, cap, 4), dtype=torch.int64, device=dev)
+        d_tot = torch.zeros(S, dtype=torch.int64, device=dev)
+        d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(sset._s, M, k), dtype=torch.uint8, device=dev)
+        run_m = lambda: ok(L.rsbwt_set_hits_1mm_dev(sset._s, p(pk1), p(ok1), M, k, p(d_hits), cap, p(d_tot), p(d_scr), None))
+        run_m()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(5):
+            run_m()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t3) / 5
+        tot = d_tot.cpu().numpy()
+        # the oracle's exact search of every variant of a sample of the k-mers, shard 0
+        kmh = km1[:200].cpu().numpy()
+        rec0 = d_hits[0, :int(tot[0])].cpu().numpy().view(np.uint64)
+        same1 = True
+        for qi in range(200):
+            w = kmh[qi].tobytes().decode()
+            want = []
+            lo_, up_ = oix.find_interval(w)
+            if up_ >= lo_:
+                want.append((qi * V, lo_, up_))
+            v = 1
+            for pp in range(k):
+                for al in [c for c in "ACGT" if c != w[pp]]:
+                    lo_, up_ = oix.find_interval(w[:pp] + al + w[pp + 1:])
+                    if up_ >= lo_:
+                        want.append((qi * V + v, lo_, up_))
+                    v += 1
+            mine = rec0[(rec0[:, 2] >= qi * V) & (rec0[:, 2] < (qi + 1) * V)]
+            same1 = same1 and [(int(r[2]), int(r[0]), int(r[1])) for r in mine] == want
+        mm_rec = {"kmers": M, "with_a_planted_substitution": 0.5, "hits_per_shard_mean": float(tot.mean()),
+                  "kmer_x_shard_searches_per_s": S * M / dtm, "variant_searches_per_s": S * M * V / dtm, "ms_per_batch": dtm * 1e3,
+                  "gpu_matches_oracle_on_sample": bool(same1)}
+        del d_hits, d_scr
     out = {
         "what": "bench.py's exact search on the 8 shards one GPU holds of a VALID 64-shard population BWT built on the GPU "
                 "(tools/popbwt_bench.py): 1e7 31-mers per batch, half genomic (either strand), half uniform random",
@@ -326,6 +423,7 @@ def run(a, log=sys.stderr):
         "oracle": {"shard": 0, "kmers": int(sel.numel()), "gpu_matches_oracle": matches,
                    "oracle_queries_per_s": float(sel.numel() / t_cpu), "threads": len(os.sched_getaffinity(0))},
         "mean_lf_steps_per_search": lf / (S * Q), "lines_per_lf_step": ln / max(lf, 1), "occ_lookups": oc,
+        "extraction_of_the_rows_of_the_genomic_intervals": rows_rec, "one_mismatch_hit_lists": mm_rec,
         "searches_per_s": S * Q / dt, "queries_per_s": Q / dt, "ms_per_step": dt * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "search_lines_kernel", "kernel_ms": kms,
