@@ -21,6 +21,13 @@
 
 namespace rsb {
 
+// Workgroups of 256 threads per CU the two group kernels are compiled for (tuning knob, tools/build_variant.sh): a
+// thread lays out a group of 16 windows, byte after byte -- a chain of dependent loads -- so what the kernels need is
+// waves in flight, not registers: left to itself hipcc keeps the group's piece buffer in 256 VGPRs, one wave per SIMD
+// (2.44 s per 20 GB shard); 8 = 60 VGPRs, 8 waves per SIMD: 1.26 s (2: 1.58 s; 4: 12.9 s -- 816 bytes of scratch per lane).
+#ifndef RSB_BUILD_MIN_WGS
+#define RSB_BUILD_MIN_WGS 8
+#endif
 constexpr int TILE_RUNS = 256;  // run bytes per tile = per thread
 constexpr int CHUNK_TILES = 256;  // tiles per chunk = threads per workgroup
 
@@ -152,7 +159,7 @@ __device__ void seek_reader(const seek_index &sx, uint64_t P, run_reader &rd) {
     rd.skip_symbols(P - (cpos + sx.tile_rel[tl * 5]));
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, RSB_BUILD_MIN_WGS)
 count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint64_t nwin, uint64_t ngroups,
                     uint32_t *__restrict__ far_lines, unsigned long long *__restrict__ stats, uint64_t every) {
     // every > 1: a SAMPLE of the groups (every `every`-th one), statistics only -- what the choice of S is tried on
@@ -174,7 +181,7 @@ count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint6
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, RSB_BUILD_MIN_WGS)
 write_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint64_t nwin, uint64_t ngroups,
                     const uint64_t *__restrict__ far_before, uint64_t first_far, uint32_t *__restrict__ lines) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
