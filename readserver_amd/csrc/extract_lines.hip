@@ -21,6 +21,7 @@
 //     (rank_device.h, select_in24).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "line_format.h"
@@ -650,7 +651,14 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, con
         return e;
     }
     size_t g = (n + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
-    const size_t cap = (size_t)num_cus * 4;
+    // workgroups per CU: the walk kernels' 88-95 VGPRs and 32 KB of LDS per workgroup admit 5; RSBWT_EXTRACT_WGS_PER_CU
+    // overrides (A/B knob, tools/README.md)
+    static const size_t wgs_per_cu = [] {
+        const char *e = getenv("RSBWT_EXTRACT_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return (size_t)(v > 0 && v <= 8 ? v : 4);
+    }();
+    const size_t cap = (size_t)num_cus * wgs_per_cu;
     if (g > cap) g = cap;
     if (d_work)
         hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
