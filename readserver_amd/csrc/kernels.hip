@@ -342,9 +342,18 @@ variants_kernel(const uint64_t *__restrict__ packed, const uint8_t *__restrict__
                 uint32_t k, uint32_t wpq, uint64_t *__restrict__ vpacked, uint8_t *__restrict__ vvalid) {
     const uint32_t V = 3u * k + 1u;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q * V) return;
-    const size_t q = i / V;
-    const uint32_t v = (uint32_t)(i % V);
+    const size_t QV = Q * V;
+    if (i >= QV) return;
+    size_t q;
+    uint32_t v;
+    if (QV <= 0xFFFFFFFFull) {  // (a 64-bit divide costs this kernel more than its memory traffic)
+        const uint32_t q32 = (uint32_t)i / V;
+        q = q32;
+        v = (uint32_t)i - q32 * V;
+    } else {
+        q = i / V;
+        v = (uint32_t)(i - q * V);
+    }
     vvalid[i] = valid[q];
     for (uint32_t w = 0; w < wpq; ++w) vpacked[i * wpq + w] = packed[q * wpq + w];
     if (v == 0u) return;
