@@ -35,9 +35,11 @@
 //   do not hold pieces but where psi takes the ROWS w*S .. w*S + S - 1 (read extraction's select,
 //   src/bwt/query.cpp:72-80): those rows are consecutive occurrences of one symbol f (the F symbol of row
 //   w*S), which lie in a few consecutive windows of the BWT: dword 30 = the window w0 of the first of them,
-//   dword 31 = k0 | k1 << 10 | k2 << 20 | last << 30 with k_j + 1 = how many of them lie in windows <= w0 + j
-//   and last = 1 when none lies past w0 + 3.  Written by a pass of its own once a shard's select samples exist
-//   (kernels.hip, psi_hint_kernel); no search ever looks at it (a lookup never reads past its window's pieces).
+//   dword 31 = four bytes b0..b3, b_j = (K_j - 1) >> 2 with K_j = how many of them lie in windows <= w0 + j
+//   (255 when that is all of them).  Row w*S + r goes to window w0 + #{j : (r >> 2) > b_j}; a row with
+//   (r >> 2) == b_j for some j, or past b3, is not settled by the hint (the walk reads a select sample).
+//   Written by a pass of its own once a shard's select samples exist (kernels.hip, psi_hint_kernel); no
+//   search ever looks at it (a lookup never reads past its window's pieces).
 //
 // SPILL LINE (line 17g + 16 of group g) = chunks at even dwords, each
 //   dword 0   totA | totC << 12 | (csym & 0xFF) << 24      tot_x = # of x in the 96 own pieces of
@@ -83,7 +85,7 @@ constexpr uint32_t GROUP = 1u << GROUP_SHIFT;
 constexpr uint32_t KIND_WHOLE = 0, KIND_CHUNK = 1, KIND_FAR = 2;
 constexpr uint32_t HINT_PIECES = 88;       // own pieces of a line whose last two dwords are a psi hint
 constexpr uint32_t HINT_META0_BIT = 21;    // bit of meta_0 (= bit 29 of dword 1) saying so
-constexpr uint32_t HINT_MAX_SPAN = 1024;   // k_j fit 10 bits
+constexpr uint32_t HINT_MAX_SPAN = 1024;   // (K_j - 1) >> 2 fits a byte
 constexpr uint32_t COUNT_BITS = 40;
 constexpr uint64_t COUNT_MASK = (1ull << COUNT_BITS) - 1;
 constexpr uint64_t MAX_SYMBOLS = 1ull << 40;  // per shard; counts are 40-bit
@@ -189,12 +191,13 @@ RSB_HD uint64_t count_before_window(const shard_view &v, uint64_t w, uint32_t b)
     return w * v.sp.S - s;
 }
 
-// psi hint (above): the window of the r-th row of the hinted window (r = 0 .. S-1); *exact = false: beyond what
-// the hint knows (more than four target windows, r past the third boundary)
+// psi hint (above): the window of the r-th row of the hinted window (r = 0 .. S-1); *exact = false: the hint does not
+// settle this row (it sits within four rows of a boundary, or past the fourth one)
 RSB_HD uint32_t hint_window(uint32_t w0, uint32_t kk, uint32_t r, bool *exact) {
-    const uint32_t k0 = kk & 0x3FFu, k1 = (kk >> 10) & 0x3FFu, k2 = (kk >> 20) & 0x3FFu;
-    *exact = r <= k2 || ((kk >> 30) & 1u) != 0u;
-    return w0 + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u);
+    const uint32_t rq = r >> 2;
+    const uint32_t b0 = kk & 0xFFu, b1 = (kk >> 8) & 0xFFu, b2 = (kk >> 16) & 0xFFu, b3 = kk >> 24;
+    *exact = rq != b0 && rq != b1 && rq != b2 && rq < b3;
+    return w0 + (rq > b0 ? 1u : 0u) + (rq > b1 ? 1u : 0u) + (rq > b2 ? 1u : 0u) + (rq > b3 ? 1u : 0u);
 }
 
 // RLEBWT::getOcc (src/bwt/rlebwt.cpp:268-301): # of symbol b in BWT[0..p], p < n.
@@ -355,14 +358,14 @@ RSB_HD bool window_psi_hint(const shard_view &ix, const uint64_t *sel, uint64_t 
     // the sample must be right: count(w0) < bc0 <= count(w0 + 1)
     if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, (uint64_t)w0 + 1, f))) return false;
     uint32_t kk = 0;
-    uint64_t upto = 0;
     for (uint32_t j = 0; j < 4; ++j) {
         const uint64_t c = count_before_window(ix, (uint64_t)w0 + 1 + j, f);
-        upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
+        uint64_t upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
         if (upto > seff) upto = seff;
-        if (j < 3) kk |= (uint32_t)((upto ? upto : 1ull) - 1ull) << (10u * j);
+        // b_j = (K_j - 1) >> 2; 255 = "all of them" (then every row up to r >> 2 == 254 is at or before window w0 + j)
+        const uint32_t bj = upto >= seff ? 255u : (uint32_t)(((upto ? upto : 1ull) - 1ull) >> 2);
+        kk |= bj << (8u * j);
     }
-    if (upto >= seff) kk |= 1u << 30;  // none past w0 + 3
     *w0_out = w0;
     *kk_out = kk;
     return true;
