@@ -743,6 +743,7 @@ def run_rows(a, c):
 
         for h in shards:
             ok(c, L.rsbwt_set_counting(h.handle, 1))
+        ok(c, L.rsbwt_set_set_counting(sset._s, 1))
         step()
         torch.cuda.synchronize()
         w = [0] * 16
@@ -751,6 +752,13 @@ def run_rows(a, c):
             ok(c, L.rsbwt_last_search_counters(h.handle, wi))  # the resumed search of the variants, per shard
             ok(c, L.rsbwt_set_counting(h.handle, 0))
             w = [x + int(y) for x, y in zip(w, wi)]
+        # ... or of all the set's shards in ONE launch (csrc/sets.hip, set_hits_1mm_fused): the set's own counters
+        ws = (C.c_uint64 * 16)()
+        ok(c, L.rsbwt_set_last_search_counters(sset._s, ws))
+        ok(c, L.rsbwt_set_set_counting(sset._s, 0))
+        fused = bool(L.rsbwt_set_hits_1mm_is_fused(sset._s, M, k))
+        if fused:
+            w = [int(x) for x in ws]
         for _ in range(a.warmup):
             step()
         gat_h.drain(); gat_t.drain(); barrier()
@@ -782,9 +790,15 @@ def run_rows(a, c):
         alg = w[2] * LINE_BYTES + S * M * V * 24 + hits_local * 48
         # below 2^26 variant searches per shard the set's shards work side by side on streams of their own
         # (csrc/sets.hip): their kernels overlap, so the sum of their durations says nothing -- the step is priced
-        side_by_side = S > 1 and M * V < (1 << int(os.environ.get("RSBWT_SET_1MM_SIDE_LOG2", "26"))) and "RSBWT_SET_1MM_TURNS" not in os.environ
+        side_by_side = (not fused and S > 1 and M * V < (1 << int(os.environ.get("RSBWT_SET_1MM_SIDE_LOG2", "26")))
+                        and "RSBWT_SET_1MM_TURNS" not in os.environ)
         if side_by_side:
             kms = dt / a.steps * 1e3
+        if fused:  # the traced and the resumed launch of every timed call, from the set's HIP events
+            buf = (C.c_float * 64)()
+            cnt = C.c_size_t()
+            ok(c, L.rsbwt_set_search_history_ms(sset._s, buf, min(64, 2 * a.steps), C.byref(cnt)))
+            kms = sum(buf[:cnt.value]) / max(cnt.value / 2, 1)
         out = {
             "metric": "31-mer 1-mismatch backward searches/sec on popBWT (BASELINE configs[3])",
             "value": world * S * M / (dt / a.steps), "unit": "(31-mer x shard) 1-mismatch searches/s",
@@ -799,7 +813,10 @@ def run_rows(a, c):
                            travels=(None if world == 1 else f"[{S}][{cap}] 32-byte records + {S} counts per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("search_lines_kernel (the k-mers traced, their variants resumed): the shards side by side, priced on the whole step"
+                         "frac_of_step": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                         "kernel": ("search_lines_kernel (the k-mers traced, their variants resumed): all the rank's shards in one launch each"
+                                    if fused else
+                                    "search_lines_kernel (the k-mers traced, their variants resumed): the shards side by side, priced on the whole step"
                                     if side_by_side else
                                     "search_lines_kernel (the k-mers traced, their variants resumed), summed over the rank's shards"),
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": w[2]},

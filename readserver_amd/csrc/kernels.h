@@ -50,20 +50,25 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
 // views are the device array d_shards (all on the current device).  d_lower/d_upper: [nshards][Q]
 // (d_lower alone receives counts with counts_only).  ev0/ev1 (optional) are recorded on `stream`
 // immediately around the search kernel itself.
+// words of the hit map of Q searches (one bit per search, a whole number of 16-byte units: the maps of a launch's
+// shards lie back to back)
+__host__ __device__ inline size_t hit_map_words(size_t Q) { return ((Q + 127) / 128) * 2; }
+
 struct search_extra {
-    // 1-mismatch search, one shard.  A traced search records, per k-mer, the interval
-    // it holds when about to take each of its first trace_n symbols ([Q][trace_n] x {lower, upper});
+    // 1-mismatch search.  A traced search records, per (shard, k-mer), the interval
+    // it holds when about to take each of its first trace_n symbols ([nshards][Q][trace_n] x {lower, upper});
     // the search of the k-mers' variants (`variants` per k-mer, variants_kernel's order) then starts
-    // every variant whose substituted position is < trace_n from that interval.
+    // every variant whose substituted position is < trace_n from that interval (the shards of one launch
+    // share trace_n: their k-mer tables have one depth).
     void *d_trace_out = nullptr;
     const void *d_trace_in = nullptr;
     uint32_t trace_n = 0, variants = 0;
     bool table_build = false;  // a k-mer table's own searches: same kernel under another name (profiles)
     bool pairs = false;        // results as {lower, upper}[nshards][Q] at d_lower (one 16-byte store per search)
-    // sparse results (one shard): nothing is written for a search that ends empty; the others store
-    // {lower, upper} at d_lower[search index] (16 B each, as with `pairs`) and set their bit in the map
-    // d_hit_bits (one bit per search, zeroed by the caller); launch_compact_hits turns the two into a
-    // list ordered by search index
+    // sparse results: nothing is written for a search that ends empty; the others store
+    // {lower, upper} at d_lower[s][search index] (16 B each, as with `pairs`) and set their bit in shard s's map
+    // d_hit_bits[s][hit_map_words(Q)] (one bit per search, zeroed by the caller); launch_compact_hits turns the
+    // two into a list per shard, ordered by search index
     void *d_hit_bits = nullptr;
     // the k-mer table leaves intervals well inside a window (n / 4^T << S): most steps of a search find
     // both positions in one line, which is what the one-lane-per-search kernel is for (search_solo.h)
@@ -97,9 +102,13 @@ hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, cons
                                size_t n, void *d_out, hipStream_t stream);
 // The list of the set bits of `bits` (n_searches bits), in order: record i = {lower, upper, search index, 0}
 // (32 B) from sparse[index]; at most `cap` records are written, *d_total receives how many there are.
-// d_block_counts: (n_searches / 16384 + 2) u64 of scratch.
+// d_block_counts: compact_hits_block_words(n_searches) u64 of scratch.
+// nseg > 1: the same for nseg maps at once (the shards of one search launch): maps hit_map_words(n_searches) words
+// apart, sparse results n_searches records apart, lists cap records apart, totals one u64 each, block scratch
+// compact_hits_block_words(n_searches) apart.
+size_t compact_hits_block_words(size_t n_searches);
 hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t n_searches, void *d_hits, size_t cap,
-                               void *d_total, void *d_block_counts, hipStream_t stream);
+                               void *d_total, void *d_block_counts, hipStream_t stream, uint32_t nseg = 1);
 // {lower, upper} pairs <-> 10-byte {lower:40, width:40} records (kernels.hip); d_unfit: optional u32 counter of
 // pairs that do not fit the record (none does for an interval findInterval produced)
 hipError_t launch_pack_pairs10(const void *d_pairs, size_t n, void *d_packed, void *d_unfit, hipStream_t stream);

@@ -368,11 +368,16 @@ variants_kernel(const uint64_t *__restrict__ packed, const uint8_t *__restrict__
 
 // ---- 1-mismatch hit list: the set bits of the search kernels' hit map, in order -------------------
 // Three small launches over n/64 words (the map of 3.8*10^7 variants is 4.7 MB): set bits per block of
-// 256 words, an exclusive scan of the block sums by one workgroup, the scatter.
+// 256 words, an exclusive scan of the block sums by one workgroup, the scatter.  blockIdx.y = the segment (the shard
+// of a launch over several): maps hit_map_words(n) words apart, sparse results n records apart, lists cap records
+// apart, block sums nblocks + 2 words apart.
 constexpr uint32_t HITS_BLOCK_WORDS = 256;
 
 __global__ void __launch_bounds__(256)
-hit_block_counts_kernel(const uint64_t *__restrict__ bits, size_t nwords, unsigned long long *__restrict__ block_counts) {
+hit_block_counts_kernel(const uint64_t *__restrict__ bits, size_t nwords, size_t map_words, size_t nblocks,
+                        unsigned long long *__restrict__ block_counts) {
+    bits += (size_t)blockIdx.y * map_words;
+    block_counts += (size_t)blockIdx.y * (nblocks + 2);
     const size_t w = (size_t)blockIdx.x * HITS_BLOCK_WORDS + threadIdx.x;
     uint32_t c = w < nwords ? (uint32_t)__builtin_popcountll(bits[w]) : 0u;
     __shared__ uint32_t part[4];
@@ -385,6 +390,8 @@ hit_block_counts_kernel(const uint64_t *__restrict__ bits, size_t nwords, unsign
 // exclusive scan in place; block_counts[nblocks] and *total receive the sum
 __global__ void __launch_bounds__(256)
 hit_block_scan_kernel(unsigned long long *__restrict__ block_counts, size_t nblocks, unsigned long long *__restrict__ total) {
+    block_counts += (size_t)blockIdx.x * (nblocks + 2);  // one workgroup per segment
+    total += blockIdx.x;
     __shared__ unsigned long long carry, sums[256];
     if (threadIdx.x == 0u) carry = 0;
     __syncthreads();
@@ -411,8 +418,13 @@ hit_block_scan_kernel(unsigned long long *__restrict__ block_counts, size_t nblo
 }
 
 __global__ void __launch_bounds__(256)
-hit_scatter_kernel(const uint64_t *__restrict__ bits, const ulonglong2 *__restrict__ sparse, size_t nwords,
-                   const unsigned long long *__restrict__ block_offsets, ulonglong2 *__restrict__ hits, size_t cap) {
+hit_scatter_kernel(const uint64_t *__restrict__ bits, const ulonglong2 *__restrict__ sparse, size_t nwords, size_t map_words,
+                   size_t n_searches, size_t nblocks, const unsigned long long *__restrict__ block_offsets,
+                   ulonglong2 *__restrict__ hits, size_t cap) {
+    bits += (size_t)blockIdx.y * map_words;
+    sparse += (size_t)blockIdx.y * n_searches;
+    block_offsets += (size_t)blockIdx.y * (nblocks + 2);
+    hits += (size_t)blockIdx.y * cap * 2;
     const size_t w = (size_t)blockIdx.x * HITS_BLOCK_WORDS + threadIdx.x;
     uint64_t word = w < nwords ? bits[w] : 0ull;
     const uint32_t c = (uint32_t)__builtin_popcountll(word);
@@ -734,16 +746,24 @@ hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, cons
     return hipGetLastError();
 }
 
+size_t compact_hits_block_words(size_t n_searches) {
+    const size_t nwords = (n_searches + 63) / 64;
+    return (nwords + HITS_BLOCK_WORDS - 1) / HITS_BLOCK_WORDS + 2;
+}
+
 hipError_t launch_compact_hits(const void *d_bits, const void *d_sparse, size_t n_searches, void *d_hits, size_t cap,
-                               void *d_total, void *d_block_counts, hipStream_t stream) {
+                               void *d_total, void *d_block_counts, hipStream_t stream, uint32_t nseg) {
     const size_t nwords = (n_searches + 63) / 64, nblocks = (nwords + HITS_BLOCK_WORDS - 1) / HITS_BLOCK_WORDS;
-    if (nwords == 0) return hipMemsetAsync(d_total, 0, 8, stream);
-    hipLaunchKernelGGL(hit_block_counts_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const uint64_t *)d_bits, nwords,
-                       (unsigned long long *)d_block_counts);
-    hipLaunchKernelGGL(hit_block_scan_kernel, dim3(1), dim3(256), 0, stream, (unsigned long long *)d_block_counts, nblocks,
+    if (nseg == 0) return hipSuccess;
+    if (nwords == 0) return hipMemsetAsync(d_total, 0, 8 * (size_t)nseg, stream);
+    const size_t map_words = hit_map_words(n_searches);
+    hipLaunchKernelGGL(hit_block_counts_kernel, dim3((unsigned)nblocks, nseg), dim3(256), 0, stream, (const uint64_t *)d_bits, nwords,
+                       map_words, nblocks, (unsigned long long *)d_block_counts);
+    hipLaunchKernelGGL(hit_block_scan_kernel, dim3(nseg), dim3(256), 0, stream, (unsigned long long *)d_block_counts, nblocks,
                        (unsigned long long *)d_total);
-    hipLaunchKernelGGL(hit_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const uint64_t *)d_bits,
-                       (const ulonglong2 *)d_sparse, nwords, (const unsigned long long *)d_block_counts, (ulonglong2 *)d_hits, cap);
+    hipLaunchKernelGGL(hit_scatter_kernel, dim3((unsigned)nblocks, nseg), dim3(256), 0, stream, (const uint64_t *)d_bits,
+                       (const ulonglong2 *)d_sparse, nwords, map_words, n_searches, nblocks,
+                       (const unsigned long long *)d_block_counts, (ulonglong2 *)d_hits, cap);
     return hipGetLastError();
 }
 

@@ -67,7 +67,9 @@ __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const u
 }
 
 // one thread per (query, shard): init[s * Q + q].  Adjacent lanes = the shards of one query, so that
-// interleaved k-mer tables are read one stretch per query.
+// interleaved k-mer tables are read one stretch per query.  (A thread per query that goes through the shards itself
+// writes whole 1 KB stretches instead of 16-byte records Q apart, and is slower: eight table reads one behind the
+// other per thread -- 0.19 against 0.15 ms per launch, profiles/r03g_kernel_stats.csv.)
 __global__ void __launch_bounds__(256)
 search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
                    const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq,
@@ -89,13 +91,17 @@ search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
 // variant whose substituted position is left of the k-mer table's reach shares its whole suffix
 // with the k-mer itself: it starts from the interval the k-mer's own (traced) search had when it
 // was about to take that position -- trace[q][pos] -- and takes the substituted symbol first.
+// Several shards per launch (a set's shards of one device): one thread per (variant, shard), adjacent lanes = the
+// shards of one variant (interleaved k-mer tables, as search_init_kernel); shard s's traces are trace[s][m][trace_n],
+// its records init[s * mv + i].
 __global__ void __launch_bounds__(256)
-search_init_1mm_kernel(const shard_view *__restrict__ shard, const uint64_t *__restrict__ vpacked,
+search_init_1mm_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ vpacked,
                        const uint8_t *__restrict__ vvalid, size_t mv, uint32_t k, uint32_t wpq, uint32_t V,
                        const ulonglong2 *__restrict__ trace, uint32_t trace_n,
                        ulonglong2 *__restrict__ init) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= mv) return;
+    const size_t t_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_ >= mv * nshards) return;
+    const size_t i = t_ / nshards, s = t_ - i * nshards;
     ulonglong2 rec;
     if (vvalid[i] == 0) {
         rec.x = INIT_INVALID;
@@ -105,14 +111,14 @@ search_init_1mm_kernel(const shard_view *__restrict__ shard, const uint64_t *__r
         const uint32_t v = (uint32_t)(i - q * V);
         const uint32_t pos = v ? (v - 1u) / 3u : ~0u;
         if (pos < trace_n) {
-            const ulonglong2 t = trace[q * trace_n + pos];
+            const ulonglong2 t = trace[(s * (mv / V) + q) * trace_n + pos];
             rec.x = (t.x & COUNT_MASK) | ((uint64_t)pos << COUNT_BITS) | INIT_EXPLICIT;
             rec.y = t.y;
         } else {
-            rec = start_record(*shard, vpacked + i * wpq, k);
+            rec = start_record(shards[s], vpacked + i * wpq, k);
         }
     }
-    init[i] = rec;
+    init[s * mv + i] = rec;
 }
 
 // work[] of a counting launch
@@ -180,6 +186,9 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;
+        // a traced search's record and a hit-list search's map are per shard: [s][Q][trace_n], [s][hit_map_words(Q)]
+        ulonglong2 *trace_s = trace ? trace + (size_t)sid * Q * trace_n : nullptr;
+        unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
         // C[b]: lanes 0..3 of every wave keep C[1..4] and a lane picks its symbol's entry with two
         // ds_bpermute reads (selects out of scalar registers cost 15 VALU instructions a pass; a
         // dynamically indexed load would be a dependent global load in every pass)
@@ -306,7 +315,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
             }
             if (fresh) {
                 // traced search (1-mismatch): the interval this query has when about to take symbol j
-                if (trace && side == 0u && (uint32_t)j < trace_n) trace[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
+                if (trace && side == 0u && (uint32_t)j < trace_n) trace_s[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
                 // Occ(b, -1) = 0: lower - 1 at lower == 0, and upper itself after a step that found no b
                 // at the top of the BWT (upper = 0 + 0 - 1 wraps; the reference carries on the same way
                 // and reports the empty interval one step later: query.cpp:11-15,35, rlebwt.cpp:269)
@@ -488,7 +497,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 if (trace && side == 0u) {
                     // the positions it never reached: a search resumed there ends where this one did
                     for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
-                        trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
+                        trace_s[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
                 }
                 if (side == 0u) {
                     if (COUNTS_ONLY) {
@@ -499,8 +508,8 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                         // atomic nobody waits for; a counter handing out list positions would stall the wave for a
                         // round trip per hit and serialise on one address).  compact_hits orders them afterwards.
                         if (lo <= hi) {
-                            reinterpret_cast<ulonglong2 *>(out_lower)[q] = make_ulonglong2(lo, hi);
-                            atomicOr(reinterpret_cast<unsigned long long *>(out_upper) + (q >> 6), 1ull << (q & 63u));
+                            reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
+                            atomicOr(hit_map + (q >> 6), 1ull << (q & 63u));
                         }
                     } else if (pairs) {
 #ifdef RSB_NT_RESULTS  // tuning knob: results are written once and read by another kernel / the host
@@ -598,10 +607,10 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                          const search_extra *extra) {
     if (Q == 0 || nshards == 0) return hipSuccess;
-    if (extra && (extra->d_trace_out || extra->d_trace_in || extra->table_build) && nshards != 1)
-        return hipErrorInvalidValue;  // traced / resumed searches: one shard
+    if (extra && extra->table_build && nshards != 1) return hipErrorInvalidValue;  // a table is one shard's
+    // traced / resumed / hit-list searches of several shards: traces [s][Q][trace_n], sparse results [s][Q], hit maps
+    // [s][hit_map_words(Q)]
     const bool hit_list = extra && extra->d_hit_bits && !counts_only;
-    if (hit_list && nshards != 1) return hipErrorInvalidValue;  // the list names searches, not (search, shard)
     const uint32_t pairs = hit_list ? 2u : (extra && extra->pairs && !counts_only) ? 1u : 0u;
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
     const uint32_t trace_n = extra ? extra->trace_n : 0u;
@@ -659,7 +668,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     if (prepared) {
         // nothing to compute
     } else if (extra && extra->d_trace_in)
-        hipLaunchKernelGGL(search_init_1mm_kernel, dim3(ig), dim3(256), 0, stream, d_shards, pk, vd, Q, k, wpq,
+        hipLaunchKernelGGL(search_init_1mm_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq,
                            extra->variants, (const ulonglong2 *)extra->d_trace_in, trace_n, init);
     else
         hipLaunchKernelGGL(search_init_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq, init);

@@ -49,6 +49,9 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;
+        // per shard, as in search_lines_kernel: traces [s][Q][trace_n], hit maps [s][hit_map_words(Q)]
+        ulonglong2 *trace_s = trace ? trace + (size_t)sid * Q * trace_n : nullptr;
+        unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
         // C[1..4] in lanes 0..3, picked with ds_bpermute (scalar loads: see search_lines_kernel)
         uint32_t ctab_lo, ctab_hi;
         {
@@ -161,7 +164,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             if (fresh) {
                 if (sub == 0u) {
                     // traced search (1-mismatch): the interval this query has when about to take symbol j
-                    if (trace && (uint32_t)j < trace_n) trace[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
+                    if (trace && (uint32_t)j < trace_n) trace_s[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
                     if (lo == 0ull) {  // Occ(b, -1) = 0 (rlebwt.cpp:269)
                         occL = 0;
                         sub = 1u;
@@ -347,7 +350,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 if (trace) {
                     // the positions it never reached: a search resumed there ends where this one did
                     for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
-                        trace[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
+                        trace_s[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);
                 }
                 if (COUNTS_ONLY) {
                     if (hi >= lo) out_lo[q] = hi - lo + 1ull;  // service.cpp:304; the array is zeroed before the launch: most searches end empty and store nothing
@@ -357,8 +360,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     // atomic nobody waits for; a counter handing out list positions would stall the wave for a
                     // round trip per hit and serialise on one address).  compact_hits orders them afterwards.
                     if (lo <= hi) {
-                        reinterpret_cast<ulonglong2 *>(out_lower)[q] = make_ulonglong2(lo, hi);
-                        atomicOr(reinterpret_cast<unsigned long long *>(out_upper) + (q >> 6), 1ull << (q & 63u));
+                        reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
+                        atomicOr(hit_map + (q >> 6), 1ull << (q & 63u));
                     }
                 } else if (pairs) {
                     reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);

@@ -569,13 +569,61 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
                          true, (hipStream_t)stream, &ex);
 }
 
-// 1-mismatch search over the shards of a one-device set.  A traced / resumed search belongs to one
-// shard (the trace is that shard's), so the shards take turns on the stream; each turn is m x (3k+1)
-// searches, large enough to fill the GPU by itself.
+// Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
+// The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
+// Below this many variant searches per shard (2^26 = 7e5 31-mers; a scratch per shard is what bounds it) the shards of
+// the set work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to the
+// caller's stream with events), instead of taking turns: a shard's own sequence -- variants, start records, the traced
+// and the resumed search, three small compaction launches -- leaves gaps and tails another shard's kernels fill
+// (8 resident 20 GB shards, per batch: 4e4 31-mers 5.7 -> 4.3 ms, 1e5 9.4 -> 7.8, 4e5 30.7 -> 27.9:
+// profiles/r03_set_side_by_side.json).
+static size_t side_by_side_below() {
+    static const size_t v = [] {
+        const char *e = getenv("RSBWT_SET_1MM_SIDE_LOG2");  // A/B knob (tools/README.md)
+        const int b = e ? atoi(e) : 0;
+        return (size_t)1 << (b >= 10 && b <= 40 ? b : 26);
+    }();
+    return v;
+}
+#define SIDE_BY_SIDE_BELOW side_by_side_below()
+
+// ONE launch sequence for all the shards of the device (below the same size): the k-mers traced in every shard by one
+// fused launch (traces [S][m][tn]), their variants resumed in every shard by another (sparse results [S][mv], hit maps
+// [S][hit_map_words(mv)]), one three-launch compaction with a segment per shard.  A (31-mer x shard) search is then
+// one of S * m * (3k+1) in a launch that fills the GPU where a shard's own m * (3k+1) do not, and the set's tails
+// are one tail.  Needs what the fused exact search needs -- one device -- and one trace length for all shards (k-mer
+// tables of one depth: rsbwt_set_attach_ktabs gives every shard of a device the same).
+struct fused_1mm_layout {
+    uint32_t tn;
+    size_t trace, own, sparse, bits, blocks, total;  // byte sizes of the parts behind the variants, each 256-aligned
+};
+static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L) {
+    static const bool off = getenv("RSBWT_SET_1MM_UNFUSED") != nullptr;  // A/B knob (tools/README.md)
+    const size_t S = s->shards.size(), mv = m * (3 * (size_t)k + 1);
+    if (off || S < 2 || s->groups.size() != 1 || mv >= SIDE_BY_SIDE_BELOW || k > 32767u) return false;
+    const uint32_t tn = trace_entries(s->shards[0]->view, k);
+    for (const rsbwt_t *h : s->shards)
+        if (trace_entries(h->view, k) != tn || h->view.n == 0) return false;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    L->tn = tn;
+    L->trace = al(S * m * (size_t)tn * 16);
+    L->own = tn ? al(S * m * 16) : 0;  // the k-mers' own intervals ({lower, upper}[S][m]: nobody reads them)
+    L->sparse = al(S * mv * 16);
+    L->bits = al(S * hit_map_words(mv) * 8);
+    L->blocks = al(S * compact_hits_block_words(mv) * 8);
+    L->total = L->trace + L->own + L->sparse + L->bits + L->blocks;
+    return true;
+}
+
+// 1-mismatch search over the shards of a one-device set: the fused launches above where they apply (dense
+// results: the resumed launch writes [S][m][3k+1] lower and upper itself), else the shards take turns on the stream,
+// each turn m x (3k+1) searches of one shard.
 size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
     size_t need = 0;
-    if (s)
-        for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_1mm_scratch_bytes(h, m, k));
+    if (!s) return 0;
+    for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_1mm_scratch_bytes(h, m, k));
+    fused_1mm_layout L;
+    if (fused_1mm_applies(s, m, k, &L)) need = std::max(need, ((variants_bytes(m, k) + 255) & ~(size_t)255) + L.trace + L.own);
     return need;
 }
 
@@ -586,6 +634,31 @@ static int rsbwt_set_find_intervals_1mm_dev_body(rsbwt_set_t *s, const void *d_p
     if (m == 0) return RSBWT_OK;
     if (!d_lower || !d_upper) return fail(RSBWT_EINVAL, "null argument");
     const size_t row = m * (3 * (size_t)k + 1) * 8;
+    fused_1mm_layout L;
+    if (fused_1mm_applies(s, m, k, &L)) {
+        if (!d_packed || !d_valid || !d_scratch) return fail(RSBWT_EINVAL, "null argument");
+        dev_group *g = s->groups[0];
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        const uint32_t S = (uint32_t)s->shards.size();
+        const size_t V = 3 * (size_t)k + 1, mv = m * V;
+        uint8_t *d_var = (uint8_t *)d_scratch, *d_trace = d_var + ((variants_bytes(m, k) + 255) & ~(size_t)255), *d_own = d_trace + L.trace;
+        if ((rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
+        const uint8_t *d_vok = d_var + ((mv * ((k + 31u) / 32u) * 8 + 15) & ~(size_t)15);  // variants_of_batch_dev's layout
+        search_extra resumed;
+        if (L.tn) {
+            search_extra traced;
+            traced.d_trace_out = d_trace;
+            traced.trace_n = L.tn;
+            traced.pairs = true;
+            if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, (hipStream_t)stream, &traced)) != RSBWT_OK)
+                return rc;
+            resumed.d_trace_in = d_trace;
+            resumed.trace_n = L.tn;
+            resumed.variants = (uint32_t)V;
+        }
+        return search_launch(*g, g->d_views, S, g->num_cus, d_var, d_vok, mv, k, d_lower, d_upper, false, (hipStream_t)stream, &resumed);
+    }
     for (size_t i = 0; i < s->shards.size(); ++i) {
         const int rc = rsbwt_find_intervals_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_lower + i * row,
                                                     (uint8_t *)d_upper + i * row, d_scratch, stream);
@@ -787,24 +860,6 @@ int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
     });
 }
 
-// Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
-// The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
-// Below this many variant searches per shard (2^26 = 7e5 31-mers; a scratch per shard is what bounds it) the shards of
-// the set work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to the
-// caller's stream with events), instead of taking turns: a shard's own sequence -- variants, start records, the traced
-// and the resumed search, three small compaction launches -- leaves gaps and tails another shard's kernels fill
-// (8 resident 20 GB shards, per batch: 4e4 31-mers 5.7 -> 4.3 ms, 1e5 9.4 -> 7.8, 4e5 30.7 -> 27.9:
-// profiles/r03_set_side_by_side.json).
-static size_t side_by_side_below() {
-    static const size_t v = [] {
-        const char *e = getenv("RSBWT_SET_1MM_SIDE_LOG2");  // A/B knob (tools/README.md)
-        const int b = e ? atoi(e) : 0;
-        return (size_t)1 << (b >= 10 && b <= 40 ? b : 26);
-    }();
-    return v;
-}
-#define SIDE_BY_SIDE_BELOW side_by_side_below()
-
 static size_t hits_1mm_scratch_one(const rsbwt_set_t *s, size_t m, uint32_t k) {
     size_t need = 0;
     for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_hits_1mm_scratch_bytes(h, m, k));
@@ -812,13 +867,52 @@ static size_t hits_1mm_scratch_one(const rsbwt_set_t *s, size_t m, uint32_t k) {
 }
 
 // scratch of a set's hit-list search: the batch's variants, expanded ONCE for all shards (they depend on the k-mers
-// alone), then a slot per shard that works at the same time
+// alone), then a slot per shard that works at the same time (or the fused launches' parts)
 size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
     if (!s) return 0;
     const size_t one = hits_1mm_scratch_one(s, m, k);
     const bool side = s->shards.size() > 1 && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
     const size_t slots = side ? std::min<size_t>(s->shards.size(), dev_group::FORK) : 1;
-    return ((variants_bytes(m, k) + 255) & ~(size_t)255) + one * slots;
+    fused_1mm_layout L;
+    const size_t fused = fused_1mm_applies(s, m, k, &L) ? L.total : 0;
+    return ((variants_bytes(m, k) + 255) & ~(size_t)255) + std::max(one * slots, fused);
+}
+
+// 1: rsbwt_set_hits_1mm_dev of m k-mers runs as the fused launches (for a caller that prices them: bench.py)
+int rsbwt_set_hits_1mm_is_fused(const rsbwt_set_t *s, size_t m, uint32_t k) {
+    fused_1mm_layout L;
+    static const bool turns_only = getenv("RSBWT_SET_1MM_TURNS") != nullptr;
+    return s && m && k && !turns_only && fused_1mm_applies(s, m, k, &L) ? 1 : 0;
+}
+
+static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layout &L, const void *d_packed, const void *d_valid,
+                              size_t m, uint32_t k, void *d_hits, size_t cap_per_shard, void *d_totals, const uint8_t *d_var,
+                              uint8_t *d_parts, hipStream_t st) {
+    const uint32_t S = (uint32_t)s->shards.size();
+    const size_t V = 3 * (size_t)k + 1, mv = m * V;
+    const size_t a_vpk = (mv * ((k + 31u) / 32u) * 8 + 15) & ~(size_t)15;  // variants_of_batch_dev's layout
+    const uint8_t *d_vpk = d_var, *d_vok = d_var + a_vpk;
+    uint8_t *d_trace = d_parts, *d_own = d_trace + L.trace, *d_sparse = d_own + L.own, *d_bits = d_sparse + L.sparse;
+    uint8_t *d_blocks = d_bits + L.bits;
+    HIP_OK(hipMemsetAsync(d_bits, 0, (size_t)S * hit_map_words(mv) * 8, st));
+    int rc;
+    search_extra resumed;
+    if (L.tn) {
+        search_extra traced;
+        traced.d_trace_out = d_trace;
+        traced.trace_n = L.tn;
+        traced.pairs = true;
+        if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced)) != RSBWT_OK)
+            return rc;
+        resumed.d_trace_in = d_trace;
+        resumed.trace_n = L.tn;
+        resumed.variants = (uint32_t)V;
+    }
+    resumed.d_hit_bits = d_bits;
+    if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_vpk, d_vok, mv, k, d_sparse, nullptr, false, st, &resumed)) != RSBWT_OK)
+        return rc;
+    const hipError_t e = launch_compact_hits(d_bits, d_sparse, mv, d_hits, cap_per_shard, d_totals, d_blocks, st, S);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "hit list kernels");
 }
 
 // d_hits: [num_shards][cap_per_shard] records of 32 B (rsbwt_hits_1mm_dev's), d_totals: u64[num_shards]
@@ -842,6 +936,9 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     const size_t one = hits_1mm_scratch_one(s, m, k);
     uint8_t *d_var = (uint8_t *)d_scratch, *d_slots = d_var + ((variants_bytes(m, k) + 255) & ~(size_t)255);
     if ((rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    fused_1mm_layout FL;
+    if (!turns_only && fused_1mm_applies(s, m, k, &FL))
+        return set_hits_1mm_fused(s, g, FL, d_packed, d_valid, m, k, d_hits, cap_per_shard, d_totals, d_var, d_slots, (hipStream_t)stream);
     auto one_shard = [&](size_t i, uint8_t *slot, hipStream_t st) {
         return hits_1mm_dev_shared(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32, cap_per_shard,
                                    (uint8_t *)d_totals + i * 8, slot, st, d_var);

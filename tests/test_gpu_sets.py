@@ -128,6 +128,7 @@ def test_gpu_set_device_resident_forms(rsb, four_shards):
     d_hits = torch.zeros((S, cap, 4), dtype=torch.int64, device=dev)
     d_tot = torch.zeros(S, dtype=torch.int64, device=dev)
     d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device=dev)
+    assert L.rsbwt_set_hits_1mm_is_fused(ss._s, m, k) == 0  # tables of depth 6 and 8: the shards side by side
     assert L.rsbwt_set_hits_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_hits), cap, p(d_tot), p(d_scr), None) == 0
     torch.cuda.synchronize()
     hits, first = ss.hits_1mm(kmers)
@@ -396,3 +397,92 @@ def test_gpu_read_packing_kernels_match_the_host_form(rsb):
         assert torch.equal(back.cpu(), sharded.unpack_reads(want, lens)), (n, stride)
     L = rsb.lib()
     assert L.rsbwt_pack_reads_dev(C.c_void_p(got.data_ptr()), C.c_void_p(got.data_ptr()), 4, 20, C.c_void_p(got.data_ptr()), 0, None) == -1
+
+
+def _spelled(km):
+    """[m][3k+1][k]: every k-mer, then its single substitutions position by position, alternatives in ACGT order."""
+    m, k = km.shape
+    out = np.repeat(km[:, None, :], 3 * k + 1, axis=1)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for pos in range(k):
+        for q in range(m):
+            out[q, 1 + 3 * pos:4 + 3 * pos, pos] = [c for c in acgt if c != km[q, pos]][:3]
+    return out
+
+
+@pytest.mark.parametrize("tables", [7, 0])
+def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
+    """rsbwt_set_hits_1mm_dev on a one-device set whose shards share a table depth traces the k-mers and resumes their
+    variants in ALL shards by one launch each (csrc/sets.hip, set_hits_1mm_fused): every shard's list = the oracle's
+    exact search of every spelled-out variant (query.cpp:24-41 per variant), ordered by variant index; a short list
+    buffer keeps the count; the set's own counters show the fused launches ran."""
+    import torch
+    L = rsb.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    sizes = [300000, 40000, 900000]
+    shards, oixs = [], []
+    for i, R in enumerate(sizes):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 2700 + i) == 0
+        oixs.append(oracle.from_runs(runs))
+        shards.append(rsb.GpuBWT(runs=runs, ktab_depth=None))
+    ss = rsb.ShardSet(shards)
+    if tables:
+        assert L.rsbwt_set_attach_ktabs(ss._s, tables) == 0
+    S = len(sizes)
+    rng = np.random.default_rng(61)
+    for k, m in ((31, 400), (12, 600), (7, 300), (33, 120)):
+        km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(m, k))
+        d_half = torch.empty((m // 2, k), dtype=torch.uint8, device=dev)
+        assert L.rsbwt_sample_present_kmers_dev(shards[2].handle, m // 2, k, k, 5, p(d_half), None) == 0
+        torch.cuda.synchronize()
+        km[: m // 2] = d_half.cpu().numpy()
+        km[1::5, k // 3] = ord("G")  # one substitution away from a present k-mer, often
+        km[7, k // 2] = ord("N")
+        V, wpq = 3 * k + 1, (k + 31) // 32
+        d_km = torch.from_numpy(km).to(dev)
+        d_pk = torch.empty((m, wpq), dtype=torch.int64, device=dev)
+        d_ok = torch.empty(m, dtype=torch.uint8, device=dev)
+        assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+        variants = _spelled(km).reshape(m * V, k)
+        want, dense = [], []
+        for oix in oixs:
+            elo, eup = oix.find_intervals(variants, nthreads=8)
+            elo[7 * V:8 * V], eup[7 * V:8 * V] = 1, 0  # a k-mer with a foreign symbol is invalid as a whole
+            idx = np.nonzero(elo <= eup)[0]
+            want.append((idx, elo[idx], eup[idx]))
+            dense.append((elo, eup))
+        # the dense form (rsbwt_set_find_intervals_1mm_dev: [S][m][3k+1] lower and upper) through the same launches
+        d_lo = torch.full((S, m, V), -1, dtype=torch.int64, device=dev)
+        d_up = torch.full((S, m, V), -1, dtype=torch.int64, device=dev)
+        d_scr1 = torch.empty(L.rsbwt_set_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device=dev)
+        assert L.rsbwt_set_find_intervals_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_lo), p(d_up), p(d_scr1), None) == 0
+        torch.cuda.synchronize()
+        for s in range(S):
+            assert np.array_equal(d_lo[s].cpu().numpy().view(np.uint64).reshape(-1), dense[s][0]), (k, s)
+            assert np.array_equal(d_up[s].cpu().numpy().view(np.uint64).reshape(-1), dense[s][1]), (k, s)
+        assert sum(len(w[0]) for w in want) > m // 2
+        d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device=dev)
+        assert L.rsbwt_set_hits_1mm_is_fused(ss._s, m, k) == 1
+        for cap in (8 * m, 3):
+            d_hits = torch.full((S, cap, 4), -1, dtype=torch.int64, device=dev)
+            d_tot = torch.full((S,), -1, dtype=torch.int64, device=dev)
+            assert L.rsbwt_set_set_counting(ss._s, 1) == 0
+            assert L.rsbwt_set_hits_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_hits), cap, p(d_tot), p(d_scr), None) == 0
+            torch.cuda.synchronize()
+            w = (C.c_uint64 * 16)()
+            assert L.rsbwt_set_last_search_counters(ss._s, w) == 0 and L.rsbwt_set_set_counting(ss._s, 0) == 0
+            assert int(w[10]) > 0  # WORK_PASSES of the set's own launch
+            for s in range(S):
+                idx, elo, eup = want[s]
+                assert int(d_tot[s].item()) == len(idx), (k, s)
+                n = min(cap, len(idx))
+                rec = d_hits[s, :n].cpu().numpy().view(np.uint64)
+                assert np.array_equal(rec[:, 2], idx[:n].astype(np.uint64)), (k, s)
+                assert np.array_equal(rec[:, 0], elo[:n]) and np.array_equal(rec[:, 1], eup[:n]), (k, s)
+                assert not rec[:, 3].any()
+                assert (d_hits[s, n:] == -1).all()  # nothing past the list's end
+    ss.close()
+    for g in shards:
+        g.close()

@@ -84,8 +84,11 @@ d_scr = torch.empty(L.rsbwt_set_1mm_scratch_bytes(sset._s, M, k), dtype=torch.ui
 ok(L.rsbwt_pack_kmers_dev(p(d_km), M, k, k, p(d_pk), p(d_ok), 0, None))
 run1 = lambda: ok(L.rsbwt_set_find_intervals_1mm_dev(sset._s, p(d_pk), p(d_ok), M, k, p(d_lo), p(d_up), p(d_scr), None))
 w = [0] * 16
+# a set whose shards share a table depth searches them all in one traced and one resumed launch, metered by the set
+fused = bool(L.rsbwt_set_hits_1mm_is_fused(sset._s, M, k))
 for h in shards:  # counters of every shard's resumed search of the m x (3k+1) variants
     ok(L.rsbwt_set_counting(h.handle, 1))
+ok(L.rsbwt_set_set_counting(sset._s, 1))
 run1()
 torch.cuda.synchronize()
 for h in shards:
@@ -93,6 +96,11 @@ for h in shards:
     ok(L.rsbwt_last_search_counters(h.handle, wi))
     ok(L.rsbwt_set_counting(h.handle, 0))
     w = [a + int(b) for a, b in zip(w, wi)]
+ws = (C.c_uint64 * 16)()
+ok(L.rsbwt_set_last_search_counters(sset._s, ws))
+ok(L.rsbwt_set_set_counting(sset._s, 0))
+if fused:
+    w = [int(x) for x in ws]
 for _ in range(2):
     run1()
 torch.cuda.synchronize()
@@ -103,11 +111,16 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 kms = 0.0
-for h in shards:
+for h in ([] if fused else shards):
     buf = (C.c_float * 64)()
     cnt = C.c_size_t()
     ok(L.rsbwt_search_history_ms(h.handle, buf, 2 * reps, C.byref(cnt)))
     kms += sum(buf[:cnt.value]) / reps  # traced + resumed search kernels of one call, every shard
+if fused:
+    buf = (C.c_float * 64)()
+    cnt = C.c_size_t()
+    ok(L.rsbwt_set_search_history_ms(sset._s, buf, 2 * reps, C.byref(cnt)))
+    kms = sum(buf[:cnt.value]) / reps
 alg = w[2] * 128 + S * M * V * 40
 hits = int((d_up >= d_lo).sum().item())
 out["one_mismatch"] = {
