@@ -5,6 +5,7 @@ against the oracle -- intervals, counts, the 1-mismatch hit list against the den
 extraction row by row, and (two-shard sets) the set-level hit lists and query lists.  Test infrastructure: the oracle is the checker, as in tests/.
 Prints a progress line per configuration and one JSON line at the end; exit code 1 on any difference.
 usage: tools/fuzz_parity.py [seconds=300] [seed=1]"""
+import ctypes as C
 import json
 import os
 import sys
@@ -25,7 +26,7 @@ orc = oracle_binding.load()
 rng = np.random.default_rng(SEED)
 acgt = np.frombuffer(b"ACGT", np.uint8)
 t_end = time.time() + SECONDS
-done, failures = 0, []
+done, failures, sets, fused_sets = 0, [], 0, 0
 
 
 def make_runs(R, shape):
@@ -86,7 +87,9 @@ while time.time() < t_end:
             if rng.random() < 0.15:  # a shard set: this shard next to a second one, one fused launch
                 runs2 = make_runs(int(2 ** rng.uniform(0, 19)), int(rng.integers(0, 6)))
                 oix2 = orc.from_runs(runs2)
-                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5][int(rng.integers(0, 3))]) as g2:
+                # (a second shard with the first one's table depth: the set then searches both in one traced and one
+                # resumed launch, csrc/sets.hip set_hits_1mm_fused)
+                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))]) as g2:
                     ss = rsb.ShardSet([g, g2])
                     slo, sup = ss.find_intervals(km[:5000])
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
@@ -97,6 +100,25 @@ while time.time() < t_end:
                         sh, first = ss.hits_1mm(km[:60])
                         ok2 = ok2 and np.array_equal(sh[int(first[0]):int(first[1])], rsb.hits_1mm_batch(g, km[:60]))
                         ok2 = ok2 and np.array_equal(sh[int(first[1]):int(first[2])], rsb.hits_1mm_batch(g2, km[:60]))
+                        # the device-resident form (fused launches when both tables have one depth) leaves the same lists
+                        import torch
+                        p_ = lambda t: C.c_void_p(t.data_ptr())
+                        d_km = torch.from_numpy(km[:60].copy()).cuda()
+                        d_pk = torch.empty((60, (k + 31) // 32), dtype=torch.int64, device="cuda")
+                        d_ok = torch.empty(60, dtype=torch.uint8, device="cuda")
+                        cap1 = max(1, len(sh))
+                        d_h = torch.zeros((2, cap1, 4), dtype=torch.int64, device="cuda")
+                        d_t = torch.zeros(2, dtype=torch.int64, device="cuda")
+                        d_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, 60, k), dtype=torch.uint8, device="cuda")
+                        assert L.rsbwt_pack_kmers_dev(p_(d_km), 60, k, k, p_(d_pk), p_(d_ok), 0, None) == 0
+                        assert L.rsbwt_set_hits_1mm_dev(ss._s, p_(d_pk), p_(d_ok), 60, k, p_(d_h), cap1, p_(d_t), p_(d_s), None) == 0
+                        torch.cuda.synchronize()
+                        cfg["set_1mm_fused"] = int(L.rsbwt_set_hits_1mm_is_fused(ss._s, 60, k))
+                        for si in range(2):
+                            mine = sh[int(first[si]):int(first[si + 1])]
+                            rec = d_h[si, :int(d_t[si].item())].cpu().numpy().view(np.uint64)
+                            ok2 = ok2 and rec.shape[0] == len(mine) and np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
+                            ok2 = ok2 and np.array_equal(rec[:, 2] // (3 * k + 1), mine["query"].astype(np.uint64))
                     # query() in every shard, lists concatenated per k-mer -- for k-mers whose intervals are narrow in
                     # both shards (every row of an interval is extracted into a 2 KB buffer: a 1-mer's would be gigabytes)
                     w1 = np.where(eup[:5000] >= elo[:5000], eup[:5000] - elo[:5000] + 1, 0)
@@ -150,6 +172,8 @@ while time.time() < t_end:
                 if tx is not None and len(tx) <= stride:
                     assert ln[i] != 0xFFFFFFFF and out[i, :ln[i]].tobytes() == tx, f"extraction of row {int(rows[i])}"
         done += 1
+        sets += 1 if cfg.get("set") else 0
+        fused_sets += cfg.get("set_1mm_fused", 0)
         print(f"ok {done}: {cfg}", file=sys.stderr, flush=True)
     except AssertionError as e:
         failures.append({"config": cfg, "what": str(e)})
@@ -157,5 +181,6 @@ while time.time() < t_end:
         if len(failures) >= 5:
             break
     oix.close()
-print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "failures": failures}))
+print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "as_two_shard_sets": sets,
+                  "sets_searched_by_the_fused_1mm_launches": fused_sets, "failures": failures}))
 sys.exit(1 if failures else 0)
