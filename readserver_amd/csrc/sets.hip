@@ -600,7 +600,7 @@ struct fused_1mm_layout {
 static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L) {
     static const bool off = getenv("RSBWT_SET_1MM_UNFUSED") != nullptr;  // A/B knob (tools/README.md)
     const size_t S = s->shards.size(), mv = m * (3 * (size_t)k + 1);
-    if (off || S < 2 || s->groups.size() != 1 || mv >= SIDE_BY_SIDE_BELOW || k > 32767u) return false;
+    if (off || S < 2 || S > 1024 || s->groups.size() != 1 || mv >= SIDE_BY_SIDE_BELOW || k > 32767u) return false;  // (S: a grid row per shard)
     const uint32_t tn = trace_entries(s->shards[0]->view, k);
     for (const rsbwt_t *h : s->shards)
         if (trace_entries(h->view, k) != tn || h->view.n == 0) return false;
