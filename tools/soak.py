@@ -7,6 +7,7 @@ single-threaded before the soak.  Also records the slowest call of each kind (a 
 call in a few thousand is how the hipMallocAsync problem of profiles/r02d_latency.md showed).
 Prints one JSON line; exit code 1 on any mismatch or error.
 usage: tools/soak.py [seconds=120] [threads=8] [run_bytes=5e8]"""
+import ctypes as C
 import json
 import os
 import sys
@@ -47,6 +48,25 @@ pl = np.empty(rows.size, np.uint32)
 assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
 ref_out, ref_ln, ref_pl = out, ln, pl
 ref_1lo, ref_1up = rsb.find_intervals_1mm(g, km[:2000])
+# the device-resident hit lists of the set (both shards in one traced and one resumed launch when their tables have one
+# depth: csrc/sets.hip, set_hits_1mm_fused): the lists of the first 2000 k-mers, single-threaded
+import torch  # noqa: E402
+V = 3 * k + 1
+DEV = torch.device("cuda", 0)
+ptr = lambda t: C.c_void_p(t.data_ptr())
+d_km = torch.from_numpy(km[:2000].copy()).to(DEV)
+d_pk = torch.empty(2000, dtype=torch.int64, device=DEV)
+d_ok = torch.empty(2000, dtype=torch.uint8, device=DEV)
+assert L.rsbwt_pack_kmers_dev(ptr(d_km), 2000, k, k, ptr(d_pk), ptr(d_ok), 0, None) == 0
+CAP1 = 8 * 2000
+_h = torch.zeros((2, CAP1, 4), dtype=torch.int64, device=DEV)
+_t = torch.zeros(2, dtype=torch.int64, device=DEV)
+_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(sset._s, 2000, k), dtype=torch.uint8, device=DEV)
+assert L.rsbwt_set_hits_1mm_dev(sset._s, ptr(d_pk), ptr(d_ok), 2000, k, ptr(_h), CAP1, ptr(_t), ptr(_s), None) == 0
+torch.cuda.synchronize()
+ref_hits = [_h[si, :int(_t[si].item())].cpu().numpy().view(np.uint64) for si in range(2)]
+fused_1mm = int(L.rsbwt_set_hits_1mm_is_fused(sset._s, 500, k))
+del _h, _t, _s
 
 stats = {}
 errors = []
@@ -64,9 +84,14 @@ def note(kind, dt):
 
 def worker(seed):
     r = np.random.default_rng(seed)
+    st = torch.cuda.Stream(device=DEV)
+    sp = C.c_void_p(st.cuda_stream)
+    w_h = torch.zeros((2, 8 * 500, 4), dtype=torch.int64, device=DEV)
+    w_t = torch.zeros(2, dtype=torch.int64, device=DEV)
+    w_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(sset._s, 500, k), dtype=torch.uint8, device=DEV)
     try:
         while time.time() < stop_at:
-            op = int(r.integers(0, 6))
+            op = int(r.integers(0, 7))
             size = int(2 ** r.uniform(0, 15.5))
             a = int(r.integers(0, POOL - size))
             t0 = time.perf_counter()
@@ -95,6 +120,19 @@ def worker(seed):
                 fits = l1 != 0xFFFFFFFF
                 ok = ok and all(np.array_equal(o[i, :l1[i]], ref_out[b + i, :l1[i]]) for i in np.nonzero(fits)[0][:200])
                 kind = "extract"
+            elif op == 6:
+                m = min(size, 500)
+                b = int(r.integers(0, 2000 - m))
+                rc = L.rsbwt_set_hits_1mm_dev(sset._s, C.c_void_p(d_pk.data_ptr() + 8 * b), C.c_void_p(d_ok.data_ptr() + b), m, k,
+                                              ptr(w_h), 8 * 500, ptr(w_t), ptr(w_s), sp)
+                st.synchronize()
+                ok = rc == 0
+                for si in range(2):
+                    want = ref_hits[si][(ref_hits[si][:, 2] >= b * V) & (ref_hits[si][:, 2] < (b + m) * V)].copy()
+                    want[:, 2] -= b * V
+                    got = w_h[si, :int(w_t[si].item())].cpu().numpy().view(np.uint64)
+                    ok = ok and np.array_equal(got, want)
+                kind = "set_hits_1mm_dev"
             else:
                 m = min(size, 500)
                 b = int(r.integers(0, 2000 - m))
@@ -124,6 +162,7 @@ while any(t.is_alive() for t in threads):  # a line every half minute: a silent 
 for t in threads:
     t.join()
 res = {"seconds": round(time.time() - t0, 1), "threads": NT, "run_bytes_per_shard": R, "symbols_per_shard": int(n),
+       "set_hits_1mm_dev_runs_as_the_fused_launches": fused_1mm,
        "calls": {k_: {"calls": v["calls"], "mean_ms": round(v["total_s"] / v["calls"] * 1e3, 3), "worst_ms": round(v["worst_ms"], 2)}
                  for k_, v in sorted(stats.items())},
        "errors": errors[:5]}
