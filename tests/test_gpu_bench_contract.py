@@ -68,3 +68,12 @@ def test_gpu_bench_launches_its_own_ranks():
     _common(d, 2)
     assert d["config"]["gather_verified"] is True and "REHEARSAL" in d["config"]["multi_gpu"]
     assert d["config"]["shards"] == 4
+
+
+@pytest.mark.parametrize("mode,extra,key", [("1mm", ["--kmers", "2e4"], "hit_lists_verified"), ("extract", ["--rows", "1e5"], "reads_verified")])
+def test_gpu_bench_rows_modes_over_two_ranks(mode, extra, key):
+    """configs[3] / configs[4] at N = 2 from the plain command (two ranks on the one GPU, gathered over gloo): rank 0
+    holds every rank's lists / reads in global shard order, checked against the ranks' checksums."""
+    d = _run(SMALL + ["--mode", mode, "--gpus", "2", "--rehearse-on-one-gpu"] + extra)
+    _common(d, 2)
+    assert d["config"][key] is True and "REHEARSAL" in d["config"]["multi_gpu"]
