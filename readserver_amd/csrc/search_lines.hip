@@ -634,7 +634,12 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         return v > 0 ? v : RSB_MIN_WGS_PER_CU;
     }();
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
-    const bool solo = !table_build && (choice == 1 || (choice == 2 && nshards == 1 && extra && extra->narrow && Q >= cap * WG_WAVES * 64u));
+    // (the variants of a 1-mismatch search that resume from a trace start on their k-mer's narrow interval and live
+    // 2.4 steps: what bounds their launch is how fast searches are taken up, and a wave of lone lanes takes up 64 per
+    // pass where pairs take 32 -- any number of shards: 25.0 -> 23.5 ms per batch of 4e5 31-mers x 8 shards)
+    const bool resumed = extra && extra->d_trace_in;
+    const bool solo = !table_build && (choice == 1 || (choice == 2 && Q * nshards >= cap * WG_WAVES * 64u &&
+                                                       (resumed || (nshards == 1 && extra && extra->narrow))));
     // 32 (pairs) or 64 (solo) searches per wave, 4 waves per workgroup
     const size_t per_wg = (solo ? 64u : 32u) * WG_WAVES;
     g = (Q * nshards + per_wg - 1) / per_wg;
