@@ -570,7 +570,9 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
 }
 
 // Device-resident forms for a set on ONE device (one process per GPU drives its shards this way: bench.py).
-// The shards take turns on the stream: each turn is a batch large enough to fill the GPU by itself.
+// Three ways, best first: (1) all the shards in ONE traced and ONE resumed launch (fused_1mm_applies, below: tables of
+// one depth); (2) else side by side; (3) at or above 2^26 variant searches per shard the shards take turns on the
+// stream: each turn is a batch large enough to fill the GPU by itself.
 // Below this many variant searches per shard (2^26 = 7e5 31-mers; a scratch per shard is what bounds it) the shards of
 // the set work SIDE BY SIDE, each on a stream of its own with a scratch of its own (forked from and joined to the
 // caller's stream with events), instead of taking turns: a shard's own sequence -- variants, start records, the traced
