@@ -432,7 +432,9 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
         assert L.rsbwt_set_attach_ktabs(ss._s, tables) == 0
     S = len(sizes)
     rng = np.random.default_rng(61)
-    for k, m in ((31, 400), (12, 600), (7, 300), (33, 120)):
+    # (31, 1000): 3 x 1000 x 94 = 282,000 variant searches -- the resumed launch then runs on the one-lane-per-search
+    # kernel (search_lines.hip, launch_search: >= 262,144 searches), with the per-shard traces and hit maps there
+    for k, m in ((31, 400), (12, 600), (7, 300), (33, 120), (31, 1000)):
         km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(m, k))
         d_half = torch.empty((m // 2, k), dtype=torch.uint8, device=dev)
         assert L.rsbwt_sample_present_kmers_dev(shards[2].handle, m // 2, k, k, 5, p(d_half), None) == 0
@@ -474,6 +476,8 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
             w = (C.c_uint64 * 16)()
             assert L.rsbwt_set_last_search_counters(ss._s, w) == 0 and L.rsbwt_set_set_counting(ss._s, 0) == 0
             assert int(w[10]) > 0  # WORK_PASSES of the set's own launch
+            if tables and m * V * S >= 262144:
+                assert int(w[12]) == 1  # WORK_SOLO: the resumed launch ran on lone lanes
             for s in range(S):
                 idx, elo, eup = want[s]
                 assert int(d_tot[s].item()) == len(idx), (k, s)
