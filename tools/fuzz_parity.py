@@ -144,7 +144,9 @@ while time.time() < t_end:
                 assert ok2, "shard set"
                 cfg["set"] = True
             if k <= 40:
-                m = 150
+                # (now and then enough variant searches for the resumed launch to take the one-lane-per-search kernel)
+                m = 3000 if (Q >= 3000 and rng.random() < 0.08) else 150
+                cfg["m_1mm"] = m
                 dlo, dup = rsb.find_intervals_1mm(g, km[:m])
                 want = []
                 for qi in range(m):
