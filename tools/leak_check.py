@@ -43,6 +43,31 @@ def cycle(i):
     ln = np.empty(rows.size, np.uint32)
     pl = np.empty(rows.size, np.uint32)
     assert L.rsbwt_extract(shards[0].handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
+    # the set-level forms of configs[3] / configs[4], host and device-resident (the fused 1-mismatch launches when the
+    # tables have one depth, else the set's side streams; the walks side by side on them)
+    ss.hits_1mm(km[:400])
+    try:  # (the mirror raises when a read of this random stream is longer than the buffer: the call was made all the same)
+        ss.extract(np.repeat(np.arange(2), 500), rows[:1000].astype(np.int64) % min(g.getBWLen() for g in shards), stride=1024)
+    except rsb.RsbwtError:
+        pass
+    p_ = lambda t: C.c_void_p(t.data_ptr())
+    m = 700
+    d_km = torch.from_numpy(km[:m].copy()).cuda()
+    d_pk = torch.empty(m, dtype=torch.int64, device="cuda")
+    d_ok = torch.empty(m, dtype=torch.uint8, device="cuda")
+    assert L.rsbwt_pack_kmers_dev(p_(d_km), m, k, k, p_(d_pk), p_(d_ok), 0, None) == 0
+    d_h = torch.empty((2, 8 * m, 4), dtype=torch.int64, device="cuda")
+    d_t = torch.empty(2, dtype=torch.int64, device="cuda")
+    d_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device="cuda")
+    assert L.rsbwt_set_hits_1mm_dev(ss._s, p_(d_pk), p_(d_ok), m, k, p_(d_h), 8 * m, p_(d_t), p_(d_s), None) == 0
+    d_r = torch.from_numpy((rows[:2000].astype(np.int64) % min(g.getBWLen() for g in shards)).reshape(2, 1000)).cuda()
+    d_o = torch.empty((2, 1000, 256), dtype=torch.uint8, device="cuda")
+    d_l = torch.empty((2, 1000), dtype=torch.int32, device="cuda")
+    d_p = torch.empty((2, 1000), dtype=torch.int32, device="cuda")
+    assert L.rsbwt_set_extract_dev(ss._s, p_(d_r), 1000, p_(d_o), 256, p_(d_l), p_(d_p), None) == 0
+    torch.cuda.synchronize()
+    del d_km, d_pk, d_ok, d_h, d_t, d_s, d_r, d_o, d_l, d_p
+    torch.cuda.empty_cache()
     tr, svc = C.c_void_p(), C.c_void_p()
     assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
     assert L.rsbwt_service_create(ss._s, tr, 100, 256, 1, C.byref(svc)) == 0
