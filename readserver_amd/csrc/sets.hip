@@ -617,6 +617,31 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
     return true;
 }
 
+// The two fused launches: the k-mers traced in every shard (when the tables leave something to trace), then their
+// variants (expanded at d_var: variants_of_batch_dev's layout) resumed in every shard.  d_bits != nullptr: sparse
+// results at d_lower + the hit maps; else dense [S][m][3k+1] lower and upper.
+static int fused_1mm_launches(rsbwt_set_t *s, dev_group *g, const fused_1mm_layout &L, const void *d_packed, const void *d_valid,
+                              size_t m, uint32_t k, const uint8_t *d_var, uint8_t *d_trace, uint8_t *d_own, void *d_lower,
+                              void *d_upper, void *d_bits, hipStream_t st) {
+    const uint32_t S = (uint32_t)s->shards.size();
+    const size_t V = 3 * (size_t)k + 1, mv = m * V;
+    const uint8_t *d_vok = d_var + ((mv * ((k + 31u) / 32u) * 8 + 15) & ~(size_t)15);
+    search_extra resumed;
+    if (L.tn) {
+        search_extra traced;
+        traced.d_trace_out = d_trace;
+        traced.trace_n = L.tn;
+        traced.pairs = true;
+        const int rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced);
+        if (rc) return rc;
+        resumed.d_trace_in = d_trace;
+        resumed.trace_n = L.tn;
+        resumed.variants = (uint32_t)V;
+    }
+    resumed.d_hit_bits = d_bits;
+    return search_launch(*g, g->d_views, S, g->num_cus, d_var, d_vok, mv, k, d_lower, d_upper, false, st, &resumed);
+}
+
 // 1-mismatch search over the shards of a one-device set: the fused launches above where they apply (dense
 // results: the resumed launch writes [S][m][3k+1] lower and upper itself), else the shards take turns on the stream,
 // each turn m x (3k+1) searches of one shard.
@@ -642,24 +667,9 @@ static int rsbwt_set_find_intervals_1mm_dev_body(rsbwt_set_t *s, const void *d_p
         dev_group *g = s->groups[0];
         int rc = use_device(g->device);
         if (rc) return rc;
-        const uint32_t S = (uint32_t)s->shards.size();
-        const size_t V = 3 * (size_t)k + 1, mv = m * V;
         uint8_t *d_var = (uint8_t *)d_scratch, *d_trace = d_var + ((variants_bytes(m, k) + 255) & ~(size_t)255), *d_own = d_trace + L.trace;
         if ((rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
-        const uint8_t *d_vok = d_var + ((mv * ((k + 31u) / 32u) * 8 + 15) & ~(size_t)15);  // variants_of_batch_dev's layout
-        search_extra resumed;
-        if (L.tn) {
-            search_extra traced;
-            traced.d_trace_out = d_trace;
-            traced.trace_n = L.tn;
-            traced.pairs = true;
-            if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, (hipStream_t)stream, &traced)) != RSBWT_OK)
-                return rc;
-            resumed.d_trace_in = d_trace;
-            resumed.trace_n = L.tn;
-            resumed.variants = (uint32_t)V;
-        }
-        return search_launch(*g, g->d_views, S, g->num_cus, d_var, d_vok, mv, k, d_lower, d_upper, false, (hipStream_t)stream, &resumed);
+        return fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_lower, d_upper, nullptr, (hipStream_t)stream);
     }
     for (size_t i = 0; i < s->shards.size(); ++i) {
         const int rc = rsbwt_find_intervals_1mm_dev(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_lower + i * row,
@@ -891,28 +901,12 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
                               size_t m, uint32_t k, void *d_hits, size_t cap_per_shard, void *d_totals, const uint8_t *d_var,
                               uint8_t *d_parts, hipStream_t st) {
     const uint32_t S = (uint32_t)s->shards.size();
-    const size_t V = 3 * (size_t)k + 1, mv = m * V;
-    const size_t a_vpk = (mv * ((k + 31u) / 32u) * 8 + 15) & ~(size_t)15;  // variants_of_batch_dev's layout
-    const uint8_t *d_vpk = d_var, *d_vok = d_var + a_vpk;
+    const size_t mv = m * (3 * (size_t)k + 1);
     uint8_t *d_trace = d_parts, *d_own = d_trace + L.trace, *d_sparse = d_own + L.own, *d_bits = d_sparse + L.sparse;
     uint8_t *d_blocks = d_bits + L.bits;
     HIP_OK(hipMemsetAsync(d_bits, 0, (size_t)S * hit_map_words(mv) * 8, st));
-    int rc;
-    search_extra resumed;
-    if (L.tn) {
-        search_extra traced;
-        traced.d_trace_out = d_trace;
-        traced.trace_n = L.tn;
-        traced.pairs = true;
-        if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced)) != RSBWT_OK)
-            return rc;
-        resumed.d_trace_in = d_trace;
-        resumed.trace_n = L.tn;
-        resumed.variants = (uint32_t)V;
-    }
-    resumed.d_hit_bits = d_bits;
-    if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_vpk, d_vok, mv, k, d_sparse, nullptr, false, st, &resumed)) != RSBWT_OK)
-        return rc;
+    const int rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);
+    if (rc) return rc;
     const hipError_t e = launch_compact_hits(d_bits, d_sparse, mv, d_hits, cap_per_shard, d_totals, d_blocks, st, S);
     return e == hipSuccess ? RSBWT_OK : fail_hip(e, "hit list kernels");
 }
