@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
     ap.add_argument("--window-span", type=int, default=0, help="symbols per window line (0 = from the data)")
+    ap.add_argument("--layout", choices=["auto", "plain", "reads"], default="auto",
+                    help="reads = RSBWT_OPEN_READS: a psi hint in every window line, built with the index (~9 %% more lines): "
+                         "what a shard that serves read extraction is opened with; auto = reads for --mode extract, plain otherwise")
     ap.add_argument("--separate-arrays", action="store_true",
                     help="results as lower[S][Q] and upper[S][Q] (two scattered 8-byte stores per search) instead of "
                          "{lower, upper}[S][Q] pairs (one 16-byte store)")
@@ -247,7 +250,8 @@ def build_shards(a, c, mix, want_host_runs=False):
         torch.cuda.synchronize()
         # tables are sized afterwards, for all shards of the GPU together (explicit depth: now)
         g = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=c.local,
-                       ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span)
+                       ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span,
+                       for_reads=(a.layout == "reads" or (a.layout == "auto" and a.mode == "extract")))
         if want_host_runs and s == 0:
             host_runs = d_runs.cpu().numpy()
         del d_runs
@@ -697,6 +701,8 @@ def run_rows(a, c):
     common = {"shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": R, "symbols_per_shard": n_sym,
               "stream": STREAM_NOTE[a.stream], "mix": mix + ": " + MIX_NOTE[mix], "k": k, "ktab_depth": shards[0].ktab_depth(),
               "window_span": shards[0].window_span(), "index_build_s": round(t_build, 2),
+              "layout": ("reads: a psi hint in every window line (RSBWT_OPEN_READS)" if L.rsbwt_opened_for_reads(shards[0].handle) else "plain"),
+              "index_hbm_bytes_per_gpu": int(sum(int(L.rsbwt_hbm_bytes(g.handle)) for g in shards)),
               "multi_gpu": ("REHEARSAL on one GPU over gloo: not a measurement" if a.rehearse_on_one_gpu else "measured" if world > 1 else "one GPU")}
 
     def barrier():
@@ -862,12 +868,12 @@ def run_rows(a, c):
                 gat_o.drain()
                 gat_l.drain()
 
-        ok(c, L.rsbwt_set_counting(shards[0].handle, 1))
+        ok(c, L.rsbwt_set_set_counting(sset._s, 1))
         step()
         torch.cuda.synchronize()
         xw = (C.c_uint64 * 16)()
-        ok(c, L.rsbwt_last_search_counters(shards[0].handle, xw))  # the walk kernels' counters of the last shard that ran with counting on
-        ok(c, L.rsbwt_set_counting(shards[0].handle, 0))
+        ok(c, L.rsbwt_set_last_search_counters(sset._s, xw))  # the walk kernels' counters: one launch sequence walks every shard of the GPU
+        ok(c, L.rsbwt_set_set_counting(sset._s, 0))
         names = ["passes", "lanes_with_a_row", "steps", "lanes_on_a_continuation", "lines_fetched", "cycles", "cycles_fetch_to_landed", "steps_from_line_hint"]
         walk = {"prefix": dict(zip(names, [int(v) for v in xw[:8]])), "postfix": dict(zip(names, [int(v) for v in xw[8:]]))}
         lens0 = d_lenb[0].reshape(-1)
@@ -918,12 +924,12 @@ def run_rows(a, c):
                            f"{world * S} shards ({S} per GPU), rows in runs of {run} consecutive rows (the rows of an interval)"
                            + (", reads gathered on rank 0 and concatenated in shard order" if world > 1 else ""),
                            rows_per_shard=NR, row_run=run, stride=stride, rows_fitting_stride=int(fits.sum()) / max(ln.size, 1),
-                           mean_read_length=bases / max(int(fits.sum()), 1), reads_verified=verified, walk_counters_one_shard=walk,
+                           mean_read_length=bases / max(int(fits.sum()), 1), reads_verified=verified, walk_counters=walk,
                            window_lines_with_a_psi_hint=int(L.rsbwt_psi_hint_lines(shards[0].handle)) / max(int(shards[0].num_lines()) * 16 // 17, 1),
                            travels=(None if world == 1 else f"[{S}][{NR}][{stride // 4}] bytes of 2-bit bases (rsbwt_pack_reads_dev) + [{S}][{NR}] lengths per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "extract_prefix_wave_kernel + extract_postfix_wave_kernel, over the rank's shards",
+                         "kernel": "extract_prefix_wave_kernel + move_prefix16_kernel + extract_postfix_wave_kernel: one launch each over all the rank's shards",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": steps_alg * LINE_BYTES, "lf_and_psi_steps": steps_alg},
             "cpu_baseline": None,
         }

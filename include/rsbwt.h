@@ -44,11 +44,20 @@ extern "C" {
 #define RSBWT_ESYS (-8)    /* the host runtime failed (a thread could not be started, ...)   */
 
 /* open flags */
-/* bits 0..4: reserved (0).
+/* bit 0: RSBWT_OPEN_READS -- the shard will serve read extraction (extractPrefix / extractPostfix, query(),
+ * src/bwt/query.cpp:43-100: what the reference's find_reads does with every interval): every window line is laid
+ * out with room for a psi hint (88 of its 96 piece bytes hold pieces, so ~9 % more lines), the hints and a sparse
+ * select-sample table (n / 512 bytes) are built as part of the open, and the index is immutable from then on.
+ * Extraction's select then finds its window in the line the walk already stands in: one HBM request per step.
+ * Without the flag the layout is the denser one; the first extraction / getOccAt then builds a dense sample
+ * table (n / 32 bytes) and writes hints into the lines that happen to have room (about 6 in 10) -- into the
+ * resident lines, where no search reads them, but an index a search-only deployment never pays for.
+ * bits 1..4: reserved (0).
  * bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
  * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (the deepest table
  * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n; rsbwt_set_open
  * sizes the tables of one GPU's shards together), 31 = no table, else T = 2..16 (T = 16: 34 GB). */
+#define RSBWT_OPEN_READS 1u
 #define RSBWT_KTAB_SHIFT 5
 #define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
@@ -106,7 +115,8 @@ uint32_t rsbwt_window_span(const rsbwt_t *h);     /* symbols per window */
 uint64_t rsbwt_far_lines(const rsbwt_t *h);       /* lines that continue windows of > 120 pieces */
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h); /* positions one request past their window's line */
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h);       /* lines + tables */
-uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi hint (0 before the first extraction / getOccAt) */
+uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi hint (without RSBWT_OPEN_READS: 0 before the first extraction / getOccAt) */
+int rsbwt_opened_for_reads(const rsbwt_t *h);     /* 1: laid out with RSBWT_OPEN_READS */
 /* Builds the k-mer table of depth T (2..16) of an open handle that has none. */
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 int rsbwt_device(const rsbwt_t *h);
@@ -438,7 +448,8 @@ void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6);
 /* Test hook (host only, answers no query): lays `runs` out as window lines with the code the GPU
  * builder runs and holds the layout's scalar readers to naive ranks at every position.  stats6 =
  * {S, lines, far lines, chunk windows, far windows, spilled symbols}; *first_bad = first position
- * that disagrees (RSBWT_EFORMAT) or UINT64_MAX. */
+ * that disagrees (RSBWT_EFORMAT) or UINT64_MAX.  Bit 31 of window_span (both hooks): the RSBWT_OPEN_READS
+ * layout. */
 int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
                                uint64_t *stats6, uint64_t *first_bad);
 
@@ -446,7 +457,7 @@ int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t 
  * builder kernels and the walk kernels share with the host (csrc/line_format.h) -- built over a host-side layout of
  * `runs` and held to the naive select at EVERY occurrence and EVERY row, then every scalar reader again over the
  * lines that now carry hints.  stats4 = {sample words, occurrences whose sample is only a bound, lines with a
- * hint, rows answered by a hint}; *first_bad as above. */
+ * hint, rows a hint settles (the others it bounds)}; *first_bad as above. */
 int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span, uint64_t *stats4,
                                    uint64_t *first_bad);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rsbwt_spilled_symbols": (C.c_uint64, [_vp]),
     "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
     "rsbwt_psi_hint_lines": (C.c_uint64, [_vp]),
+    "rsbwt_opened_for_reads": (C.c_int, [_vp]),
     "rsbwt_attach_ktab": (C.c_int, [_vp, C.c_uint32]),
     "rsbwt_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),

@@ -46,13 +46,16 @@ class GpuBWT:
     """
 
     def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
-                 ktab_depth=0, window_span=0):
+                 ktab_depth=0, window_span=0, for_reads=False):
         """ktab_depth: depth of the k-mer table (0 = auto, None = no table).  window_span: symbols
-        per window of the HBM layout (0 = from the data: ~88 run pieces per 128-byte line)."""
+        per window of the HBM layout (0 = from the data: ~88 run pieces per 128-byte line).
+        for_reads: RSBWT_OPEN_READS -- a psi hint in every window line, built with the index
+        (the layout for a shard that serves read extraction)."""
         self._h = C.c_void_p()
         L = lib()
         flags = (31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5
         flags |= (int(window_span) & 0xFFF) << 12
+        flags |= 1 if for_reads else 0
         if filename is not None:
             check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
         elif runs is not None:

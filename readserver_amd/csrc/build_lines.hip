@@ -161,7 +161,7 @@ __device__ void seek_reader(const seek_index &sx, uint64_t P, run_reader &rd) {
 
 __global__ void __launch_bounds__(256, RSB_BUILD_MIN_WGS)
 count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint64_t nwin, uint64_t ngroups,
-                    uint32_t *__restrict__ far_lines, unsigned long long *__restrict__ stats, uint64_t every) {
+                    uint32_t *__restrict__ far_lines, unsigned long long *__restrict__ stats, uint64_t every, bool room) {
     // every > 1: a SAMPLE of the groups (every `every`-th one), statistics only -- what the choice of S is tried on
     // before the one full pass (a full pass reads all the run bytes: 1.2 s for a 20 GB shard)
     const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * every;
@@ -169,7 +169,7 @@ count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint6
     if (g < ngroups) {
         run_reader rd;
         seek_reader(sx, g * GROUP * (uint64_t)sp.S, rd);
-        st = build_group<false>(sp, n, nwin, g, rd, nullptr, 0);
+        st = build_group<false>(sp, n, nwin, g, rd, nullptr, 0, room);
         if (far_lines) far_lines[g] = st.far_lines;
     }
     // statistics: one atomic set per wave
@@ -183,12 +183,12 @@ count_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint6
 
 __global__ void __launch_bounds__(256, RSB_BUILD_MIN_WGS)
 write_groups_kernel(const seek_index sx, const span_params sp, uint64_t n, uint64_t nwin, uint64_t ngroups,
-                    const uint64_t *__restrict__ far_before, uint64_t first_far, uint32_t *__restrict__ lines) {
+                    const uint64_t *__restrict__ far_before, uint64_t first_far, uint32_t *__restrict__ lines, bool room) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
     run_reader rd;
     seek_reader(sx, g * GROUP * (uint64_t)sp.S, rd);
-    build_group<true>(sp, n, nwin, g, rd, lines, first_far + far_before[g]);
+    build_group<true>(sp, n, nwin, g, rd, lines, first_far + far_before[g], room);
 }
 
 // ---- exclusive scan u32 -> u64 (three small kernels)
@@ -254,7 +254,7 @@ scan_final_kernel(const uint32_t *__restrict__ in, uint64_t n, const uint64_t *_
         }                       \
     } while (0)
 
-hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span, hipStream_t stream,
+hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span, bool hint_room, hipStream_t stream,
                        build_result *out, int *build_error) {
     hipError_t err = hipSuccess;
     *build_error = 0;
@@ -272,6 +272,8 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
     shard_view v;
     memset(&v, 0, sizeof v);
     memset(out, 0, sizeof *out);
+    v.sel_shift = hint_room ? SEL_SHIFT_SPARSE : SEL_SHIFT_DENSE;
+    v.hint_room = hint_room ? 1u : 0u;
 
     if (nchunks >= (1ull << 31)) { *build_error = BUILD_ERANGE; return hipSuccess; }
     HIP_TRY(hipMalloc(&d_tile, ntiles * 5 * sizeof(uint32_t)));
@@ -309,27 +311,34 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
         // one request further away on the bench stream; tools/ sweep in DESIGN.md); shrunk while more
         // than 2.5 % of the positions spill or more than 1.5 % of the windows need far lines -- how
         // full a window may be depends on the spread of the run lengths, which only the data tells.
+        // (a shard laid out with room for a psi hint in every window line keeps 88 of a line's 96 piece bytes: the
+        // same fill of what is left)
         const double L = (double)n / (double)(R ? R : 1);
-        span_params sp = make_span(want_span ? want_span : (uint32_t)(88.0 * L + 0.5));
+        const double target = hint_room ? 88.0 * (double)HINT_PIECES / (double)LINE_PIECES : 88.0;
+        span_params sp = make_span(want_span ? want_span : (uint32_t)(target * L + 0.5));
         seek_index sx = {runs, R, d_chunk, d_tile, nchunks, ntiles};
         uint64_t nwin = 0, ngroups = 0, nsum = 0;
         // S is first tried on a sample of the groups (one in 64, spread over the whole shard): the spans that
         // would clearly spill too much are passed over without a full pass each.  The full pass below still
         // decides: a span the sample let through is shrunk further if the whole shard says so.
+        // (the layout with hint room is a tenth larger, and eight 20 GB shards of it plus the run bytes of the one being
+        // built are all an MI355X holds: its span comes down in steps of 1.25 %, not 5 %, to the first that passes)
+        const double shrink = hint_room ? 0.9875 : 0.95;
+        const int max_attempts = hint_room ? 16 : 4;
         constexpr uint64_t SAMPLE_EVERY = 64;
         if (!want_span && (n + sp.S - 1) / sp.S / GROUP >= 64 * SAMPLE_EVERY) {
-            for (int attempt = 0; attempt < 4 && sp.S > 8u; ++attempt) {
+            for (int attempt = 0; attempt < max_attempts && sp.S > 8u; ++attempt) {
                 const uint64_t nw = (n + sp.S - 1) / sp.S, ng = (nw + GROUP - 1) / GROUP, ns = (ng + SAMPLE_EVERY - 1) / SAMPLE_EVERY;
                 HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
                 hipLaunchKernelGGL(count_groups_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, sx, sp, n, nw, ng,
-                                   (uint32_t *)nullptr, d_stats, SAMPLE_EVERY);
+                                   (uint32_t *)nullptr, d_stats, SAMPLE_EVERY, hint_room);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 // (held to the limits themselves: a sample within 5 % of them is left to the full pass)
                 const bool ok = stats[3] * SAMPLE_EVERY * 40 <= n + n / 20 && stats[2] * SAMPLE_EVERY * 200 <= (nw + nw / 20) * 3;
                 if (ok) break;
-                const span_params smaller = make_span((uint32_t)((double)sp.S * 0.95));
+                const span_params smaller = make_span((uint32_t)((double)sp.S * shrink));
                 if (smaller.S >= sp.S) break;
                 sp = smaller;
             }
@@ -342,13 +351,13 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
             HIP_TRY(hipMalloc(&d_far, ngroups * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(count_groups_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, stream, sx, sp,
-                               n, nwin, ngroups, d_far, d_stats, (uint64_t)1);
+                               n, nwin, ngroups, d_far, d_stats, (uint64_t)1, hint_room);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             const bool ok = stats[3] * 40 <= n && stats[2] * 200 <= nwin * 3;
-            if (want_span || ok || attempt >= 4 || sp.S <= 8u) break;
-            const span_params smaller = make_span((uint32_t)((double)sp.S * 0.95));
+            if (want_span || ok || attempt >= max_attempts || sp.S <= 8u) break;
+            const span_params smaller = make_span((uint32_t)((double)sp.S * shrink));
             if (smaller.S >= sp.S) break;
             sp = smaller;
             (void)hipFree(d_far);
@@ -365,7 +374,7 @@ hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span
         HIP_TRY(hipMalloc(&d_lines, nlines * LINE_BYTES));
         HIP_TRY(hipMemsetAsync(d_lines, 0, nlines * LINE_BYTES, stream));
         hipLaunchKernelGGL(write_groups_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, stream, sx, sp, n,
-                           nwin, ngroups, d_base, first_far, d_lines);
+                           nwin, ngroups, d_base, first_far, d_lines, hint_room);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         v.lines = d_lines;

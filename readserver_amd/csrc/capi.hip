@@ -254,6 +254,8 @@ int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) {
     return rc;
 }
 
+static int ensure_select_samples(rsbwt_t *h, hipStream_t stream);
+
 static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
                        uint32_t flags, rsbwt_t **out) {
     rsbwt_t *h = new (std::nothrow) rsbwt();
@@ -282,7 +284,7 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
         ctx_guard g(h->pool);
         if (!g.c) { rsbwt_close(h); return fail(RSBWT_EHIP, "cannot create a HIP stream"); }
         const uint32_t want_span = (flags & RSBWT_SPAN_MASK) >> RSBWT_SPAN_SHIFT;
-        e = build_lines(d_runs, num_runs, want_span, g.c->st[0], &br, &berr);
+        e = build_lines(d_runs, num_runs, want_span, (flags & RSBWT_OPEN_READS) != 0u, g.c->st[0], &br, &berr);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -307,6 +309,14 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     h->spilled_symbols = br.spilled_symbols;
     int rc = upload_view(h);
     if (rc) { rsbwt_close(h); return rc; }
+    // a shard opened for reads gets its select samples and psi hints now: the index is complete, and immutable,
+    // before the handle is handed out
+    if ((flags & RSBWT_OPEN_READS) != 0u && h->view.n != 0) {
+        ctx_guard g(h->pool);
+        if (!g.c) { rsbwt_close(h); return fail(RSBWT_EHIP, "cannot create a HIP stream"); }
+        rc = ensure_select_samples(h, g.c->st[0]);
+        if (rc) { rsbwt_close(h); return rc; }
+    }
     // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries take no more
     // HBM than 5/4 of the index itself and no more than a quarter of what is still free (HBM is there
     // to be used: every level replaces one LF step, two Occ lookups, of each query by the same
@@ -443,6 +453,7 @@ uint64_t rsbwt_far_lines(const rsbwt_t *h) { return h->far_lines; }
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h) { return h->spilled_symbols; }
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h) { return h->psi_hint_lines; }
+int rsbwt_opened_for_reads(const rsbwt_t *h) { return h->view.hint_room ? 1 : 0; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
 
 // Test hook: w[i] = p[i] / S, r[i] = p[i] % S as the KERNELS compute them (fast_window); host buffers.
@@ -481,23 +492,28 @@ int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes,
 
 // ---- class BWT mirrors ------------------------------------------------------------------------
 
-// the sampled select table (getOccAt, read extraction): built once, on first use
+// the sampled select table (getOccAt, read extraction) and the psi hints: built once -- at open for a shard opened
+// with RSBWT_OPEN_READS, else on first use
 static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(h->mu);
     if (h->d_sel) return RSBWT_OK;
-    const uint64_t words = 5 * select_sample_stride(h->view);
+    const uint64_t stride_m = select_sample_stride(h->view);
+    const uint64_t words = 5 * stride_m;
     uint64_t *d = nullptr;
     HIP_OK(hipMalloc(&d, words * sizeof(uint64_t)));
     hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint64_t), stream);
     if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
     // and the psi hints, into the window lines that have room for one (line_format.h): extraction's select then
     // needs no sample for the rows of those windows.  Searches that run meanwhile are not disturbed: a hint sits
-    // where a line of at most 88 pieces holds none, and the flag is a header bit no search reads.
+    // where a line holds no piece of its own, and the flag is a header bit no search reads.
+    shard_view with = h->view;
+    with.sel = d;
+    with.sel_stride = stride_m;
     unsigned long long *d_made = nullptr, made = 0;
     if (e == hipSuccess && getenv("RSBWT_NO_PSI_HINTS") == nullptr) {
         e = hipMalloc(&d_made, sizeof made);
         if (e == hipSuccess) e = hipMemsetAsync(d_made, 0, sizeof made, stream);
-        if (e == hipSuccess) e = launch_psi_hints(h->view, d, d_made, stream);
+        if (e == hipSuccess) e = launch_psi_hints(with, d_made, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&made, d_made, sizeof made, hipMemcpyDeviceToHost, stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -507,10 +523,24 @@ static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
         return fail_hip(e, "select sample kernel");
     }
     h->psi_hint_lines = made;
-    h->d_sel = d;
+    h->view = with;
     h->hbm_bytes += words * sizeof(uint64_t);
+    const int rc = upload_view(h);  // (the view in HBM: the walk kernels take the samples from it)
+    if (rc != RSBWT_OK) {
+        h->view.sel = nullptr;
+        h->view.sel_stride = 0;
+        (void)hipFree(d);
+        return rc;
+    }
+    h->d_sel = d;
     return RSBWT_OK;
 }
+
+}  // extern "C"
+namespace rsb {
+int ensure_samples(rsbwt *h, hipStream_t stream) { return ensure_select_samples(h, stream); }
+}  // namespace rsb
+extern "C" {
 
 // kind 0: occ(syms, vals)  1: char(vals)  2: occ_at(syms, vals)
 static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *vals, size_t n, void *out) {
@@ -535,7 +565,7 @@ static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *
     hipError_t e = hipSuccess;
     if (kind == 0) e = launch_occ_batch(h->view, d_syms, d_vals, n, d_out, st);
     else if (kind == 1) e = launch_char_batch(h->view, d_vals, n, d_out, st);
-    else e = launch_occ_at_batch(h->view, h->d_sel, d_syms, d_vals, n, d_out, st);
+    else e = launch_occ_at_batch(h->view, d_syms, d_vals, n, d_out, st);
     if (e != hipSuccess) return fail_hip(e, "mirror kernel launch");
     HIP_OK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -1248,7 +1278,7 @@ static int extract_slices(rsbwt_t *h, call_ctx *c, const uint64_t *rows, size_t 
         uint8_t *base = (uint8_t *)c->d_stage;
         uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
         HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
+        hipError_t e = launch_extract_wave(h->scratch, h->d_view, 1, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
         if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
         if ((rc = fn(i0, m, d_out, d_len, d_pl, d_len + a_len)) != RSBWT_OK) return rc;
     }
@@ -1279,7 +1309,8 @@ int rsbwt_extract(rsbwt_t *h, const uint64_t *rows, size_t n, char *out, uint32_
 }
 
 // Device-resident form: d_rows [n] u64 -> d_out [n][stride] bytes, d_len / d_prefix_len [n] u32 (both
-// required), on `stream`; nothing is synchronised (the select sample table is built on first use).
+// required), on `stream`; nothing is synchronised (without RSBWT_OPEN_READS the select sample table is built on
+// first use).
 int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
                       void *d_prefix_len, void *stream) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
@@ -1295,7 +1326,7 @@ int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uin
         work = h->d_work;
         HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
     }
-    hipError_t e = launch_extract_wave(h->scratch, h->view, h->d_sel, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus,
+    hipError_t e = launch_extract_wave(h->scratch, h->d_view, 1, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus,
                                        (hipStream_t)stream, work);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;

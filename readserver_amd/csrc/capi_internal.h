@@ -96,6 +96,7 @@ int hits_1mm_dev_shared(rsbwt *h, const void *d_packed, const void *d_valid, siz
 // Builds h's k-mer table of depth T into d_table[c * stride] (memory owned by the caller).
 int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride);
 int detach_ktab(rsbwt *h);  // forgets a table it does not own
+int ensure_samples(rsbwt *h, hipStream_t stream);  // the select samples + psi hints of a shard (built once); its view then names them
 }  // namespace rsb
 
 #endif

@@ -13,12 +13,15 @@
 //     look at the quarter's 24 pieces (rank_device.h, char_rank24: dword totals by v_dot4, only the
 //     dword holding the position is taken apart); a spilled position takes one more pass, the window
 //     line's four counts travelling with the lane;
-//   * psi step (postfix): one 8-byte select sample per 256 occurrences NAMES the window of the wanted
-//     occurrence (its window and how the block's occurrences spread over the following windows:
-//     kernels.h, sample_window), so the first line fetched is the right one -- round 2 interpolated between
-//     two bare window numbers and was wrong 31 % of the time, a second fetch and pass each; then selected
-//     in: three quarter boundaries from the header and two v_dot4 sums, one quarter taken apart
-//     (rank_device.h, select_in24).
+//   * psi step (postfix): the window of the wanted occurrence comes from the PSI HINT of the line the walk stands
+//     in (line_format.h: where psi takes the rows of that window -- the line the previous step landed in, or, for a
+//     row that has just been handed out, its own window's line when the shard was laid out with a hint in every
+//     line): no other read.  A row the hint bounds without settling (within a boundary's granule, or past its last
+//     boundary) tries the lower candidate first -- the line's own count word says "earlier", its pieces running out
+//     says "later" -- and only a guess that fails past the hint's reach, or a line without a hint, reads an 8-byte
+//     select sample (kernels.h, sample_window: it names the window, or bounds it with the next sample for a floor
+//     search over the window headers).  Then selected in: three quarter boundaries from the header and two
+//     v_dot4 sums, one quarter taken apart (rank_device.h, select_in24).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -103,28 +106,44 @@ __device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, si
 enum { XW_PASSES = 0, XW_ACTIVE = 1, XW_STEPS = 2, XW_CONT = 3, XW_FETCHED = 4, XW_CYCLES = 5, XW_WAIT = 6, XW_PROBES = 7, XW_WORDS = 8 };
 
 template <bool COUNT_WORK>
-__global__ void __launch_bounds__(64 * WG_WAVES)
-extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out,
-                           uint32_t stride, uint32_t *__restrict__ plen, unsigned long long *__restrict__ pool,
-                           unsigned long long *__restrict__ work) {
+__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
+                           size_t n, uint8_t *__restrict__ out_all, uint32_t stride, uint32_t *__restrict__ plen_all,
+                           unsigned long long *__restrict__ pools, unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
     const staged_line L = {own_stage_row(stage, lane), lane & 7u};
-    const char *lines_bytes = reinterpret_cast<const char *>(ix.lines);
-    const uint32_t S = ix.sp.S, nlines = (uint32_t)ix.nlines;
-    const double inv = ix.sp.inv;
+    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
+    // A wave walks the rows of ONE shard at a time (rows, buffers and lengths of shard s: block s of n): it starts on
+    // shard blockIdx % nshards and draws from that shard's pool until it is empty and its own walks have ended, then
+    // moves on to the next shard that still has rows -- the shards of a set walked by one launch (sets.hip): every
+    // lane walks nshards x n / lanes rows before the launch's one tail, and everything shard-specific sits in scalar
+    // registers.
+    uint32_t sid = blockIdx.x % nshards;
+    for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
+    const shard_view *sv = shards + sid;
+    const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
+    const uint32_t S = sv->sp.S, nlines = (uint32_t)sv->nlines;
+    const double inv = sv->sp.inv;
+    const uint64_t ix_n = sv->n;
+    const uint64_t *__restrict__ rows = rows_all + (size_t)sid * n;
+    uint8_t *__restrict__ out = out_all + (size_t)sid * n * stride;
+    uint32_t *__restrict__ plen = plen_all + (size_t)sid * n;
+    unsigned long long *pool = pools + sid;
     uint32_t ctab_lo, ctab_hi;  // C[1..4] in lanes 0..3, read with ds_bpermute
     {
+        const uint64_t c1 = sv->C[1], c2 = sv->C[2], c3 = sv->C[3], c4 = sv->C[4];
         const uint32_t l3 = lane & 3u;
-        const uint64_t cv = l3 == 0u ? ix.C[1] : l3 == 1u ? ix.C[2] : l3 == 2u ? ix.C[3] : ix.C[4];
+        const uint64_t cv = l3 == 0u ? c1 : l3 == 1u ? c2 : l3 == 2u ? c3 : c4;
         ctab_lo = (uint32_t)cv;
         ctab_hi = (uint32_t)(cv >> 32);
     }
     bool have = false;
     row_pool rp;
-    size_t r = 0;
+    uint32_t r = 0;
     uint64_t idx = 0;
     uint32_t len = 0;
     uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0, w = 0;
@@ -137,19 +156,17 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
     // kernel's requests.  q0..q3 = the 16 most recent characters, the most recent in q0's low byte (lowest address).
     const bool out16 = (stride & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
     uint32_t chars = 0, q1 = 0, q2 = 0, q3 = 0;  // (chars doubles as q0)
-    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         size_t nr = 0;
         if (draw_row(!have, pool, n, lane, rp, &nr)) {
-            r = nr;
+            r = (uint32_t)nr;
             idx = rows[r];
             len = 0;
             cont = 0;
             chars = 0;
             q1 = q2 = q3 = 0;
             have = true;
-            if (idx >= ix.n) {
+            if (idx >= ix_n) {
                 plen[r] = 0xFFFFFFFFu;
                 have = false;
             }
@@ -302,6 +319,7 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
         }
         if (COUNT_WORK) xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(done));
     }
+    }  // (the next shard)
     if (COUNT_WORK && lane == 0u) {
         xw[XW_CYCLES] = __builtin_amdgcn_s_memtime() - t_begin;
         for (int i = 0; i < XW_WORDS; ++i) atomicAdd(&work[i], xw[i]);
@@ -313,32 +331,57 @@ extract_prefix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ row
 // tlen = length of the whole read (UINT32_MAX: it does not fit, or the prefix did not).
 // ---------------------------------------------------------------------------------------------------
 template <bool COUNT_WORK>
-__global__ void __launch_bounds__(64 * WG_WAVES)
-extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t stride_m,
-                            const uint64_t *__restrict__ rows, size_t n, uint8_t *__restrict__ out, uint32_t stride,
-                            const uint32_t *__restrict__ plen, uint32_t *__restrict__ tlen,
-                            unsigned long long *__restrict__ pool, unsigned long long *__restrict__ work) {
+__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
+                            size_t n, uint8_t *__restrict__ out_all, uint32_t stride, const uint32_t *__restrict__ plen_all,
+                            uint32_t *__restrict__ tlen_all, unsigned long long *__restrict__ pools,
+                            unsigned long long *__restrict__ work) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
     const staged_line L = {own_stage_row(stage, lane), lane & 7u};
-    const char *lines_bytes = reinterpret_cast<const char *>(ix.lines);
-    const uint32_t S = ix.sp.S, nlines = (uint32_t)ix.nlines;
-    const uint64_t C1 = ix.C[1], C2 = ix.C[2], C3 = ix.C[3], C4 = ix.C[4];
-    const uint64_t T1 = ix.total[1], T2 = ix.total[2], T3 = ix.total[3], T4 = ix.total[4];
+    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
+    // (one shard at a time, as the prefix kernel)
+    uint32_t sid = blockIdx.x % nshards;
+    for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
+    const shard_view *sv = shards + sid;
+    const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
+    const uint32_t S = sv->sp.S, nlines = (uint32_t)sv->nlines;
+    const uint64_t C1 = sv->C[1], C2 = sv->C[2], C3 = sv->C[3], C4 = sv->C[4];
+    const uint64_t T1 = sv->total[1], T2 = sv->total[2], T3 = sv->total[3], T4 = sv->total[4];
+    const uint64_t ix_n = sv->n;
+    const uint64_t *__restrict__ sel = sv->sel;
+    const uint64_t stride_m = sv->sel_stride;
+    const uint64_t *__restrict__ rows = rows_all + (size_t)sid * n;
+    uint8_t *__restrict__ out = out_all + (size_t)sid * n * stride;
+    const uint32_t *__restrict__ plen = plen_all + (size_t)sid * n;
+    uint32_t *__restrict__ tlen = tlen_all + (size_t)sid * n;
+    unsigned long long *pool = pools + sid;
     bool have = false;
     row_pool rp;
-    size_t r = 0;
-    uint64_t idx = 0, bc = 0, posbase = 0;
+    uint32_t r = 0;
+    uint64_t idx = 0, bc = 0;
+    uint32_t poff = 0;  // symbols of window wcur held by the lines before the one staged (a continuation's offset)
     uint32_t len = 0, f = 0;
-    // phase 0: F symbol + select samples; 3: the samples are in flight; 2: select in window wcur, which
-    // lies between the samples' windows wlo and whi
+    // phase 0: F symbol, then where the bc-th f lies -- from the hint in hand, or: 4: the row's own window line is
+    // being fetched for its hint (a row just handed out, on a shard with a hint in every line); 3: a select sample is
+    // in flight; 2: select in window wcur, one of wlo..whi (guess_open: whi is only the hint's first guess)
     uint32_t phase = 0, wlo = 0, whi = 0, wcur = 0, tries = 0;
+    bool guess_open = false, fresh = false;
+    uint32_t wmin = 0;  // windows below this one were tried and lie before the bc-th f (a hint's guesses that failed)
+    uint32_t otry = 0;  // windows tried past an open hint's reach
+    // the psi hint of the window line last parsed (the line the walk now stands in)
+    bool hv = false;
+    uint32_t hw0 = 0, hkk = 0;
     uint64_t samp = 0;
     uint32_t cont = 0, cblk = 0, cdw = 0;
-    const uint32_t nwin = (uint32_t)ix.nwin;
-    uint64_t t = 0;  // occurrences of f still to pass (select's running argument)
+    const uint32_t nwin = (uint32_t)sv->nwin;
+    const uint32_t sel_shift = sv->sel_shift, hshift = hint_shift(S);
+    const bool rich = sv->hint_room != 0u;
+    const double inv = sv->sp.inv;
+    uint32_t t = 0;  // occurrences of f still to pass (select's running argument; held to 32 bits: past 4,095 the window is not this one)
     // characters go out four at a time as aligned dwords when the row buffers allow it; `word` holds the
     // bytes of the dword being filled (low byte = lowest address), seeded with the prefix's last bytes
     const bool packed_out = (stride & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
@@ -346,17 +389,17 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
     // being filled, byte len & 15 next
     const bool out16 = (stride & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
     uint32_t word = 0, w1 = 0, w2 = 0, w3 = 0;
-    unsigned long long xw[XW_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = COUNT_WORK ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         size_t nr = 0;
         if (draw_row(!have, pool, n, lane, rp, &nr)) {
-            r = nr;
+            r = (uint32_t)nr;
             idx = rows[r];
             const uint32_t pl = plen[r];
             have = true;
             phase = 0;
-            if (pl == 0xFFFFFFFFu || idx >= ix.n) {
+            fresh = true;
+            hv = false;
+            if (pl == 0xFFFFFFFFu || idx >= ix_n) {
                 tlen[r] = 0xFFFFFFFFu;
                 have = false;
             } else {
@@ -388,40 +431,50 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             xw[XW_ACTIVE] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
         }
         // ---- the sample issued at the end of the last pass has landed: it names the window of the bc-th f
-        // outright (kernels.h, sample_window: exact unless the block's 256 occurrences spread over more than
-        // five windows, then a lower bound the search below walks up from)
+        // outright (line_format.h, sample_window: exact within the first occurrences of its block unless they
+        // spread over more than five windows; else a lower bound the search below walks up from)
         if (have && phase == 3u) {
             bool exact;
-            wcur = sample_window(samp, bc, &exact);
+            wcur = sample_window(samp, bc, sel_shift, &exact);
             if (wcur >= nwin) wcur = nwin - 1u;  // never for a sample this index built
             wlo = whi = wcur;
             if (!exact) {
-                // the block's occurrences spread over more than five windows (a stretch of the BWT nearly without
-                // f): the bc-th lies between w0 + 4 and the window the next block starts in -- a dependent load,
-                // taken by the few lanes that need it, and the bisection of the window headers below
-                const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
+                // the bc-th f lies between the sample's bound and the window the next block starts in -- a dependent
+                // load, taken by the few lanes that need it, and the bisection of the window headers below
+                const uint64_t m = (bc - 1ull) >> sel_shift;
                 const uint64_t tf = f == 1u ? T1 : f == 2u ? T2 : f == 3u ? T3 : T4;
-                const uint32_t nxt = ((m + 1ull) << SEL_SHIFT) < tf ? (uint32_t)sel[f * stride_m + m + 1ull] : nwin - 1u;
+                const uint32_t nxt = ((m + 1ull) << sel_shift) < tf ? (uint32_t)sel[f * stride_m + m + 1ull] : nwin - 1u;
                 whi = nxt > wlo ? (nxt < nwin ? nxt : nwin - 1u) : wlo;
+                wlo = wlo > wmin ? wlo : wmin;
+                whi = whi > wlo ? whi : wlo;
                 wcur = wlo + ((whi - wlo) >> 1);
             }
             phase = 2;
             cont = 0;
             tries = 0;
+            guess_open = false;
         }
         // ---- phase 2: the window's line (or its continuation).  The bc-th f is in wcur iff
         // count(wcur) < bc <= count(wcur + 1): the line's own count word settles the first half, the
         // second shows when the window's pieces run out before the select argument does.
+        // ---- phase 4: the row's own window line, for its hint
         const bool selecting = have && phase == 2u;
+        const bool asking = have && phase == 4u;
         uint32_t line = 0;
         if (selecting && cont == 0u) {
             line = wcur + (wcur >> GROUP_SHIFT);
             if (line >= nlines) line = 0;
         }
-        const uint32_t want = selecting ? (cont ? cblk : line) : ~0u;
+        if (asking) {
+            uint32_t pin;
+            const uint32_t hwin = fast_window(idx, S, inv, pin);
+            line = hwin + (hwin >> GROUP_SHIFT);
+            if (line >= nlines) line = 0;
+        }
+        const uint32_t want = selecting ? (cont ? cblk : line) : asking ? line : ~0u;
         unsigned long long t_fetch = 0;
         if (COUNT_WORK) {
-            xw[XW_FETCHED] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(selecting));
+            xw[XW_FETCHED] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(selecting || asking));
             xw[XW_CONT] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(selecting && cont != 0u));
             __builtin_amdgcn_sched_barrier(0);
             t_fetch = __builtin_amdgcn_s_memtime();
@@ -432,10 +485,17 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             __builtin_amdgcn_sched_barrier(0);
             xw[XW_WAIT] += __builtin_amdgcn_s_memtime() - t_fetch;
         }
-        bool stepped = false, moved = false;
-        // the psi hint of the window the step lands in (line_format.h), taken while its line is staged
-        bool hint_here = false, hinted_now = false;
-        uint32_t hint_w0 = 0, hint_kk = 0, hint_win = 0;
+        bool stepped = false, hinted_now = false;
+        // the psi hint of a window line, taken while the line is staged (line_format.h: dwords 30, 31; 29, 30 of a
+        // line that ends in a far link)
+        if (asking || (selecting && cont == 0u)) {
+            const uint32_t d1 = L.dword(1), d3 = L.dword(3);
+            const uint32_t hd = ((d3 >> 28) & 3u) == KIND_FAR ? LINE_DWORDS - 3u : LINE_DWORDS - 2u;
+            hv = ((d1 >> (8u + HINT_META0_BIT)) & 1u) != 0u;
+            hw0 = L.dword(hd);
+            hkk = L.dword(hd + 1u);
+            if (asking) phase = 0;  // the block below takes it from here
+        }
         if (selecting) {
             bool found = false;
             uint64_t pos = 0;
@@ -446,13 +506,13 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                 const line_head h = read_head(L);
                 const uint64_t cnt = read_count(L, f);
                 if (cont == 0u) {
-                    posbase = (uint64_t)wcur * S;
+                    poff = 0;
                     if (cnt >= bc) move = -1;
                 }
-                t = bc - cnt;
+                t = bc - cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(bc - cnt);
                 const uint32_t c1 = matched24(L, HDR_DWORDS, f), c2 = read_half(L, f);
                 const uint32_t c3 = c2 + matched24(L, HDR_DWORDS + 12u, f);
-                const uint32_t tt = t > 4095ull ? 4095u : (uint32_t)t;
+                const uint32_t tt = t > 4095u ? 4095u : t;
                 const uint32_t cq = (tt > c1 ? 1u : 0u) + (tt > c2 ? 1u : 0u) + (tt > c3 ? 1u : 0u);
                 const uint32_t before = cq == 0u ? 0u : cq == 1u ? c1 : cq == 2u ? c2 : c3;
                 const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
@@ -461,69 +521,77 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                 const uint32_t p = select_in24(r6, f, tt - before, &left);
                 // a hit lies within the symbols the line's own pieces hold: when the window tried is an
                 // earlier one than the bc-th f's, the argument outlasts the pieces and may "find" its f in
-                // the bytes after them (a far line's link)
+                // the bytes after them (a psi hint, a far line's link)
                 if (move != 0) {
                     // (nothing of this line is of use)
                 } else if (left == 0u && start + p < h.span) {
                     found = true;
-                    pos = posbase + start + p;
-                    if (cont == 0u && ((L.dword(1) >> (8u + HINT_META0_BIT)) & 1u) != 0u) {
-                        hint_here = true;
-                        hint_w0 = L.dword(LINE_DWORDS - 2u);
-                        hint_kk = L.dword(LINE_DWORDS - 1u);
-                        hint_win = wcur;
-                    }
+                    pos = (uint64_t)wcur * S + poff + start + p;
                 } else if (h.kind == KIND_FAR) {
                     cblk = L.dword(LINE_DWORDS - 1u);
                     if (cblk >= nlines) cblk = 0;
                     cont = KIND_FAR;
-                    posbase += h.span;
+                    poff += h.span;
                 } else if (h.kind == KIND_CHUNK && cont == 0u) {
                     cdw = read_chunk_dword(L);
                     cblk = (wcur >> GROUP_SHIFT) * (GROUP + 1u) + GROUP;
                     if (cblk >= nlines) cblk = 0;
                     cont = KIND_CHUNK;
-                    posbase += h.span;
-                    t = left;  // what the chunk's pieces still have to provide
+                    poff += h.span;
+                    // (t stays bc minus the window's count word: the chunk's header says what the line's own pieces
+                    // hold of f -- `left` may not be used for that: the scan above ran over the whole quarter, and in
+                    // a line with a psi hint the quarter's last bytes are the hint, not pieces)
                 } else {
                     move = 1;  // the window's pieces ran out first
                 }
             } else {
                 uint32_t r6[6], left = 0;
                 load24(L, cdw + 2u, r6);
-                const uint32_t p = select_in24(r6, f, (uint32_t)t, &left);
                 const uint2 hd = L.u2(cdw);
+                const uint32_t own = ((f < 3u ? hd.x : hd.y) >> (12u * ((f - 1u) & 1u))) & 0xFFFu;  // f's in the line's own pieces
+                const uint32_t tc = t > own ? t - own : 0u;  // (0: never for a sound index -- select_in24 then reports position 0, refused below)
+                const uint32_t p = select_in24(r6, f, tc > 4095u ? 4095u : tc, &left);
                 const uint32_t csym = (hd.x >> 24) | ((hd.y >> 24) << 8);  // symbols the chunk holds; the next chunk follows
-                found = left == 0u && p < csym;
-                pos = posbase + p;
+                found = tc != 0u && left == 0u && p < csym;
+                pos = (uint64_t)wcur * S + poff + p;
                 if (!found) move = 1;
             }
+            bool to_sample = false;
             if (move < 0) {
                 if (wcur == 0u) {  // count(0) = 0 < bc: only a corrupt index gets here
                     found = true;
-                    pos = ix.n;
+                    pos = ix_n;
                 }
                 whi = wcur - 1u;
                 wlo = wlo < whi ? wlo : whi;
             } else if (move > 0) {
+                // past an open hint's reach: the next window, and the one after (four in five such rows lie in the
+                // first window past the reach); then a sample bounds what is left
+                if (guess_open && wcur >= whi) to_sample = ++otry > 2u;
                 wlo = wcur + 1u;
                 whi = whi > wlo ? whi : wlo;
                 if (wlo >= nwin) {  // past the last window: a corrupt index
                     found = true;
-                    pos = ix.n;
+                    pos = ix_n;
+                    to_sample = false;
                 }
             }
             if (move != 0) {
                 wcur = wlo + ((whi - wlo) >> 1);
                 cont = 0;
-                moved = true;
             }
             if (!found && ++tries > 72u) {
                 found = true;
-                pos = ix.n;
+                pos = ix_n;
+                to_sample = false;
+            }
+            if (to_sample) {
+                wmin = wlo < nwin ? wlo : nwin - 1u;
+                samp = sel[f * stride_m + ((bc - 1ull) >> sel_shift)];
+                phase = 3;
             }
             if (found) {
-                if (pos >= ix.n) {  // a corrupt index: end the read instead of walking off
+                if (pos >= ix_n) {  // a corrupt index: end the read instead of walking off
                     tlen[r] = len;
                     have = false;
                 } else {
@@ -555,12 +623,9 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                 }
             }
         }
-        if (COUNT_WORK) {
-            xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(stepped));
-            (void)moved;
-        }
-        // ---- phase 0 (rows that just arrived or just stepped): getF (rlebwt.cpp:307-314) and the select
-        // samples around the bc-th f; the sample loads fly with the next pass's fetches
+        if (COUNT_WORK) xw[XW_STEPS] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(stepped));
+        // ---- phase 0 (rows that just arrived, just stepped, or just got their own line): getF (rlebwt.cpp:307-314),
+        // then the window of the bc-th f
         if (have && phase == 0u) {
             f = (idx >= C1 ? 1u : 0u) + (idx >= C2 ? 1u : 0u) + (idx >= C3 ? 1u : 0u) + (idx >= C4 ? 1u : 0u);
             if (f == 0u) {  // '$': the read ends here (query.cpp:76)
@@ -581,17 +646,22 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
             } else {
                 const uint64_t cf = f == 1u ? C1 : f == 2u ? C2 : f == 3u ? C3 : C4;
                 bc = idx - cf + 1ull;
-                // The line this row was found in may say where psi takes the rows of its window: then the next
-                // window is known now, with no sample read and no round trip for it.  The hint speaks of the F
-                // symbol of the window's first row: it holds for this row when that row lies in f's block too.
+                // The line the walk stands in may say where psi takes the rows of its window: then the next window is
+                // known now (or bounded: the lower candidate is tried first), with no sample read and no round trip
+                // for it.  The hint speaks of the F symbol of the window's first row: it holds for this row when that
+                // row lies in f's block too.
                 bool via_hint = false;
-                if (hint_here) {
-                    const uint64_t r0 = (uint64_t)hint_win * S;
-                    if (r0 >= cf && idx >= r0) {
-                        bool exact;
-                        const uint32_t wn = hint_window(hint_w0, hint_kk, (uint32_t)(idx - r0), &exact);
-                        if (exact && wn < nwin) {
-                            wcur = wlo = whi = wn;
+                if (hv && hw0 != HINT_NONE) {
+                    uint32_t pin;
+                    const uint64_t r0 = (uint64_t)fast_window(idx, S, inv, pin) * S;  // (the walk stands in idx's window)
+                    if (r0 >= cf && idx >= r0 && idx - r0 < S) {
+                        const hint_range hr = hint_windows(hw0, hkk, (uint32_t)(idx - r0), hshift);
+                        if (hr.hi < nwin && hr.lo <= hr.hi) {
+                            wlo = hr.lo;
+                            whi = hr.hi;
+                            wcur = wlo + ((whi - wlo) >> 1);
+                            guess_open = hr.open;
+                            otry = 0;
                             phase = 2;
                             cont = 0;
                             tries = 0;
@@ -601,23 +671,68 @@ extract_postfix_wave_kernel(const shard_view ix, const uint64_t *__restrict__ se
                 }
                 hinted_now = via_hint;
                 if (!via_hint) {
-                    const uint64_t m = (bc - 1ull) >> SEL_SHIFT;
-                    samp = sel[f * stride_m + m];
-                    phase = 3;  // the sample is used from the next pass on
+                    if (fresh && rich) {
+                        phase = 4;  // this row's own window line carries the hint
+                    } else {
+                        wmin = 0;
+                        samp = sel[f * stride_m + ((bc - 1ull) >> sel_shift)];
+                        phase = 3;  // the sample is used from the next pass on
+                    }
                 }
+                fresh = false;
+                hv = false;
             }
         }
         if (COUNT_WORK) xw[XW_PROBES] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hinted_now));
     }
+    }  // (the next shard)
     if (COUNT_WORK && lane == 0u) {
         xw[XW_CYCLES] = __builtin_amdgcn_s_memtime() - t_begin;
         for (int i = 0; i < XW_WORDS; ++i) atomicAdd(&work[i], xw[i]);
     }
 }
 
-// The prefix, written right to left from the end of the row's buffer, moved to its head: one wave per
-// row, 64 bytes per step, low addresses first (source >= destination, so a step never overwrites a later
-// step's source, and within a step every lane has loaded before any lane stores).
+// The prefix, written right to left from the end of the row's buffer, moved to its head.  Sixteen lanes per row, 16
+// bytes per lane and step (two aligned 16-byte loads and a funnel shift: the prefix starts wherever stride - plen
+// falls), low addresses first: source >= destination, so a step never overwrites a later step's source, and within a
+// step every lane has loaded before any lane stores.  The bytes of the last chunk past the prefix's end are whatever
+// followed it: the postfix walk overwrites them (it keeps the bytes below plen & 15 of that chunk, no others).
+__global__ void __launch_bounds__(256)
+move_prefix16_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *__restrict__ plen, size_t n) {
+    const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
+    uint32_t pl = r < n ? plen[r] : 0u;
+    if (pl == 0xFFFFFFFFu || pl >= stride) pl = 0u;
+    uint8_t *buf = out + (r < n ? r : 0) * (size_t)stride;
+    const uint32_t off = stride - pl;
+    for (uint32_t k0 = 0; __builtin_amdgcn_ballot_w64(k0 < pl) != 0ull; k0 += 256u) {  // (every lane of the wave reaches the barrier)
+        const uint32_t k = k0 + 16u * sub;
+        const bool active = k < pl;
+        uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
+        uint32_t sh = 0;
+        if (active) {
+            const uint32_t a = off + k, a0 = a & ~15u;
+            sh = a & 15u;
+            A = *reinterpret_cast<const uint4 *>(buf + a0);
+            if (a0 + 16u < stride) B = *reinterpret_cast<const uint4 *>(buf + a0 + 16u);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every lane's bytes are in before any store of this step
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            const uint32_t ds = sh >> 2, bs = sh & 3u;
+            const uint32_t e0 = ds == 0u ? A.x : ds == 1u ? A.y : ds == 2u ? A.z : A.w;
+            const uint32_t e1 = ds == 0u ? A.y : ds == 1u ? A.z : ds == 2u ? A.w : B.x;
+            const uint32_t e2 = ds == 0u ? A.z : ds == 1u ? A.w : ds == 2u ? B.x : B.y;
+            const uint32_t e3 = ds == 0u ? A.w : ds == 1u ? B.x : ds == 2u ? B.y : B.z;
+            const uint32_t e4 = ds == 0u ? B.x : ds == 1u ? B.y : ds == 2u ? B.z : B.w;
+            *reinterpret_cast<uint4 *>(buf + k) =
+                make_uint4(__builtin_amdgcn_alignbyte(e1, e0, bs), __builtin_amdgcn_alignbyte(e2, e1, bs),
+                           __builtin_amdgcn_alignbyte(e3, e2, bs), __builtin_amdgcn_alignbyte(e4, e3, bs));
+        }
+    }
+}
+
+// ... and for row buffers that are not 16-byte aligned: one wave per row, a byte per lane, 64 bytes per step.
 __global__ void __launch_bounds__(256)
 move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *__restrict__ plen, size_t n) {
     const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -637,22 +752,39 @@ move_prefix_kernel(uint8_t *__restrict__ out, uint32_t stride, const uint32_t *_
     }
 }
 
-hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint64_t *d_sel, const void *d_rows,
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
                                hipStream_t stream, unsigned long long *d_work) {
-    if (n == 0) return hipSuccess;
+    if (n == 0 || nshards == 0) return hipSuccess;
+    constexpr size_t MAX_ROWS = 1ull << 31;  // (the walk kernels number a shard's rows in 32 bits)
+    if (n > MAX_ROWS) {
+        if (nshards != 1) return hipErrorInvalidValue;  // (a set's caller cuts its batches)
+        for (size_t i0 = 0; i0 < n; i0 += MAX_ROWS) {
+            const size_t m = n - i0 < MAX_ROWS ? n - i0 : MAX_ROWS;
+            const hipError_t e2 = launch_extract_wave(scratch, d_shards, 1, (const uint64_t *)d_rows + i0, m, (uint8_t *)d_out + i0 * (size_t)stride,
+                                                      stride, (uint32_t *)d_plen + i0, (uint32_t *)d_len + i0, num_cus, stream, d_work);
+            if (e2 != hipSuccess) return e2;
+        }
+        return hipSuccess;
+    }
     scratch_cache::lease mem;
-    hipError_t e = scratch.take(2 * sizeof(unsigned long long), stream, &mem);
+    const size_t pool_bytes = 2 * (size_t)nshards * sizeof(unsigned long long);
+    hipError_t e = scratch.take(pool_bytes, stream, &mem);
     if (e != hipSuccess) return e;
     unsigned long long *pool = (unsigned long long *)mem.p;
-    e = hipMemsetAsync(pool, 0, 2 * sizeof(unsigned long long), stream);
+    e = hipMemsetAsync(pool, 0, pool_bytes, stream);
     if (e != hipSuccess) {
         scratch.give(mem, stream);
         return e;
     }
-    size_t g = (n + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
-    // workgroups per CU: the walk kernels' 88-95 VGPRs and 32 KB of LDS per workgroup admit 5; RSBWT_EXTRACT_WGS_PER_CU
-    // overrides (A/B knob, tools/README.md)
+    const size_t total = n * (size_t)nshards;
+    size_t g = (total + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
+    // Workgroups: what is resident at once (4 per CU: 99 of 128 VGPRs, 32 KB of LDS each) and no more.  A walk kernel
+    // ends in a tail as long as its longest walk (a few hundred passes, most lanes idle), so the more rows each lane
+    // walks before that tail the better: the shards of a set are walked by ONE launch (a launch per shard, side by
+    // side on streams of the set -- round 3 -- queued the shards' grids behind one another: every lane walked 8 rows
+    // instead of 60 and a third of the lane-passes were idle).  RSBWT_EXTRACT_WGS_PER_CU overrides the 4 (A/B knob,
+    // tools/README.md)
     static const size_t wgs_per_cu = [] {
         const char *e = getenv("RSBWT_EXTRACT_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
@@ -660,22 +792,28 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, con
     }();
     const size_t cap = (size_t)num_cus * wgs_per_cu;
     if (g > cap) g = cap;
+    if (g >= nshards) g -= g % nshards;  // (every shard starts with as many workgroups as any other)
     if (d_work)
-        hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
     else
-        hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix,
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
-    hipLaunchKernelGGL(move_prefix_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
-                       (const uint32_t *)d_plen, n);
-    if (d_work)
-        hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
-                           select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
-                           (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1, d_work + XW_WORDS);
+    // (the row buffers of the shards lie back to back: one launch moves every prefix)
+    if ((stride & 15u) == 0u && ((uintptr_t)d_out & 15u) == 0u)
+        hipLaunchKernelGGL(move_prefix16_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
+                           (const uint32_t *)d_plen, total);
     else
-        hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, ix, d_sel,
-                           select_sample_stride(ix), (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride,
-                           (const uint32_t *)d_plen, (uint32_t *)d_len, pool + 1, d_work + XW_WORDS);
+        hipLaunchKernelGGL(move_prefix_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
+                           (const uint32_t *)d_plen, total);
+    if (d_work)
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
+                           pool + nshards, d_work + XW_WORDS);
+    else
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
+                           pool + nshards, d_work + XW_WORDS);
     e = hipGetLastError();
     scratch.give(mem, stream);
     return e;

@@ -97,9 +97,9 @@ hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void
                             void *d_out, hipStream_t stream);
 hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n, void *d_out,
                              hipStream_t stream);
-// d_sel: the sampled select table (launch_select_samples)
-hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, const void *d_syms, const void *d_bc,
-                               size_t n, void *d_out, hipStream_t stream);
+// (needs the sampled select table: shard_view::sel, launch_select_samples)
+hipError_t launch_occ_at_batch(const shard_view &ix, const void *d_syms, const void *d_bc, size_t n, void *d_out,
+                               hipStream_t stream);
 // The list of the set bits of `bits` (n_searches bits), in order: record i = {lower, upper, search index, 0}
 // (32 B) from sparse[index]; at most `cap` records are written, *d_total receives how many there are.
 // d_block_counts: compact_hits_block_words(n_searches) u64 of scratch.
@@ -125,9 +125,11 @@ uint64_t select_sample_stride(const shard_view &ix);
 hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStream_t stream);
 // psi hints inside the window lines that have room for one (line_format.h); after the samples.  *d_made (optional,
 // zeroed by the caller) counts the lines that got one
-hipError_t launch_psi_hints(const shard_view &ix, const uint64_t *d_sel, unsigned long long *d_made, hipStream_t stream);
-// extract_lines.hip: extractPrefix + extractPostfix of n rows, wave-cooperative
-hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view &ix, const uint64_t *d_sel, const void *d_rows,
+hipError_t launch_psi_hints(const shard_view &ix, unsigned long long *d_made, hipStream_t stream);
+// extract_lines.hip: extractPrefix + extractPostfix of n rows of EACH of the nshards shards whose views (with their
+// select samples: shard_view::sel) are the device array d_shards, wave-cooperative, one launch sequence for all of
+// them: d_rows [nshards][n], d_out [nshards][n][stride], d_plen / d_len [nshards][n]
+hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_rows,
                                size_t n, void *d_out, uint32_t stride, void *d_plen, void *d_len, int num_cus,
                                hipStream_t stream, unsigned long long *d_work = nullptr);
 // d_work (counting mode): WORK_WORDS counters, zeroed by the caller: words 0-7 the prefix walk, 8-15 the
@@ -150,7 +152,8 @@ struct build_result {
     uint64_t hbm_bytes;
     uint64_t far_lines, chunk_windows, far_windows, spilled_symbols;
 };
-hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span, hipStream_t stream,
+// hint_room: every window line keeps room for a psi hint (line_format.h; RSBWT_OPEN_READS).
+hipError_t build_lines(const void *d_runs, uint64_t num_runs, uint32_t want_span, bool hint_room, hipStream_t stream,
                        build_result *out, int *build_error);
 
 }  // namespace rsb

@@ -223,13 +223,13 @@ char_batch_kernel(const shard_view ix, const uint64_t *__restrict__ index, size_
     out[i] = (uint8_t)("$ACGT"[view_char(ix, p)]);
 }
 
-// Sampled select: sel[c][m] describes the block of 256 occurrences of symbol c that starts with occurrence
-// (m << SEL_SHIFT) + 1: bits 0..31 = the window w0 holding that first occurrence, then four bytes k0..k3 with
+// Sampled select: sel[c][m] describes the block of 2^sel_shift occurrences of symbol c that starts with occurrence
+// (m << sel_shift) + 1: bits 0..31 = the window w0 holding that first occurrence, then four bytes k0..k3 with
 // k_j + 1 = how many of the block's occurrences lie in windows <= w0 + j (capped at 256).  The window of the
-// block's r-th occurrence (r = 0..255) is then w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while
-// the block spans at most five windows' worth of knowledge (r <= k3), a lower bound beyond.  Round 2 kept the
-// bare window (4 bytes) and interpolated between two samples: 31 % of first guesses were wrong and cost a second
-// line fetch and a second pass (profiles/r02d_extract_profile.json).
+// block's r-th occurrence is then w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while r <= k3, a lower
+// bound beyond (line_format.h, sample_window).  Round 2 kept the bare window (4 bytes) and interpolated between
+// two samples: 31 % of first guesses were wrong and cost a second line fetch and a second pass
+// (profiles/r02d_extract_profile.json).
 
 __global__ void __launch_bounds__(256)
 select_sample_kernel(const shard_view ix, uint64_t *__restrict__ sel, uint64_t stride_m) {
@@ -248,8 +248,9 @@ psi_hint_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t 
     uint32_t w0, kk;
     if (!window_psi_hint(ix, sel, stride_m, w, &w0, &kk)) return;
     uint32_t *Ln = lines + line_of_window(w) * LINE_DWORDS;
-    Ln[LINE_DWORDS - 2] = w0;
-    Ln[LINE_DWORDS - 1] = kk;
+    const uint32_t hd = hint_dword((Ln[3] >> 28) & 3u);  // (kind: bits 20, 21 of meta_1)
+    Ln[hd + 1u] = kk;
+    Ln[hd] = w0;
     __threadfence();
     Ln[1] |= 1u << (8u + HINT_META0_BIT);  // the flag last: a reader that sees it sees the hint
     if (made) atomicAdd(made, 1ull);
@@ -258,13 +259,8 @@ psi_hint_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint64_t 
 // getOccAt with the sample table naming the window (BPTree::select's role)
 __device__ uint64_t thread_occ_at_sampled(const shard_view &ix, const uint64_t *__restrict__ sel,
                                           uint64_t stride_m, uint32_t b, uint64_t bc) {
-    const uint64_t m = (bc - 1) >> SEL_SHIFT;
-    bool exact;
-    const uint64_t lo = sample_window(sel[b * stride_m + m], bc, &exact);
-    uint64_t hi = lo;
-    if (!exact) hi = ((m + 1) << SEL_SHIFT) < ix.total[b] ? (uint32_t)sel[b * stride_m + m + 1] : ix.nwin - 1;
-    if (hi < lo) hi = lo;
-    return view_occ_at(ix, b, bc, lo < ix.nwin ? lo : ix.nwin - 1, hi < ix.nwin ? hi : ix.nwin - 1);
+    const uint64_t w = select_window(ix, sel, stride_m, b, bc);
+    return view_occ_at(ix, b, bc, w, w);
 }
 
 __global__ void __launch_bounds__(256)
@@ -738,11 +734,11 @@ hipError_t launch_char_batch(const shard_view &ix, const void *d_index, size_t n
     return hipGetLastError();
 }
 
-hipError_t launch_occ_at_batch(const shard_view &ix, const uint64_t *d_sel, const void *d_syms, const void *d_bc,
+hipError_t launch_occ_at_batch(const shard_view &ix, const void *d_syms, const void *d_bc,
                                size_t n, void *d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, d_sel,
-                       select_sample_stride(ix), (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
+    hipLaunchKernelGGL(occ_at_batch_kernel, dim3(blocks256(n)), dim3(256), 0, stream, ix, ix.sel, ix.sel_stride,
+                       (const uint8_t *)d_syms, (const uint64_t *)d_bc, n, (uint64_t *)d_out);
     return hipGetLastError();
 }
 
@@ -886,9 +882,9 @@ hipError_t launch_select_samples(const shard_view &ix, uint64_t *d_sel, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_psi_hints(const shard_view &ix, const uint64_t *d_sel, unsigned long long *d_made, hipStream_t stream) {
-    if (ix.nwin == 0 || ix.sp.S > HINT_MAX_SPAN) return hipSuccess;
-    hipLaunchKernelGGL(psi_hint_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, d_sel, select_sample_stride(ix),
+hipError_t launch_psi_hints(const shard_view &ix, unsigned long long *d_made, hipStream_t stream) {
+    if (ix.nwin == 0 || !ix.sel) return hipSuccess;
+    hipLaunchKernelGGL(psi_hint_kernel, dim3(blocks256(ix.nwin)), dim3(256), 0, stream, ix, ix.sel, ix.sel_stride,
                        const_cast<uint32_t *>(ix.lines), d_made);
     return hipGetLastError();
 }

@@ -14,9 +14,14 @@
 
 using namespace rsb;
 
+// (bit 31 of window_span, both hooks: the RSBWT_OPEN_READS layout -- room for a psi hint in every window line)
+static constexpr uint32_t SELFTEST_ROOM = 1u << 31;
+
 extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span,
                                           uint64_t *stats6, uint64_t *first_bad) {
     if (!runs && num_runs) return RSBWT_EINVAL;
+    const bool room = (window_span & SELFTEST_ROOM) != 0u;
+    window_span &= ~SELFTEST_ROOM;
     // naive expansion
     std::vector<uint8_t> bwt;
     for (uint64_t r = 0; r < num_runs; ++r) {
@@ -38,7 +43,7 @@ extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs
         run_reader rd;
         rd.start(runs, num_runs, 0, zero);
         for (uint64_t g = 0; g < ngroups; ++g) {
-            const group_stats st = build_group<false>(sp, n, nwin, g, rd, nullptr, 0);
+            const group_stats st = build_group<false>(sp, n, nwin, g, rd, nullptr, 0, room);
             far_base[g + 1] = far_base[g] + st.far_lines;
             tot.far_lines += st.far_lines;
             tot.chunk_windows += st.chunk_windows;
@@ -64,7 +69,7 @@ extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs
             run_reader rd;
             rd.start(runs, num_runs, r, cnt);
             rd.skip_symbols(gstart - at);
-            build_group<true>(sp, n, nwin, g, rd, lines.data(), first_far + far_base[g]);
+            build_group<true>(sp, n, nwin, g, rd, lines.data(), first_far + far_base[g], room);
         }
     }
     shard_view v;
@@ -75,6 +80,8 @@ extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs
     v.nlines = nlines;
     v.first_far = first_far;
     v.sp = sp;
+    v.sel_shift = room ? SEL_SHIFT_SPARSE : SEL_SHIFT_DENSE;
+    v.hint_room = room ? 1u : 0u;
     for (uint64_t p = 0; p < n; ++p) v.total[bwt[p]]++;
     for (int c = 1; c < 5; ++c) v.C[c] = v.C[c - 1] + v.total[c - 1];
     if (stats6) {
@@ -114,6 +121,8 @@ extern "C" int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs
 extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span, uint64_t *stats4,
                                               uint64_t *first_bad) {
     if (!runs && num_runs) return RSBWT_EINVAL;
+    const bool room = (window_span & SELFTEST_ROOM) != 0u;
+    window_span &= ~SELFTEST_ROOM;
     std::vector<uint8_t> bwt;
     for (uint64_t r = 0; r < num_runs; ++r) {
         if ((runs[r] >> 5) > 4) return RSBWT_EFORMAT;
@@ -132,7 +141,7 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
         const uint64_t zero[4] = {0, 0, 0, 0};
         run_reader rd;
         rd.start(runs, num_runs, 0, zero);
-        for (uint64_t g = 0; g < ngroups; ++g) far_base[g + 1] = far_base[g] + build_group<false>(sp, n, nwin, g, rd, nullptr, 0).far_lines;
+        for (uint64_t g = 0; g < ngroups; ++g) far_base[g + 1] = far_base[g] + build_group<false>(sp, n, nwin, g, rd, nullptr, 0, room).far_lines;
     }
     const uint64_t first_far = ngroups * (GROUP + 1), nlines = first_far + far_base[ngroups];
     std::vector<uint32_t> lines(nlines * LINE_DWORDS, 0);
@@ -140,7 +149,7 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
         const uint64_t zero[4] = {0, 0, 0, 0};
         run_reader rd;
         rd.start(runs, num_runs, 0, zero);
-        for (uint64_t g = 0; g < ngroups; ++g) build_group<true>(sp, n, nwin, g, rd, lines.data(), first_far + far_base[g]);
+        for (uint64_t g = 0; g < ngroups; ++g) build_group<true>(sp, n, nwin, g, rd, lines.data(), first_far + far_base[g], room);
     }
     shard_view v;
     memset(&v, 0, sizeof v);
@@ -150,6 +159,8 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
     v.nlines = nlines;
     v.first_far = first_far;
     v.sp = sp;
+    v.sel_shift = room ? SEL_SHIFT_SPARSE : SEL_SHIFT_DENSE;
+    v.hint_room = room ? 1u : 0u;
     for (uint64_t p = 0; p < n; ++p) v.total[bwt[p]]++;
     for (int c = 1; c < 5; ++c) v.C[c] = v.C[c - 1] + v.total[c - 1];
     // positions of the occurrences of every symbol (the naive select)
@@ -168,10 +179,11 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
     for (uint32_t c = 0; c <= 4; ++c)
         for (uint64_t bc = 1; bc <= v.total[c]; ++bc) {
             bool exact;
-            const uint32_t w = sample_window(sel[c * stride + ((bc - 1) >> SEL_SHIFT)], bc, &exact);
+            const uint32_t w = sample_window(sel[c * stride + ((bc - 1) >> v.sel_shift)], bc, v.sel_shift, &exact);
             const uint64_t truth = where[c][bc - 1] / sp.S;
             if (!exact) ++inexact;
-            if (exact ? w != truth : w > truth) {
+            // exact or a bound -- and, either way, the floor search between the samples ends on the window
+            if ((exact ? w != truth : w > truth) || select_window(v, sel.data(), stride, c, bc) != truth) {
                 if (first_bad) *first_bad = where[c][bc - 1];
                 return RSBWT_EFORMAT;
             }
@@ -182,26 +194,29 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
         uint32_t w0, kk;
         if (!window_psi_hint(v, sel.data(), stride, w, &w0, &kk)) continue;
         uint32_t *Ln = lines.data() + line_of_window(w) * LINE_DWORDS;
-        Ln[LINE_DWORDS - 2] = w0;
-        Ln[LINE_DWORDS - 1] = kk;
+        const uint32_t hd = hint_dword(parse_line(Ln).kind);
+        Ln[hd] = w0;
+        Ln[hd + 1u] = kk;
         Ln[1] |= 1u << (8u + HINT_META0_BIT);
         ++hint_lines;
     }
+    const uint32_t hs = hint_shift(sp.S);
     for (uint64_t i = 0; i < n; ++i) {  // row i: psi(i) = select_f(i - C[f] + 1), f = F(i)
         uint32_t f = 0;
         while (f < 4u && v.C[f + 1] <= i) ++f;
         if (f == 0u) continue;
         const uint64_t w = i / sp.S, r0 = w * (uint64_t)sp.S;
         const uint32_t *Ln = lines.data() + line_of_window(w) * LINE_DWORDS;
-        if (!parse_line(Ln).hint || r0 < v.C[f]) continue;  // (the walk kernel's own conditions)
-        bool exact;
-        const uint32_t wn = hint_window(Ln[LINE_DWORDS - 2], Ln[LINE_DWORDS - 1], (uint32_t)(i - r0), &exact);
-        if (!exact) continue;
-        ++by_hint;
-        if (wn != where[f][i - v.C[f]] / sp.S) {
+        const line_meta lm = parse_line(Ln);
+        if (!lm.hint || Ln[hint_dword(lm.kind)] == HINT_NONE || r0 < v.C[f]) continue;  // (the walk kernel's own conditions)
+        const hint_range hr = hint_windows(Ln[hint_dword(lm.kind)], Ln[hint_dword(lm.kind) + 1u], (uint32_t)(i - r0), hs);
+        const uint64_t truth = where[f][i - v.C[f]] / sp.S;
+        // the row's window lies in lo..hi -- or, an open range, anywhere from lo on
+        if (truth < hr.lo || (!hr.open && truth > hr.hi)) {
             if (first_bad) *first_bad = i;
             return RSBWT_EFORMAT;
         }
+        if (hr.lo == hr.hi && !hr.open) ++by_hint;
     }
     if (stats4) {
         stats4[0] = words;

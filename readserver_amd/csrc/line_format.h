@@ -31,15 +31,20 @@
 //                  continues the window (more than 120 pieces, or the spill line was full)
 //   dwords 8..31   96 piece bytes (unused = 0; a valid piece has len >= 1)
 //   $ before the window = w*S - (A + C + G + T).
-//   PSI HINT (bit 21 of meta_0 set; only kind = 0 lines with at most 88 pieces, S <= 1024): dwords 30 and 31
-//   do not hold pieces but where psi takes the ROWS w*S .. w*S + S - 1 (read extraction's select,
-//   src/bwt/query.cpp:72-80): those rows are consecutive occurrences of one symbol f (the F symbol of row
-//   w*S), which lie in a few consecutive windows of the BWT: dword 30 = the window w0 of the first of them,
-//   dword 31 = four bytes b0..b3, b_j = (K_j - 1) >> 2 with K_j = how many of them lie in windows <= w0 + j
-//   (255 when that is all of them).  Row w*S + r goes to window w0 + #{j : (r >> 2) > b_j}; a row with
-//   (r >> 2) == b_j for some j, or past b3, is not settled by the hint (the walk reads a select sample).
-//   Written by a pass of its own once a shard's select samples exist (kernels.hip, psi_hint_kernel); no
-//   search ever looks at it (a lookup never reads past its window's pieces).
+//   PSI HINT (bit 21 of meta_0 set): the line's last two piece dwords do not hold pieces but where psi takes the
+//   ROWS w*S .. w*S + S - 1 (read extraction's select, src/bwt/query.cpp:72-80): a WHOLE or CHUNK line then holds
+//   at most 88 pieces of its own and the hint in dwords 30 and 31; a FAR window line 84 pieces, the hint in dwords
+//   29 and 30 and its link in dword 31 as ever.  Those rows are consecutive occurrences of one symbol f (the F
+//   symbol of row w*S), which lie in a few consecutive windows of the BWT: first dword = the window w0 of the
+//   first of them (HINT_NONE: the slot is not filled), second dword = four bytes b0..b3, b_j = (K_j - 1) >> s with
+//   K_j = how many of them lie in windows <= w0 + j (255 when that is all of them) and s = hint_shift(S), the
+//   smallest shift that brings a row offset below 256.  Row w*S + r goes to window w0 + #{j : r >= K_j}: at least
+//   w0 + #{j : (r >> s) > b_j}, at most that plus #{j : (r >> s) == b_j} -- and past b3 the upper bound is only a
+//   first guess (hint_windows).  Two ways a line gets one: a shard opened for reads (RSBWT_OPEN_READS) is laid out
+//   with the room in EVERY window line (88 / 84 own pieces, the slot marked HINT_NONE by the builder and filled by
+//   the hint pass that follows the build); any other shard gets hints on its first extraction, in the WHOLE lines
+//   that happen to hold at most 88 pieces.  No search ever looks at a hint: a lookup never reads past the symbols
+//   its line's own pieces hold (span, in the header), and the flag is a header bit every reader masks off.
 //
 // SPILL LINE (line 17g + 16 of group g) = chunks at even dwords, each
 //   dword 0   totA | totC << 12 | (csym & 0xFF) << 24      tot_x = # of x in the 96 own pieces of
@@ -83,9 +88,10 @@ constexpr uint32_t CHUNK_MAX_PIECES = 24;
 constexpr uint32_t GROUP_SHIFT = 4;    // 16 window lines + 1 spill line
 constexpr uint32_t GROUP = 1u << GROUP_SHIFT;
 constexpr uint32_t KIND_WHOLE = 0, KIND_CHUNK = 1, KIND_FAR = 2;
-constexpr uint32_t HINT_PIECES = 88;       // own pieces of a line whose last two dwords are a psi hint
+constexpr uint32_t HINT_PIECES = 88;       // own pieces of a WHOLE / CHUNK line whose last two dwords are a psi hint
+constexpr uint32_t FAR_HINT_PIECES = 84;   // own pieces of a FAR window line that carries one (dwords 29, 30; 31 = link)
 constexpr uint32_t HINT_META0_BIT = 21;    // bit of meta_0 (= bit 29 of dword 1) saying so
-constexpr uint32_t HINT_MAX_SPAN = 1024;   // (K_j - 1) >> 2 fits a byte
+constexpr uint32_t HINT_NONE = 0xFFFFFFFFu;  // first hint dword of a slot that is not filled
 constexpr uint32_t COUNT_BITS = 40;
 constexpr uint64_t COUNT_MASK = (1ull << COUNT_BITS) - 1;
 constexpr uint64_t MAX_SYMBOLS = 1ull << 40;  // per shard; counts are 40-bit
@@ -113,11 +119,26 @@ struct shard_view {
     const uint64_t *ktab;
     uint64_t C[5];          // C[c] = # symbols with rank < c   (getPC)
     uint64_t total[5];      // occurrences of each symbol in the whole BWT
+    uint32_t sel_shift;     // one select sample per 2^sel_shift occurrences of a symbol (SEL_SHIFT_DENSE / _SPARSE)
+    uint32_t hint_room;     // 1: every window line was laid out with room for a psi hint (RSBWT_OPEN_READS)
+    const uint64_t *sel;    // the select samples, 5 x sel_stride words (nullptr until built: read extraction, getOccAt)
+    uint64_t sel_stride;    // entries per symbol (select_stride)
 };
 
 RSB_HD uint64_t window_of(const span_params &sp, uint64_t p) { return p / sp.S; }
 RSB_HD uint64_t line_of_window(uint64_t w) { return w + (w >> GROUP_SHIFT); }
 RSB_HD uint64_t spill_line_of_window(uint64_t w) { return ((w >> GROUP_SHIFT) * (GROUP + 1)) + GROUP; }
+// pieces a line holds itself, and where its psi hint sits when it has one (above, PSI HINT)
+RSB_HD uint32_t own_pieces(uint32_t kind, uint32_t hint) {
+    return kind == KIND_FAR ? (hint ? FAR_HINT_PIECES : FAR_PIECES) : (hint ? HINT_PIECES : LINE_PIECES);
+}
+RSB_HD uint32_t hint_dword(uint32_t kind) { return kind == KIND_FAR ? LINE_DWORDS - 3u : LINE_DWORDS - 2u; }
+// the shift that brings a row offset r < S below 256 (the hint's boundaries are bytes)
+RSB_HD uint32_t hint_shift(uint32_t S) {
+    uint32_t s = 0;
+    while (((S - 1u) >> s) > 255u) ++s;
+    return s;
+}
 
 struct line_meta {
     uint64_t cnt[4];
@@ -156,7 +177,7 @@ RSB_HD void walk_window(const shard_view &v, uint64_t w, F &&f) {
     for (uint32_t guard = 0; guard < 64; ++guard) {  // a window has at most S <= 2944 pieces = 33 lines
         const uint32_t *L = v.lines + line * LINE_DWORDS;
         const line_meta m = parse_line(L);
-        const uint32_t own = m.kind == KIND_FAR ? FAR_PIECES : m.hint ? HINT_PIECES : LINE_PIECES;
+        const uint32_t own = own_pieces(m.kind, m.hint);
         for (uint32_t i = 0; i < own; ++i) {
             const uint32_t u = dword_piece(L + HDR_DWORDS, i);
             if ((u & 31u) == 0u) break;
@@ -191,13 +212,26 @@ RSB_HD uint64_t count_before_window(const shard_view &v, uint64_t w, uint32_t b)
     return w * v.sp.S - s;
 }
 
-// psi hint (above): the window of the r-th row of the hinted window (r = 0 .. S-1); *exact = false: the hint does not
-// settle this row (it sits within four rows of a boundary, or past the fourth one)
-RSB_HD uint32_t hint_window(uint32_t w0, uint32_t kk, uint32_t r, bool *exact) {
-    const uint32_t rq = r >> 2;
+// psi hint (above): where psi takes the r-th row of the hinted window (r = 0 .. S-1): a window in lo..hi; `open`:
+// the row lies past the hint's last boundary and hi is only the first window to try -- it lies there or further on
+// (measured on the population stream: 15 % of the rows are past the fourth boundary -- a window holds 114 +- 44 of
+// a block's 467 rows -- and four in five of those lie in the very next window; extrapolating from the windows the
+// hint knows does no better than that).  lo == hi and not open: the hint settles the row.  (The boundaries are
+// non-decreasing, so the comparisons count.)
+struct hint_range {
+    uint32_t lo, hi;
+    bool open;
+};
+RSB_HD hint_range hint_windows(uint32_t w0, uint32_t kk, uint32_t r, uint32_t shift) {
+    const uint32_t rq = r >> shift;
     const uint32_t b0 = kk & 0xFFu, b1 = (kk >> 8) & 0xFFu, b2 = (kk >> 16) & 0xFFu, b3 = kk >> 24;
-    *exact = rq != b0 && rq != b1 && rq != b2 && rq < b3;
-    return w0 + (rq > b0 ? 1u : 0u) + (rq > b1 ? 1u : 0u) + (rq > b2 ? 1u : 0u) + (rq > b3 ? 1u : 0u);
+    const uint32_t gt = (rq > b0 ? 1u : 0u) + (rq > b1 ? 1u : 0u) + (rq > b2 ? 1u : 0u) + (rq > b3 ? 1u : 0u);
+    const uint32_t eq = (rq == b0 ? 1u : 0u) + (rq == b1 ? 1u : 0u) + (rq == b2 ? 1u : 0u) + (rq == b3 ? 1u : 0u);
+    hint_range h;
+    h.lo = w0 + gt;
+    h.hi = h.lo + eq;
+    h.open = rq >= b3;
+    return h;
 }
 
 // RLEBWT::getOcc (src/bwt/rlebwt.cpp:268-301): # of symbol b in BWT[0..p], p < n.
@@ -274,26 +308,33 @@ RSB_HD uint64_t view_occ_at(const shard_view &v, uint32_t b, uint64_t bc, uint64
 // Select samples and psi hints (read extraction's getOccAt, src/bwt/rlebwt.cpp:233-266): what the builder
 // kernels write (kernels.hip) and the host-side layout test checks, one piece of code for both.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t SEL_SHIFT = 8;  // one select sample per 256 occurrences (its four count bytes assume exactly that)
+// One select sample per 2^sel_shift occurrences of every symbol (shard_view::sel_shift): DENSE for a shard whose
+// extraction leans on them (8 bytes per 256 occurrences = n / 32 bytes: the sample names the window of ANY occurrence
+// of its block, see below), SPARSE for a shard laid out with a psi hint in every window line (RSBWT_OPEN_READS:
+// n / 512 bytes), where a sample is only the way out for the few rows a hint does not settle.
+constexpr uint32_t SEL_SHIFT_DENSE = 8, SEL_SHIFT_SPARSE = 12;
 
 // entries per symbol of the sample table
 RSB_HD uint64_t select_stride(const shard_view &ix) {
     uint64_t mx = 0;
     for (int c = 0; c <= 4; ++c) mx = ix.total[c] > mx ? ix.total[c] : mx;
-    return (mx >> SEL_SHIFT) + 2;
+    return (mx >> ix.sel_shift) + 2;
 }
 
-// Sample word of the block of 256 occurrences of a symbol that starts with occurrence (m << SEL_SHIFT) + 1:
+// Sample word of the block of 2^shift occurrences of a symbol that starts with occurrence (m << shift) + 1:
 // bits 0..31 = the window w0 holding that first occurrence, then four bytes k0..k3 with k_j + 1 = how many of
 // the block's occurrences lie in windows <= w0 + j (capped at 256).  The window of the block's r-th occurrence
-// (r = 0..255) is w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while r <= k3, a lower bound beyond
-// (the block spreads over more than five windows).
-RSB_HD uint32_t sample_window(uint64_t word, uint64_t bc, bool *exact) {
-    const uint32_t r = (uint32_t)((bc - 1) & ((1u << SEL_SHIFT) - 1u));
+// (r = 0 .. 2^shift - 1) is w0 + [r > k0] + [r > k1] + [r > k2] + [r > k3] -- EXACT while r <= k3, a lower bound
+// beyond (the block's first 256 occurrences spread over more than five windows, or r >= 256 in a sparse table --
+// where a capped count byte, 255, no longer counts).
+RSB_HD uint32_t sample_window(uint64_t word, uint64_t bc, uint32_t shift, bool *exact) {
+    const uint32_t r = (uint32_t)((bc - 1) & ((1ull << shift) - 1ull));
     const uint32_t k0 = (uint32_t)(word >> 32) & 0xFFu, k1 = (uint32_t)(word >> 40) & 0xFFu;
     const uint32_t k2 = (uint32_t)(word >> 48) & 0xFFu, k3 = (uint32_t)(word >> 56);
     *exact = r <= k3;
-    return (uint32_t)word + (r > k0 ? 1u : 0u) + (r > k1 ? 1u : 0u) + (r > k2 ? 1u : 0u) + (r > k3 ? 1u : 0u);
+    // (a count byte of 255 is capped: it says "256 or more", and nothing about an r beyond 255 -- sparse tables)
+    return (uint32_t)word + (r > k0 && k0 != 255u ? 1u : 0u) + (r > k1 && k1 != 255u ? 1u : 0u) +
+           (r > k2 && k2 != 255u ? 1u : 0u) + (r > k3 && k3 != 255u ? 1u : 0u);
 }
 
 // The sample words of the blocks of symbol c whose first occurrence lies in window w: emit(m, word).
@@ -301,22 +342,23 @@ template <class E>
 RSB_HD void window_samples(const shard_view &ix, uint64_t w, uint32_t c, E &&emit) {
     // (held to the symbol's total: the sample index is then inside the table whatever the lines say -- a
     // damaged count word would otherwise send the caller writing far outside it)
+    const uint32_t shift = ix.sel_shift;
     const uint64_t tc = ix.total[c];
     const uint64_t cb = count_before_window(ix, w, c);
     uint64_t ce = count_before_window(ix, w + 1, c);
     ce = ce < tc ? ce : tc;
     if (ce <= cb) return;
-    // occurrences cb+1 .. ce live here; sample m is occurrence (m << SEL_SHIFT) + 1
-    uint64_t m = (cb + (1ull << SEL_SHIFT) - 1) >> SEL_SHIFT;
-    if ((m << SEL_SHIFT) >= ce) return;
+    // occurrences cb+1 .. ce live here; sample m is occurrence (m << shift) + 1
+    uint64_t m = (cb + (1ull << shift) - 1) >> shift;
+    if ((m << shift) >= ce) return;
     uint64_t upto[4] = {ce, 0, 0, 0};
     for (int j = 1; j < 4; ++j) {
         const uint64_t x = count_before_window(ix, w + 1 + j, c);
         upto[j] = x < tc ? x : tc;
         if (upto[j] < upto[j - 1]) upto[j] = upto[j - 1];  // monotone whatever the lines say
     }
-    for (; (m << SEL_SHIFT) < ce; ++m) {
-        const uint64_t before = m << SEL_SHIFT;  // occurrences before the block
+    for (; (m << shift) < ce; ++m) {
+        const uint64_t before = m << shift;  // occurrences before the block
         uint64_t word = w & 0xFFFFFFFFull;
         for (int j = 0; j < 4; ++j) {
             uint64_t kj = upto[j] - before;  // >= 1 for j = 0
@@ -327,20 +369,43 @@ RSB_HD void window_samples(const shard_view &ix, uint64_t w, uint32_t c, E &&emi
     }
 }
 
-// The psi hint of window w (above, WINDOW LINE): true when the line may carry one, with its two dwords.
+// The window that holds the bc-th b (1 <= bc <= total[b]): the sample names it, or bounds it together with the next
+// sample -- then the floor search over the window headers in between (BPTree::select's role, BPTree.h:50-67).
+RSB_HD uint64_t select_window(const shard_view &ix, const uint64_t *sel, uint64_t stride_m, uint32_t b, uint64_t bc) {
+    const uint64_t m = (bc - 1) >> ix.sel_shift;
+    bool exact;
+    uint64_t lo = sample_window(sel[b * stride_m + m], bc, ix.sel_shift, &exact);
+    if (lo >= ix.nwin) lo = ix.nwin - 1;
+    if (exact) return lo;
+    uint64_t hi = ((m + 1) << ix.sel_shift) < ix.total[b] ? (uint32_t)sel[b * stride_m + m + 1] : ix.nwin - 1;
+    if (hi >= ix.nwin) hi = ix.nwin - 1;
+    if (hi < lo) hi = lo;
+    while (hi > lo) {  // largest w in [lo, hi] with count_before(w) < bc
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (count_before_window(ix, mid, b) >= bc) hi = mid - 1;
+        else lo = mid;
+    }
+    return lo;
+}
+
+// The psi hint of window w (above, WINDOW LINE): true when the line may carry one -- it was laid out with the room
+// (its flag is set, its slot still says HINT_NONE) or it is a WHOLE line of at most 88 pieces -- with its two dwords.
 RSB_HD bool window_psi_hint(const shard_view &ix, const uint64_t *sel, uint64_t stride_m, uint64_t w, uint32_t *w0_out,
                             uint32_t *kk_out) {
     const uint32_t S = ix.sp.S;
-    if (S > HINT_MAX_SPAN) return false;
     const uint32_t *Ln = ix.lines + line_of_window(w) * LINE_DWORDS;
     const line_meta m = parse_line(Ln);
-    if (m.kind != KIND_WHOLE || m.hint) return false;
-    uint32_t np = 0;  // pieces the line holds: a hint needs the last 8 piece bytes free
-    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
-        if ((dword_piece(Ln + HDR_DWORDS, i) & 31u) == 0u) break;
-        ++np;
+    if (m.hint) {
+        if (Ln[hint_dword(m.kind)] != HINT_NONE) return false;  // filled already
+    } else {
+        if (m.kind != KIND_WHOLE) return false;
+        uint32_t np = 0;  // pieces the line holds: a hint needs the last 8 piece bytes free
+        for (uint32_t i = 0; i < LINE_PIECES; ++i) {
+            if ((dword_piece(Ln + HDR_DWORDS, i) & 31u) == 0u) break;
+            ++np;
+        }
+        if (np > HINT_PIECES) return false;
     }
-    if (np > HINT_PIECES) return false;
     const uint64_t r0 = w * (uint64_t)S;
     uint32_t f = 0;
     while (f < 4u && ix.C[f + 1] <= r0) ++f;  // F symbol of row r0 (getF, rlebwt.cpp:307-314)
@@ -352,21 +417,20 @@ RSB_HD bool window_psi_hint(const shard_view &ix, const uint64_t *sel, uint64_t 
     uint64_t seff = tot - bc0 + 1ull;          // rows of this window that belong to f's block
     if (seff > S) seff = S;
     if (r0 + seff > ix.n) seff = ix.n - r0;
-    bool exact;
-    const uint32_t w0 = sample_window(sel[f * stride_m + ((bc0 - 1ull) >> SEL_SHIFT)], bc0, &exact);
-    if (!exact || w0 >= ix.nwin) return false;
-    // the sample must be right: count(w0) < bc0 <= count(w0 + 1)
-    if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, (uint64_t)w0 + 1, f))) return false;
+    const uint64_t w0 = select_window(ix, sel, stride_m, f, bc0);
+    // the window must be right: count(w0) < bc0 <= count(w0 + 1)
+    if (!(count_before_window(ix, w0, f) < bc0 && bc0 <= count_before_window(ix, w0 + 1, f))) return false;
+    const uint32_t shift = hint_shift(S);
     uint32_t kk = 0;
     for (uint32_t j = 0; j < 4; ++j) {
-        const uint64_t c = count_before_window(ix, (uint64_t)w0 + 1 + j, f);
+        const uint64_t c = count_before_window(ix, w0 + 1 + j, f);
         uint64_t upto = c < bc0 - 1ull ? 0ull : c - (bc0 - 1ull);  // of the block's occurrences, those in windows <= w0 + j
         if (upto > seff) upto = seff;
-        // b_j = (K_j - 1) >> 2; 255 = "all of them" (then every row up to r >> 2 == 254 is at or before window w0 + j)
-        const uint32_t bj = upto >= seff ? 255u : (uint32_t)(((upto ? upto : 1ull) - 1ull) >> 2);
+        // b_j = (K_j - 1) >> shift; 255 = "all of them" (then every row of the window is at or before window w0 + j)
+        const uint32_t bj = upto >= seff ? 255u : (uint32_t)(((upto ? upto : 1ull) - 1ull) >> shift);
         kk |= bj << (8u * j);
     }
-    *w0_out = w0;
+    *w0_out = (uint32_t)w0;
     *kk_out = kk;
     return true;
 }
@@ -424,9 +488,10 @@ struct group_stats {
     uint64_t spilled_symbols; // symbols not held by their window's own line
 };
 
-// Packs one window / far line: counts at its first piece, its np pieces, how it continues.
+// Packs one window / far line: counts at its first piece, its np pieces, how it continues.  hint_slot: the line is
+// laid out with room for a psi hint (np <= own_pieces(kind, 1)): flag set, slot marked HINT_NONE.
 RSB_HD void emit_line(uint32_t *L, const uint64_t cnt0[4], const uint8_t *pieces, uint32_t np, uint32_t kind,
-                      uint32_t cdw, uint32_t far_link) {
+                      uint32_t cdw, uint32_t far_link, bool hint_slot) {
     uint32_t start[5] = {0, 0, 0, 0, 0};
     uint32_t half[4] = {0, 0, 0, 0};
     uint32_t sofar = 0;
@@ -439,7 +504,7 @@ RSB_HD void emit_line(uint32_t *L, const uint64_t cnt0[4], const uint8_t *pieces
         }
     }
     start[4] = sofar;
-    const uint32_t meta[4] = {start[1] | (start[2] << 10),
+    const uint32_t meta[4] = {start[1] | (start[2] << 10) | ((hint_slot ? 1u : 0u) << HINT_META0_BIT),
                               (start[3] - start[2]) | ((start[4] - start[3]) << 10) | (kind << 20),
                               half[0] | (half[1] << 11) | (((cdw >> 1) & 3u) << 22),
                               half[2] | (half[3] << 11) | (((cdw >> 3) & 3u) << 22)};
@@ -456,15 +521,20 @@ RSB_HD void emit_line(uint32_t *L, const uint64_t cnt0[4], const uint8_t *pieces
         }
         L[HDR_DWORDS + d] = x;
     }
+    if (hint_slot) {
+        L[hint_dword(kind)] = HINT_NONE;
+        L[hint_dword(kind) + 1u] = 0u;
+    }
     if (kind == KIND_FAR) L[LINE_DWORDS - 1] = far_link;
 }
 
 // Lays out group g (windows 16g .. 16g+15).  `rd` stands at symbol 16*g*S.  With WRITE the 17 lines
 // of the group and its far lines (from absolute line far_base on) are written; without, only the
 // statistics are gathered -- by the same decisions, so that a counting pass sizes the far region.
+// `room`: every window line keeps its last 8 piece bytes for a psi hint (RSBWT_OPEN_READS).
 template <bool WRITE>
 RSB_HD group_stats build_group(const span_params &sp, uint64_t n, uint64_t nwin, uint64_t g, run_reader &rd,
-                               uint32_t *lines, uint64_t far_base) {
+                               uint32_t *lines, uint64_t far_base, bool room = false) {
     group_stats st = {0, 0, 0, 0};
     uint32_t spill[LINE_DWORDS];
     for (uint32_t d = 0; d < LINE_DWORDS; ++d) spill[d] = 0;
@@ -490,24 +560,26 @@ RSB_HD group_stats build_group(const span_params &sp, uint64_t n, uint64_t nwin,
                 remaining -= len;
             }
             const bool ends = remaining == 0u;
+            const bool slot = room && first;  // only a window's first line is ever looked at for a hint
+            const uint32_t cap = own_pieces(KIND_WHOLE, slot ? 1u : 0u);
             uint32_t keep, kind = KIND_WHOLE, cdw = 0, link = 0;
-            if (ends && nb <= LINE_PIECES) {
+            if (ends && nb <= cap) {
                 keep = nb;
             } else {
-                const uint32_t extra = nb > LINE_PIECES ? nb - LINE_PIECES : 0u;
+                const uint32_t extra = nb > cap ? nb - cap : 0u;
                 const uint32_t need = 2u + 2u * ((extra + 7u) / 8u);  // header + pieces, in dwords, even
                 if (first && ends && extra <= CHUNK_MAX_PIECES && sdw + need <= LINE_DWORDS) {
-                    keep = LINE_PIECES;
+                    keep = cap;
                     kind = KIND_CHUNK;
                     cdw = sdw;
                     uint32_t tot[4] = {0, 0, 0, 0}, csym = 0;
-                    for (uint32_t i = 0; i < LINE_PIECES; ++i) {
+                    for (uint32_t i = 0; i < cap; ++i) {
                         const uint32_t sy = buf[i] >> 5;
                         if (sy >= 1u && sy <= 4u) tot[sy - 1u] += buf[i] & 31u;
                     }
-                    for (uint32_t i = LINE_PIECES; i < nb; ++i) {
+                    for (uint32_t i = cap; i < nb; ++i) {
                         csym += buf[i] & 31u;
-                        spill[sdw + 2u + ((i - LINE_PIECES) >> 2)] |= (uint32_t)buf[i] << (8u * ((i - LINE_PIECES) & 3u));
+                        spill[sdw + 2u + ((i - cap) >> 2)] |= (uint32_t)buf[i] << (8u * ((i - cap) & 3u));
                     }
                     spill[sdw] = tot[0] | (tot[1] << 12) | ((csym & 0xFFu) << 24);
                     spill[sdw + 1] = tot[2] | (tot[3] << 12) | ((csym >> 8) << 24);
@@ -515,7 +587,7 @@ RSB_HD group_stats build_group(const span_params &sp, uint64_t n, uint64_t nwin,
                     st.chunk_windows += 1;
                     st.spilled_symbols += csym;
                 } else {
-                    keep = FAR_PIECES;
+                    keep = own_pieces(KIND_FAR, slot ? 1u : 0u);
                     kind = KIND_FAR;
                     link = (uint32_t)(far_base + st.far_lines);
                     st.far_lines += 1;
@@ -525,7 +597,7 @@ RSB_HD group_stats build_group(const span_params &sp, uint64_t n, uint64_t nwin,
             uint32_t held = 0;
             for (uint32_t i = 0; i < keep; ++i) held += buf[i] & 31u;
             if (first && kind == KIND_FAR) st.spilled_symbols += wsyms - held;
-            if (WRITE) emit_line(lines + line * LINE_DWORDS, cnt_line, buf, keep, kind, cdw, link);
+            if (WRITE) emit_line(lines + line * LINE_DWORDS, cnt_line, buf, keep, kind, cdw, link, slot);
             if (kind != KIND_FAR) break;
             // the window goes on in the far line: counts at its first piece, pieces shifted down
             for (uint32_t i = 0; i < keep; ++i) {

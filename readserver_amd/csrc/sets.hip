@@ -116,6 +116,7 @@ struct rsbwt_set {
     bool owns = false;
     std::vector<dev_group *> groups;
     bool comms_tried = false, comms_ok = false;
+    bool views_name_samples = false;  // the views in HBM were published after every shard had its select samples
     std::mutex mu;
     // Collectives on the set's communicators are enqueued by one thread at a time: two callers
     // interleaving their group calls could reach the communicators in different orders.
@@ -973,39 +974,47 @@ int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_
     if (s->groups.size() != 1) return fail(RSBWT_EINVAL, "the set spans %zu devices: device-resident calls need one", s->groups.size());
     if (n == 0) return RSBWT_OK;
     if (!d_rows || !d_out || !d_len || !d_prefix_len) return fail(RSBWT_EINVAL, "null argument");
+    if (stride == 0) return fail(RSBWT_EINVAL, "stride must be positive");
     dev_group *g = s->groups[0];
     const size_t S = s->shards.size();
-    auto one = [&](size_t i, hipStream_t st) {
-        return rsbwt_extract_dev(s->shards[i], (const uint8_t *)d_rows + i * n * 8, n, (uint8_t *)d_out + i * n * (size_t)stride,
-                                 stride, (uint8_t *)d_len + i * n * 4, (uint8_t *)d_prefix_len + i * n * 4, st);
-    };
-    static const bool turns_only = getenv("RSBWT_SET_EXTRACT_TURNS") != nullptr;  // A/B knob (tools/README.md)
-    if (S == 1 || turns_only) {
+    static const bool turns_only = getenv("RSBWT_SET_EXTRACT_TURNS") != nullptr;  // A/B knob (tools/README.md): a launch sequence per shard
+    if (turns_only || n > (1ull << 31)) {
         for (size_t i = 0; i < S; ++i) {
-            const int rc = one(i, (hipStream_t)stream);
+            const int rc = rsbwt_extract_dev(s->shards[i], (const uint8_t *)d_rows + i * n * 8, n, (uint8_t *)d_out + i * n * (size_t)stride,
+                                             stride, (uint8_t *)d_len + i * n * 4, (uint8_t *)d_prefix_len + i * n * 4, stream);
             if (rc) return rc;
         }
         return RSBWT_OK;
     }
     int rc = use_device(g->device);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(g->fork_mu);
-    if ((rc = g->ensure_fork()) != RSBWT_OK) return rc;
-    HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));
-    for (size_t i = 0; i < S; ++i) {
-        hipStream_t st = g->fork_st[i % dev_group::FORK];
-        HIP_OK(hipStreamWaitEvent(st, g->fork_ev, 0));
-        if ((rc = one(i, st)) != RSBWT_OK) break;
-        if (i + dev_group::FORK >= S) {
-            HIP_OK(hipEventRecord(g->join_ev[i % dev_group::FORK], st));
-            HIP_OK(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0));
+    // ONE launch sequence walks the rows of every shard (extract_lines.hip: a wave walks one shard at a time); the
+    // shards' views in HBM must name their select samples -- built here for a shard that has none yet
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        bool stale = false;
+        for (size_t i = 0; i < S; ++i) {
+            rsbwt_t *h = s->shards[i];
+            if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+            if (!h->view.sel) {
+                if ((rc = ensure_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
+                stale = true;
+            }
+        }
+        if (stale || !s->views_name_samples) {
+            if ((rc = publish_views(s)) != RSBWT_OK) return rc;
+            s->views_name_samples = true;
         }
     }
-    if (rc) {
-        for (int i = 0; i < dev_group::FORK; ++i)
-            if (hipEventRecord(g->join_ev[i], g->fork_st[i]) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i], 0);
+    unsigned long long *work = nullptr;
+    if (g->counting) {  // rsbwt_set_set_counting: the walk kernels' counters over all shards, read with rsbwt_set_last_search_counters
+        work = g->d_work;
+        HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
     }
-    return rc;
+    const hipError_t e = launch_extract_wave(g->scratch, g->d_views, (uint32_t)S, d_rows, n, d_out, stride, d_prefix_len, d_len, g->num_cus,
+                                             (hipStream_t)stream, work);
+    if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
+    return RSBWT_OK;
 }
 
 int rsbwt_rccl_available(void) { return rccl().ok ? 1 : 0; }

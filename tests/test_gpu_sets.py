@@ -377,6 +377,86 @@ def test_gpu_psi_hints_change_nothing_but_the_requests(rsb, oracle, style, span)
         assert np.array_equal(lo, elo) and np.array_equal(up, eup)
 
 
+@pytest.mark.parametrize("style,span", [("pop", 0), ("pop", 300), ("pop", 40), ("mixed", 0), ("mixed", 1500), ("dense", 90),
+                                        ("dense", 70), ("long", 0), ("desert", 0)])
+def test_gpu_shard_opened_for_reads(rsb, oracle, style, span):
+    """RSBWT_OPEN_READS: every window line is laid out with room for a psi hint (88 own pieces; 84 in a window line
+    that ends in a far link), the hints and a sparse select-sample table are built as part of the open.  Held to:
+    (1) a hint in every window whose rows have a psi; (2) the reads of a plain handle of the same runs and of the oracle,
+    rows of every kind (chunk and far windows, rows a hint only bounds, rows past its reach: the desert stream);
+    (3) every other reader exact on this layout -- Occ at every position, getChar, getOccAt through the sparse
+    samples, findInterval with and without a table, the 1-mismatch matrices."""
+    L = rsb.lib()
+    rng = np.random.default_rng(len(style) * 131 + span)
+    R = 250000
+    if style in ("pop", "mixed"):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 4243 | ((1 << 62) if style == "pop" else 0)) == 0
+    elif style == "dense":
+        runs = (rng.integers(0, 5, R).astype(np.uint8) << 5) | 1
+    elif style == "desert":  # stretches without one symbol: the rows of a window spread over many windows
+        sym = np.where((np.arange(R) // 9000) % 2 == 0, rng.integers(0, 5, R), rng.integers(0, 4, R))
+        runs = (sym.astype(np.uint8) << 5) | rng.integers(1, 9, R).astype(np.uint8)
+    else:
+        runs = (np.where(rng.random(R) < 0.02, 0, rng.integers(1, 5, R)).astype(np.uint8) << 5) | 31
+    oix = oracle.from_runs(runs)
+    n = oix.bwlen()
+    rows = np.concatenate([rng.integers(0, n, 30000), np.arange(0, min(n, 4000))]).astype(np.uint64)
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (20000, 14))]
+    elo, eup = oix.find_intervals(km)
+
+    def extract(g):
+        out = np.zeros((rows.size, 1024), np.uint8)
+        ln, pl = np.empty(rows.size, np.uint32), np.empty(rows.size, np.uint32)
+        assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
+        return out, ln, pl
+
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as plain:
+        assert L.rsbwt_opened_for_reads(plain.handle) == 0
+        o0, l0, p0 = extract(plain)
+        S_plain = plain.window_span()
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6, for_reads=True) as g:
+        assert L.rsbwt_opened_for_reads(g.handle) == 1
+        S = g.window_span()
+        assert S == span if span else S < S_plain  # (88 of 96 piece bytes hold pieces: a smaller window for the same fill)
+        hints = L.rsbwt_psi_hint_lines(g.handle)  # there before any extraction
+        dollars = int((runs & 31)[(runs >> 5) == 0].astype(np.int64).sum())
+        assert hints >= 0.97 * ((n - dollars) // S) - 8, (hints, n, dollars, S)
+        o1, l1, p1 = extract(g)
+        assert L.rsbwt_psi_hint_lines(g.handle) == hints  # the index is immutable once open
+        assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
+        fit = l1 != 0xFFFFFFFF
+        for i in np.nonzero(fit)[0]:
+            assert np.array_equal(o0[i, :l0[i]], o1[i, :l1[i]]), i
+        for i in np.nonzero(fit)[0][::29]:
+            pre, post = oix.extract(int(rows[i]), cap=4096)
+            assert o1[i, :l1[i]].tobytes().decode() == pre + post and p1[i] == len(pre)
+        lo, up = rsb.find_intervals(g, km)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+        pos = np.arange(0, n, 1, dtype=np.uint64) if n < 3000000 else np.arange(0, n, 3, dtype=np.uint64)
+        tot = np.zeros(pos.size, np.uint64)
+        for ch in "$ACGT":
+            tot += g.occ_batch(ch, pos)
+        assert np.array_equal(tot, pos + 1)
+        for ch in "ACGT":
+            t = oix.occ(ch, n - 1)
+            if t:
+                bc = rng.integers(1, t + 1, 3000).astype(np.uint64)
+                idx = g.occ_at_batch(ch, bc)
+                assert (g.char_batch(idx) == ord(ch)).all() and np.array_equal(g.occ_batch(ch, idx), bc)
+                assert all(int(idx[j]) == oix.occ_at(ch, int(bc[j])) for j in range(0, 3000, 101))
+        samp = pos[::max(1, pos.size // 20000)]
+        assert all(int(o) == oix.occ("G", int(p_)) for o, p_ in zip(g.occ_batch("G", samp)[::40], samp[::40]))
+        lo1, up1 = rsb.find_intervals_1mm(g, km[:200])
+        assert np.array_equal(lo1[:, 0], elo[:200]) and np.array_equal(up1[:, 0], eup[:200])
+        from readserver_amd import selfcheck
+        res = selfcheck.extraction_vs_mirrors(g, rows[:3000], stride=1024)
+        assert res["rows_differing"] == 0, res
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=None, for_reads=True) as g2:  # no table: every step through the lines
+        lo, up = rsb.find_intervals(g2, km)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+
+
 def test_gpu_read_packing_kernels_match_the_host_form(rsb):
     """rsbwt_pack_reads_dev / rsbwt_unpack_reads_dev against the torch form of readserver_amd/sharded.py."""
     import torch

@@ -29,23 +29,28 @@ def _runs(style, R, rng, L):
                                           ("mixed", 60000, 0), ("mixed", 60000, 768), ("rand", 40000, 0),
                                           ("rand", 1, 0), ("rand", 2, 0), ("rand", 97, 0), ("rand", 17, 5),
                                           ("rand", 3000, 2), ("rand", 3000, 3)])
-def test_layout_is_exact_at_every_position(rsb, style, R, span):
+@pytest.mark.parametrize("room", [False, True])
+def test_layout_is_exact_at_every_position(rsb, style, R, span, room):
+    """room: the RSBWT_OPEN_READS layout -- every window line keeps its last 8 piece bytes for a psi hint."""
     L = rsb.lib()
     rng = np.random.default_rng(R + span)
     runs = _runs(style, R, rng, L)
     st = (C.c_uint64 * 6)()
     bad = C.c_uint64()
-    rc = L.rsbwt_layout_selftest_host(runs.ctypes.data, R, span, st, C.byref(bad))
+    n = int((runs & 31).astype(np.int64).sum())
+    want = span
+    if room and span == 0:  # (the GPU builder aims at 88/96 of the plain layout's pieces per window: build_lines.hip)
+        want = max(2, min(2944, int(82.0 * n / R + 0.5)))
+    rc = L.rsbwt_layout_selftest_host(runs.ctypes.data, R, want | (1 << 31 if room else 0), st, C.byref(bad))
     assert rc == 0, f"first disagreement at position {bad.value}"
     S, nlines, far, chunkw, farw, spilled = list(st)
-    n = int((runs & 31).astype(np.int64).sum())
-    assert 2 <= S <= 2944 and (span == 0 or S == span)
+    assert 2 <= S <= 2944 and (want == 0 or S == want)
     assert nlines == ((n + S - 1) // S + 15) // 16 * 17 + far
     if span == 0 and style != "mixed":  # (the GPU builder also shrinks S when stretches differ: build_lines.hip)
         assert spilled <= 0.03 * n  # ~90 pieces per window: few positions past their line
     if style == "dense" and span:
         assert far > 0 and farw > 0
-    if style == "synth" and span == 0:
+    if style == "synth" and span == 0 and not room:
         assert chunkw > 0 and nlines * 128 < 1.62 * R  # ~1.55 bytes per run byte
 
 
@@ -80,11 +85,15 @@ def test_layout_code_under_address_and_ub_sanitizers(tmp_path):
 
 @pytest.mark.parametrize("style,R,span", [("synth", 60000, 0), ("pop", 80000, 0), ("pop", 80000, 300), ("pop", 60000, 1024),
                                           ("dense", 30000, 90), ("long", 30000, 0), ("mixed", 60000, 0), ("rand", 40000, 0),
-                                          ("desert", 60000, 0), ("rand", 1, 0), ("rand", 97, 5), ("rand", 3000, 2)])
-def test_select_samples_and_psi_hints_are_exact(rsb, style, R, span):
-    """The select samples name the window of EVERY occurrence (or bound it from below where they say so), a psi hint
-    that claims to be exact names the window psi takes EVERY row of its window to, and the lines that carry hints
-    still answer Occ / getChar / getOccAt like the naive BWT at every position -- host run of the code the GPU runs."""
+                                          ("desert", 60000, 0), ("rand", 1, 0), ("rand", 97, 5), ("rand", 3000, 2),
+                                          ("pop", 80000, 2000), ("dense", 30000, 2944)])
+@pytest.mark.parametrize("room", [False, True])
+def test_select_samples_and_psi_hints_are_exact(rsb, style, R, span, room):
+    """The select samples name the window of EVERY occurrence (or bound it from below where they say so, and the floor
+    search between two samples then ends on it), a psi hint bounds the window psi takes EVERY row of its window to
+    (lo..hi, or from lo on where it says so), and the lines that carry hints still answer Occ / getChar / getOccAt like
+    the naive BWT at every position -- host run of the code the GPU runs.  room: the RSBWT_OPEN_READS layout (a hint
+    slot in every window line, one sample per 4,096 occurrences)."""
     L = rsb.lib()
     rng = np.random.default_rng(R * 7 + span)
     if style == "pop":
@@ -97,12 +106,22 @@ def test_select_samples_and_psi_hints_are_exact(rsb, style, R, span):
         runs = _runs(style, R, rng, L)
     st = (C.c_uint64 * 4)()
     bad = C.c_uint64()
-    rc = L.rsbwt_layout_selftest_psi_host(runs.ctypes.data, R, span, st, C.byref(bad))
+    n = int((runs & 31).astype(np.int64).sum())
+    want = span
+    if room and span == 0:
+        want = max(2, min(2944, int(82.0 * n / R + 0.5)))
+    rc = L.rsbwt_layout_selftest_psi_host(runs.ctypes.data, R, want | (1 << 31 if room else 0), st, C.byref(bad))
     assert rc == 0, f"first disagreement at {bad.value}"
     words, inexact, hint_lines, by_hint = list(st)
-    n = int((runs & 31).astype(np.int64).sum())
-    assert words >= n // 256
+    assert words >= n // (4096 if room else 256)
     if style == "desert":
         assert inexact > 0
     if style == "pop" and span == 0:
         assert hint_lines > 0.3 * (n // 500) and by_hint > 0.2 * n
+    if room and n > 3000:  # every window whose rows have a psi at all carries a hint
+        S = want if want else int(90.0 * n / R + 0.5)
+        dollars = int((runs & 31)[(runs >> 5) == 0].astype(np.int64).sum())  # ('$' rows end a walk: their windows get none)
+        nwin = (n - dollars + S - 1) // S
+        assert hint_lines >= 0.9 * nwin - 8, (hint_lines, nwin)
+        if style == "pop":
+            assert by_hint > 0.8 * n, (by_hint, n)
