@@ -464,7 +464,8 @@ int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint3
 /* Test hook (answers no query): overwrites n bytes of the index in HBM -- region 0: the window lines,
  * 1: the handle's own k-mer table -- so that tests can hold the kernels to what they do with a DAMAGED
  * index: no read outside the index, every wave drains, a table entry that is not an interval of this BWT
- * is not believed.  RSBWT_ERANGE outside the region. */
+ * is not believed.  RSBWT_ERANGE outside the region.  Refused (RSBWT_EINVAL) unless the environment has
+ * RSBWT_ENABLE_TEST_HOOKS set: nothing in a deployment may write into a published index. */
 int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes, size_t n);
 
 /* Test hook (answers no query): the kernels' position -> window division (an f64 multiply and one fix-up step

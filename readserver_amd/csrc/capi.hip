@@ -52,49 +52,21 @@ int use_device(int device) {
 // handle (the reference shares one BWT* across its pool threads, service.cpp:1513,1532-1569) run
 // side by side instead of queueing on one lock.  At most MAX_CTX per handle; further callers wait.
 call_ctx *ctx_pool::acquire() {
-    std::unique_lock<std::mutex> lock(mu);
-    for (;;) {
-        if (!free_.empty()) {
-            call_ctx *c = free_.back();
-            free_.pop_back();
-            return c;
+    return bounded_pool<call_ctx, 8>::acquire([]() -> call_ctx * {
+        call_ctx *c = new (std::nothrow) call_ctx();
+        if (!c) return nullptr;
+        if (hipStreamCreateWithFlags(&c->st[0], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->st[1], hipStreamNonBlocking) != hipSuccess) {
+            if (c->st[0]) (void)hipStreamDestroy(c->st[0]);
+            delete c;
+            return nullptr;
         }
-        if (created < MAX_CTX) {
-            ++created;
-            lock.unlock();
-            call_ctx *c = new (std::nothrow) call_ctx();
-            if (c) {
-                if (hipStreamCreateWithFlags(&c->st[0], hipStreamNonBlocking) != hipSuccess ||
-                    hipStreamCreateWithFlags(&c->st[1], hipStreamNonBlocking) != hipSuccess) {
-                    if (c->st[0]) (void)hipStreamDestroy(c->st[0]);
-                    delete c;
-                    c = nullptr;
-                }
-            }
-            if (!c) {
-                lock.lock();
-                --created;
-                if (created == 0) return nullptr;  // not even one context: report it
-                cv.wait(lock);  // others exist: wait for one of them instead of asking the runtime again at once
-                continue;
-            }
-            if (hipHostMalloc(&c->h_pin, call_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                c->h_pin = nullptr;  // small calls go the ordinary way
-            }
-            return c;
+        if (hipHostMalloc(&c->h_pin, call_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_pin = nullptr;  // small calls go the ordinary way
         }
-        cv.wait(lock);
-    }
-}
-
-void ctx_pool::release(call_ctx *c) {
-    if (!c) return;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        free_.push_back(c);
-    }
-    cv.notify_one();
+        return c;
+    });
 }
 
 void ctx_pool::destroy() {
@@ -478,6 +450,8 @@ int rsbwt_debug_fast_window(const uint64_t *p, size_t n, uint32_t S, uint32_t *w
 // wave drains); answers no query.
 int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes, size_t n) {
     if (!h || (!bytes && n)) return fail(RSBWT_EINVAL, "null argument");
+    // (a write into a published index: refused unless the process asked for the test hooks)
+    if (getenv("RSBWT_ENABLE_TEST_HOOKS") == nullptr) return fail(RSBWT_EINVAL, "rsbwt_debug_poke is a test hook: set RSBWT_ENABLE_TEST_HOOKS=1");
     const uint64_t size = region == 0 ? h->view.nlines * (uint64_t)LINE_BYTES
                           : region == 1 && h->view.ktab && h->ktab_owned ? 8ull << (2u * h->view.ktab_depth) : 0ull;
     if (offset > size || n > size - offset) return fail(RSBWT_ERANGE, "poke outside the region (%llu bytes)", (unsigned long long)size);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/rsbwt.h"
+#include "ctx_pool.h"
 #include "kernels.h"
 #include "line_format.h"
 
@@ -35,14 +36,10 @@ struct call_ctx {
     void *h_pin = nullptr;
 };
 
-struct ctx_pool {
-    static constexpr int MAX_CTX = 8;  // the reference's query pool has 8 threads (service.cpp:88)
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<call_ctx *> free_;
-    int created = 0;
+// (the waiting logic: ctx_pool.h; 8 = the threads of the reference's query pool, service.cpp:88)
+struct ctx_pool : bounded_pool<call_ctx, 8> {
+    static constexpr int MAX_CTX = 8;
     call_ctx *acquire();  // blocks while MAX_CTX calls are in flight; nullptr = no stream could be made
-    void release(call_ctx *c);
     void destroy();       // with no call in flight
 };
 

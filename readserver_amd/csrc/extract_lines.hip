@@ -33,6 +33,17 @@
 
 namespace rsb {
 
+// Waves per workgroup of the walk kernels and the workgroups per CU they are compiled for (tuning knobs,
+// tools/build_variant.sh): a wave's 8 KB stage is all a workgroup shares, so smaller workgroups only change how many
+// waves a CU's LDS and registers admit.
+#ifndef RSB_WALK_WG_WAVES
+#define RSB_WALK_WG_WAVES 4
+#endif
+#ifndef RSB_WALK_MIN_WGS
+#define RSB_WALK_MIN_WGS 4
+#endif
+constexpr int XWG_WAVES = RSB_WALK_WG_WAVES;
+
 
 // the header fields a lane-private parse needs
 struct line_head {
@@ -106,11 +117,11 @@ __device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, si
 enum { XW_PASSES = 0, XW_ACTIVE = 1, XW_STEPS = 2, XW_CONT = 3, XW_FETCHED = 4, XW_CYCLES = 5, XW_WAIT = 6, XW_PROBES = 7, XW_WORDS = 8 };
 
 template <bool COUNT_WORK>
-__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+__global__ void __launch_bounds__(64 * XWG_WAVES, RSB_WALK_MIN_WGS)
 extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
                            size_t n, uint8_t *__restrict__ out_all, uint32_t stride, uint32_t *__restrict__ plen_all,
                            unsigned long long *__restrict__ pools, unsigned long long *__restrict__ work) {
-    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    __shared__ uint4 s_stage[XWG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
@@ -331,12 +342,12 @@ extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshar
 // tlen = length of the whole read (UINT32_MAX: it does not fit, or the prefix did not).
 // ---------------------------------------------------------------------------------------------------
 template <bool COUNT_WORK>
-__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+__global__ void __launch_bounds__(64 * XWG_WAVES, RSB_WALK_MIN_WGS)
 extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
                             size_t n, uint8_t *__restrict__ out_all, uint32_t stride, const uint32_t *__restrict__ plen_all,
                             uint32_t *__restrict__ tlen_all, unsigned long long *__restrict__ pools,
                             unsigned long long *__restrict__ work) {
-    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    __shared__ uint4 s_stage[XWG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
@@ -778,7 +789,7 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
         return e;
     }
     const size_t total = n * (size_t)nshards;
-    size_t g = (total + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
+    size_t g = (total + 64 * XWG_WAVES - 1) / (64 * XWG_WAVES);
     // Workgroups: what is resident at once (4 per CU: 99 of 128 VGPRs, 32 KB of LDS each) and no more.  A walk kernel
     // ends in a tail as long as its longest walk (a few hundred passes, most lanes idle), so the more rows each lane
     // walks before that tail the better: the shards of a set are walked by ONE launch (a launch per shard, side by
@@ -788,16 +799,16 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
     static const size_t wgs_per_cu = [] {
         const char *e = getenv("RSBWT_EXTRACT_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return (size_t)(v > 0 && v <= 8 ? v : 4);
+        return (size_t)(v > 0 && v <= 20 ? v : RSB_WALK_MIN_WGS);
     }();
     const size_t cap = (size_t)num_cus * wgs_per_cu;
     if (g > cap) g = cap;
     if (g >= nshards) g -= g % nshards;  // (every shard starts with as many workgroups as any other)
     if (d_work)
-        hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
     else
-        hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+        hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
     // (the row buffers of the shards lie back to back: one launch moves every prefix)
     if ((stride & 15u) == 0u && ((uintptr_t)d_out & 15u) == 0u)
@@ -807,11 +818,11 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
         hipLaunchKernelGGL(move_prefix_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
                            (const uint32_t *)d_plen, total);
     if (d_work)
-        hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
                            pool + nshards, d_work + XW_WORDS);
     else
-        hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards,
+        hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
                            pool + nshards, d_work + XW_WORDS);
     e = hipGetLastError();

@@ -100,13 +100,19 @@ struct dev_group : search_meter {
     hipEvent_t fork_ev = nullptr, join_ev[FORK] = {};
     std::mutex fork_mu;
     int ensure_fork() {
-        if (fork_ev) return RSBWT_OK;
+        if (fork_ev) return RSBWT_OK;  // (set last: everything below exists)
+        // each stream / event is made once, whatever a previous, partly failed attempt left behind
         for (int i = 0; i < FORK; ++i) {
-            if (hipStreamCreateWithFlags(&fork_st[i], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming) != hipSuccess)
+            if ((!fork_st[i] && hipStreamCreateWithFlags(&fork_st[i], hipStreamNonBlocking) != hipSuccess) ||
+                (!join_ev[i] && hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming) != hipSuccess)) {
+                (void)hipGetLastError();
                 return fail(RSBWT_EHIP, "cannot create the side streams of a shard set");
+            }
         }
-        if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return fail(RSBWT_EHIP, "cannot create an event");
+        if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) {
+            fork_ev = nullptr;
+            return fail(RSBWT_EHIP, "cannot create an event");
+        }
         return RSBWT_OK;
     }
 };
@@ -948,13 +954,16 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     std::lock_guard<std::mutex> lock(g->fork_mu);  // one fork / join sequence at a time uses the side streams' events
     if ((rc = g->ensure_fork()) != RSBWT_OK) return rc;
     HIP_OK(hipEventRecord(g->fork_ev, (hipStream_t)stream));  // (behind the variants)
-    for (size_t i = 0; i < S; ++i) {
+    // (a failure inside the loop leaves it through `rc`, never by returning: what was already enqueued on the side
+    // streams reads and writes the caller's buffers and is joined below before the caller's stream goes on)
+    auto hip_rc = [](hipError_t e, const char *what) { return e == hipSuccess ? RSBWT_OK : fail_hip(e, what); };
+    for (size_t i = 0; i < S && rc == RSBWT_OK; ++i) {
         hipStream_t st = g->fork_st[i % dev_group::FORK];
-        HIP_OK(hipStreamWaitEvent(st, g->fork_ev, 0));
+        if ((rc = hip_rc(hipStreamWaitEvent(st, g->fork_ev, 0), "hipStreamWaitEvent")) != RSBWT_OK) break;
         if ((rc = one_shard(i, d_slots + (i % dev_group::FORK) * one, st)) != RSBWT_OK) break;
         if (i + dev_group::FORK >= S) {  // the last shard of each side stream: its event joins the caller's stream
-            HIP_OK(hipEventRecord(g->join_ev[i % dev_group::FORK], st));
-            HIP_OK(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0));
+            if ((rc = hip_rc(hipEventRecord(g->join_ev[i % dev_group::FORK], st), "hipEventRecord")) != RSBWT_OK) break;
+            rc = hip_rc(hipStreamWaitEvent((hipStream_t)stream, g->join_ev[i % dev_group::FORK], 0), "hipStreamWaitEvent");
         }
     }
     if (rc) {  // whatever was enqueued still finishes before the caller's stream goes on
@@ -966,8 +975,9 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
 }
 
 // d_rows: [num_shards][n] SA rows (row numbers are per shard); d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n].
-// The shards' walks run side by side on streams of the set (forked from and joined to `stream`): a walk kernel ends in
-// a tail -- the last rows of a launch are its longest reads -- that another shard's rows fill.
+// ONE launch sequence walks the rows of all the shards (extract_lines.hip): a walk kernel ends in a tail as long as its
+// longest walk, and a launch per shard -- round 3: side by side on streams of the set -- has a tail per shard and a
+// fraction of the rows per lane.
 int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_out, uint32_t stride, void *d_len,
                           void *d_prefix_len, void *stream) {
     if (!s) return fail(RSBWT_EINVAL, "null set");

@@ -89,3 +89,25 @@ def test_header_is_plain_c(tmp_path):
         r = subprocess.run([cc, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-x", "c" if cc == "gcc" else "c++",
                             f"-I{os.path.join(root, 'include')}", "-fsyntax-only", str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_context_pool_does_not_hang_when_streams_cannot_be_made(tmp_path):
+    """readserver_amd/csrc/ctx_pool.h (the per-call contexts of a handle: a stream pair each) with a maker that fails,
+    on the CPU under -fsanitize=thread: every caller is refused or served, nobody waits for a release that cannot
+    come (two callers failing at once; a release that happens while a caller is inside its failing maker), and the
+    pool never holds more than its bound (tests/native/ctx_pool_test.cpp)."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ctx_pool_test")
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", os.path.join(root, "tests", "native", "ctx_pool_test.cpp"),
+                        "-lpthread", "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("no sanitizer runtime here")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "ctx_pool ok" in r.stdout, r.stdout + r.stderr[-3000:]

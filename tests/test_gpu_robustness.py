@@ -16,6 +16,7 @@ import oracle_binding as ob
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RSBWT_ENABLE_TEST_HOOKS"] = "1"  # rsbwt_debug_poke writes into a resident index: refused without it
 
 
 def _random_runs(rng, R, with_dollar=True):

@@ -57,9 +57,10 @@ while time.time() < t_end:
     k = int(rng.integers(1, 71)) if rng.random() < 0.5 else 31
     oix = orc.from_runs(runs)
     n = oix.bwlen()
-    cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n)}
+    reads_layout = bool(rng.random() < 0.4)  # RSBWT_OPEN_READS: a psi hint slot in every window line, sparse select samples
+    cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n), "for_reads": reads_layout}
     try:
-        with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span) as g:
+        with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span, for_reads=reads_layout) as g:
             Q = 300000 if rng.random() < 0.1 else 20000  # the larger batch takes the one-lane-per-search kernel on a deep table
             cfg["Q"] = Q
             km = acgt[rng.integers(0, 4, (Q, k))].copy()
@@ -89,7 +90,7 @@ while time.time() < t_end:
                 oix2 = orc.from_runs(runs2)
                 # (a second shard with the first one's table depth: the set then searches both in one traced and one
                 # resumed launch, csrc/sets.hip set_hits_1mm_fused)
-                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))]) as g2:
+                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))], for_reads=bool(rng.random() < 0.5)) as g2:
                     ss = rsb.ShardSet([g, g2])
                     slo, sup = ss.find_intervals(km[:5000])
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
@@ -119,6 +120,26 @@ while time.time() < t_end:
                             rec = d_h[si, :int(d_t[si].item())].cpu().numpy().view(np.uint64)
                             ok2 = ok2 and rec.shape[0] == len(mine) and np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
                             ok2 = ok2 and np.array_equal(rec[:, 2] // (3 * k + 1), mine["query"].astype(np.uint64))
+                    # read extraction over the set, device-resident: ONE launch sequence walks the rows of both shards
+                    # (csrc/extract_lines.hip), against each shard's own host call
+                    import torch
+                    p_ = lambda t: C.c_void_p(t.data_ptr())
+                    nr_ = 300
+                    n2 = oix2.bwlen()
+                    rws = np.stack([rng.integers(0, n + 3, nr_), rng.integers(0, n2 + 3, nr_)]).astype(np.uint64)  # (a few past the end)
+                    d_rw = torch.from_numpy(rws.view(np.int64)).cuda()
+                    d_o = torch.zeros((2, nr_, 512), dtype=torch.uint8, device="cuda")
+                    d_l = torch.empty((2, nr_), dtype=torch.int32, device="cuda")
+                    d_p = torch.empty((2, nr_), dtype=torch.int32, device="cuda")
+                    assert L.rsbwt_set_extract_dev(ss._s, p_(d_rw), nr_, p_(d_o), 512, p_(d_l), p_(d_p), None) == 0
+                    torch.cuda.synchronize()
+                    for si, gg in enumerate((g, g2)):
+                        o1 = np.zeros((nr_, 512), np.uint8)
+                        l1, p1 = np.empty(nr_, np.uint32), np.empty(nr_, np.uint32)
+                        assert L.rsbwt_extract(gg.handle, rws[si].ctypes.data, nr_, o1.ctypes.data, 512, l1.ctypes.data, p1.ctypes.data) == 0
+                        gl, gp, go = d_l[si].cpu().numpy().view(np.uint32), d_p[si].cpu().numpy().view(np.uint32), d_o[si].cpu().numpy()
+                        ok2 = ok2 and np.array_equal(gl, l1) and np.array_equal(gp[l1 != 0xFFFFFFFF], p1[l1 != 0xFFFFFFFF])
+                        ok2 = ok2 and all(np.array_equal(go[i, :l1[i]], o1[i, :l1[i]]) for i in range(nr_) if l1[i] != 0xFFFFFFFF)
                     # query() in every shard, lists concatenated per k-mer -- for k-mers whose intervals are narrow in
                     # both shards (every row of an interval is extracted into a 2 KB buffer: a 1-mer's would be gigabytes)
                     w1 = np.where(eup[:5000] >= elo[:5000], eup[:5000] - elo[:5000] + 1, 0)

@@ -28,7 +28,7 @@ shards = []
 for s in range(2):
     runs = np.empty(R, np.uint8)
     assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 31337 + s) == 0
-    shards.append(rsb.GpuBWT(runs=runs))
+    shards.append(rsb.GpuBWT(runs=runs, for_reads=(s == 1)))  # (one plain shard, one laid out for reads)
     del runs
 sset = rsb.ShardSet(shards)
 g = shards[0]
@@ -67,6 +67,19 @@ torch.cuda.synchronize()
 ref_hits = [_h[si, :int(_t[si].item())].cpu().numpy().view(np.uint64) for si in range(2)]
 fused_1mm = int(L.rsbwt_set_hits_1mm_is_fused(sset._s, 500, k))
 del _h, _t, _s
+# the set's device-resident extraction (ONE launch sequence walks both shards: csrc/extract_lines.hip): 4000 rows of each
+n_min = min(int(x.getBWLen()) for x in shards)
+rows2 = np.stack([rng.integers(0, n_min, 4000), rng.integers(0, n_min, 4000)]).astype(np.uint64)
+d_rows2 = torch.from_numpy(rows2.view(np.int64)).to(DEV)
+_o = torch.zeros((2, 4000, 512), dtype=torch.uint8, device=DEV)
+_l = torch.empty((2, 4000), dtype=torch.int32, device=DEV)
+_pl = torch.empty((2, 4000), dtype=torch.int32, device=DEV)
+assert L.rsbwt_set_extract_dev(sset._s, ptr(d_rows2), 4000, ptr(_o), 512, ptr(_l), ptr(_pl), None) == 0
+torch.cuda.synchronize()
+ref_x_len = _l.cpu().numpy().view(np.uint32).copy()
+_keep = (torch.arange(512, device=DEV)[None, None, :] < _l.clamp(min=0)[..., None])
+ref_x_out = (_o * _keep).cpu().numpy()
+del _o, _l, _pl, _keep
 
 stats = {}
 errors = []
@@ -91,7 +104,7 @@ def worker(seed):
     w_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(sset._s, 500, k), dtype=torch.uint8, device=DEV)
     try:
         while time.time() < stop_at:
-            op = int(r.integers(0, 7))
+            op = int(r.integers(0, 8))
             size = int(2 ** r.uniform(0, 15.5))
             a = int(r.integers(0, POOL - size))
             t0 = time.perf_counter()
@@ -120,6 +133,20 @@ def worker(seed):
                 fits = l1 != 0xFFFFFFFF
                 ok = ok and all(np.array_equal(o[i, :l1[i]], ref_out[b + i, :l1[i]]) for i in np.nonzero(fits)[0][:200])
                 kind = "extract"
+            elif op == 7:
+                m = min(size, 2000)
+                b = int(r.integers(0, 4000 - m))
+                with torch.cuda.stream(st):
+                    x_r = d_rows2[:, b:b + m].contiguous()
+                    x_o = torch.zeros((2, m, 512), dtype=torch.uint8, device=DEV)
+                    x_l = torch.empty((2, m), dtype=torch.int32, device=DEV)
+                    x_p = torch.empty((2, m), dtype=torch.int32, device=DEV)
+                    rc = L.rsbwt_set_extract_dev(sset._s, ptr(x_r), m, ptr(x_o), 512, ptr(x_l), ptr(x_p), sp)
+                    keep = (torch.arange(512, device=DEV)[None, None, :] < x_l.clamp(min=0)[..., None])
+                    got_o = (x_o * keep).cpu().numpy()
+                st.synchronize()
+                ok = rc == 0 and np.array_equal(x_l.cpu().numpy().view(np.uint32), ref_x_len[:, b:b + m]) and np.array_equal(got_o, ref_x_out[:, b:b + m])
+                kind = "set_extract_dev"
             elif op == 6:
                 m = min(size, 500)
                 b = int(r.integers(0, 2000 - m))
