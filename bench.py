@@ -79,6 +79,15 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
     ap.add_argument("--window-span", type=int, default=0, help="symbols per window line (0 = from the data)")
+    ap.add_argument("--ref-out-of-cache-runs", type=float, default=2e9,
+                    help="run bytes of the index the compiled reference is timed on OUT OF CACHE beside the port (cpu_baseline.reference_beside_port.out_of_cache; 0 = skip)")
+    ap.add_argument("--host", choices=["ranks", "cxx"], default="ranks",
+                    help="ranks = one process per GPU over torch.distributed / RCCL (the driver's launch shape); cxx = the C++ host's "
+                         "shape: ONE process drives all --gpus devices (a fused launch per device on a stream of its own, the 10-byte "
+                         "records gathered onto device 0 by rsbwt_set_gather_intervals_dev: ncclSend / ncclRecv), no launcher.  An "
+                         "N > 1 run of the default host adds this as a second leg (config.cxx_host) unless --no-cxx-leg")
+    ap.add_argument("--no-cxx-leg", action="store_true", help="N > 1: skip the one-process (C++ host) leg after the per-rank one")
+    ap.add_argument("--cxx-leg-timeout", type=float, default=420.0, help="seconds the second leg may take before it is given up")
     ap.add_argument("--layout", choices=["auto", "plain", "reads"], default="auto",
                     help="reads = RSBWT_OPEN_READS: a psi hint in every window line, built with the index (~9 %% more lines): "
                          "what a shard that serves read extraction is opened with; auto = reads for --mode extract, plain otherwise")
@@ -581,8 +590,20 @@ MIX_NOTE = {
 }
 
 
+def cxx_leg_cmd(a):
+    """The command of the second leg of an N > 1 run: this script as the one-process host over the same devices."""
+    return [sys.executable, os.path.abspath(__file__), "--host", "cxx", "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
+            "--runs", str(a.runs), "--queries", str(a.queries), "--k", str(a.k), "--shards-per-gpu", str(a.shards_per_gpu),
+            "--stream", a.stream, "--mix", a.mix, "--seed", str(a.seed), "--ktab-depth", str(a.ktab_depth), "--window-span", str(a.window_span)]
+
+
 def main():
     a = parse()
+    if a.host == "cxx":
+        if a.mode != "exact":
+            raise SystemExit("bench.py --host cxx: the exact search (configs[1] / configs[2])")
+        print(json.dumps(run_exact_cxx(a)), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a, sys.argv[1:])
     c = setup(a)
@@ -671,6 +692,21 @@ def main():
         }
         if "shards_matching_oracle" in head:
             out["config"]["shards_matching_oracle"] = head["shards_matching_oracle"]
+        if world > 1 and not a.no_cxx_leg and not a.rehearse_on_one_gpu:
+            # second leg: the same workload driven by ONE process over all the GPUs (the C++ host's shape).  Every rank has
+            # closed its shards; rank 0 starts the leg as a child with a time limit and the others wait -- whatever happens
+            # to it, the line above stands.
+            c.torch.cuda.synchronize()
+            c.dist.barrier()
+            if c.rank == 0:
+                import subprocess
+                try:
+                    r = subprocess.run(cxx_leg_cmd(a), capture_output=True, text=True, timeout=a.cxx_leg_timeout)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    out["config"]["cxx_host"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-800:]}
+                except Exception as e:  # noqa: BLE001
+                    out["config"]["cxx_host"] = {"error": repr(e)}
+            c.dist.barrier()
     if c.rank == 0:
         print(json.dumps(out), flush=True)
     if c.world > 1:
@@ -1016,6 +1052,8 @@ def cpu_baseline(a, host_runs, d_kmers, d_lower, d_upper, Q, k):
     dt = time.perf_counter() - t0
     match = bool(np.array_equal(lo, glo) and np.array_equal(up, gup))
     ref = reference_beside_port(threads)
+    if isinstance(ref, dict) and "error" not in ref and a.ref_out_of_cache_runs > 0:
+        ref["out_of_cache"] = reference_out_of_cache(a, threads, d_kmers.device)
     return {
         "value": m / dt, "unit": "queries/s", "cores": threads, "kind": "port",
         "sample": f"{m} of the batch's {Q} k-mers (evenly spaced) on shard 0 (one of the resident shards: per-shard "
@@ -1072,6 +1110,221 @@ def reference_beside_port(threads):
         return out
     except Exception as e:  # the checker's checker must not take the bench line down
         return {"error": repr(e)}
+
+
+def run_exact_cxx(a):
+    """--host cxx: configs[1] / configs[2] driven by ONE process over --gpus devices (readserver_amd/onehost.py: the
+    sequence of C-ABI calls the C++ host makes per batch).  Same workload, same batch, same step definition as the
+    per-rank host; one JSON line."""
+    import threading
+    import torch
+    import readserver_amd as rsb
+    from readserver_amd import onehost
+    L = rsb.lib()
+    G, S, R, Q, k = a.gpus, a.shards_per_gpu, int(a.runs), int(a.queries), a.k
+    if not torch.cuda.is_available() or torch.cuda.device_count() < G:
+        raise SystemExit(f"bench.py --host cxx --gpus {G}: {torch.cuda.device_count() if torch.cuda.is_available() else 0} device(s) visible")
+    t0 = time.time()
+    by_dev = [[None] * S for _ in range(G)]
+    errs = []
+
+    def build(g):  # a device's shards, one after the other; the devices side by side (a host thread each)
+        try:
+            dev = torch.device("cuda", g)
+            with torch.cuda.device(dev):
+                sp_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for s_ in range(S):
+                    d_runs = torch.empty(R, dtype=torch.uint8, device=dev)
+                    if L.rsbwt_synth_runs_dev(ptr(d_runs), R, shard_seed(a, a.mix, g, S, s_), g, sp_) != 0:
+                        raise RuntimeError(L.rsbwt_last_error().decode())
+                    torch.cuda.synchronize(dev)
+                    by_dev[g][s_] = rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R), device=g,
+                                               ktab_depth=(a.ktab_depth if a.ktab_depth > 0 else None), window_span=a.window_span)
+                    del d_runs
+                    torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=build, args=(g,)) for g in range(G)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise SystemExit("bench.py --host cxx: " + errs[0])
+    host = onehost.OneProcessHost(by_dev, Q, k)
+    if a.ktab_depth == 0:  # one depth for the whole job, out of the HBM that is free now that every buffer exists
+        n_sym = by_dev[0][0].getBWLen()
+        T = host.auto_table_depth()
+        free_b = min(torch.cuda.mem_get_info(g)[0] for g in range(G))
+        while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
+            T += 1
+        if T >= 2:
+            host.attach_tables(T)
+    t_build = time.time() - t0
+    # the batch (device 0), then a copy on every device
+    ctx0 = Ctx()
+    ctx0.torch, ctx0.dist, ctx0.L, ctx0.rsb = torch, None, L, rsb
+    ctx0.rank, ctx0.world, ctx0.local = 0, 1, 0
+    ctx0.dev = ctx0.cdev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx0.stream = torch.cuda.current_stream()
+    ctx0.sp = C.c_void_p(ctx0.stream.cuda_stream)
+    d_km0 = torch.empty((Q, k), dtype=torch.uint8, device=ctx0.dev)
+    if a.mix == "population":
+        make_batch(a, ctx0, by_dev[0], a.mix, Q, k, d_km0)
+    else:  # (every device's shards are their own streams: present k-mers drawn from device 0's, as rank 0's share would be)
+        make_batch(a, ctx0, by_dev[0], "population", Q, k, d_km0)
+    torch.cuda.synchronize()
+    d_km = [d_km0 if g == 0 else d_km0.to(torch.device("cuda", g)) for g in range(G)]
+    # exact work of one step on device 0 (counting mode, untimed)
+    ok(ctx0, L.rsbwt_set_set_counting(host.subsets[0]._s, 1))
+    host.step(d_km)
+    host.synchronize()
+    w = (C.c_uint64 * 16)()
+    ok(ctx0, L.rsbwt_set_last_search_counters(host.subsets[0]._s, w))
+    ok(ctx0, L.rsbwt_set_set_counting(host.subsets[0]._s, 0))
+    for _ in range(a.warmup):
+        host.step(d_km)
+    host.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        host.step(d_km)
+    host.synchronize()
+    dt = time.perf_counter() - t1
+    buf = (C.c_float * 64)()
+    cnt = C.c_size_t()
+    ok(ctx0, L.rsbwt_set_search_history_ms(host.subsets[0]._s, buf, min(a.steps, 64), C.byref(cnt)))
+    k_ms = float(np.mean(list(buf[:cnt.value]))) if cnt.value else float("nan")
+    verified = host.verify_last_gather()
+    lf, oc, ln, kt = w[0], w[1], w[2], w[3]
+    alg = ln * LINE_BYTES + S * Q * 40
+    ms = dt / a.steps * 1e3
+    out = {
+        "metric": "31-mer backward-search queries/sec on popBWT", "value": G * S * Q / (dt / a.steps), "unit": "searches/s",
+        "queries_per_s": Q / (dt / a.steps), "n_gpus": G, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": f"configs[2]: {G * S} of 64 suffix-shards over {G} GPU(s), {S} per GPU, exact match, one fused launch per GPU and batch"
+                        + (", interval records gathered onto device 0 over RCCL (ncclSend / ncclRecv)" if G > 1 else " (one GPU: no gather)"),
+            "host": "cxx: ONE process drives every device through the C-ABI (rsbwt_pack_kmers_dev, rsbwt_set_find_interval_pairs_dev, "
+                    "rsbwt_pack_interval_pairs_dev on a stream per device; rsbwt_set_gather_intervals_dev on a second one, batch i "
+                    "travelling while batch i + 1 is searched): readserver_amd/onehost.py, csrc/sets.hip",
+            "mix": a.mix, "shards_per_gpu": S, "shards": G * S, "run_bytes_per_shard": R, "queries_per_batch": Q, "k": k,
+            "ktab_depth": by_dev[0][0].ktab_depth(), "window_span": by_dev[0][0].window_span(), "index_build_s": round(t_build, 2),
+            "mean_lf_steps_per_search": lf / max(S * Q, 1), "gather_verified": verified,
+            "gathered_as": None if G == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact",
+            "multi_gpu": "measured" if G > 1 else "one GPU",
+        },
+        "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "search_lines_kernel (device 0's launches)",
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": ln, "occ_lookups_per_launch": oc,
+                     "ktab_starts_per_launch": kt,
+                     "frac_of_step": (alg + Q * (k + 8 * ((k + 31) // 32) + 1) + S * Q * 24) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "cpu_baseline": None,
+    }
+    host.close()
+    for sh in by_dev:
+        for g_ in sh:
+            g_.close()
+    return out
+
+
+def reference_out_of_cache(a, threads, dev):
+    """The REAL reference (oracle/_ref/libref_bwt.so) beside the port in the regime the headline runs in: an index
+    that fits no cache.  A run stream of the bench's kind (--ref-out-of-cache-runs run bytes, 2e9: 1.2e10 symbols) is
+    written to local disk as an SGA .bwt (src/bwt/rlebwt_reader.cpp:27-48), checked for the two conditions under
+    which the reference is sound (tests/golden/make_golden.py's: D1 the last 65,536-symbol window lies inside
+    one 2^20-run bucket, D2 n does not reach a multiple of 65,536 inside the last run), opened by the reference's own
+    RLEBWT(filename) and by the port; 1e6 DISTINCT 31-mers -- half drawn from the index by LF walks on the GPU (all 30
+    steps), half random -- are searched by both on all usable threads, a tenth of them on one thread first, and the
+    answers must agree.  Here the reference's ~6-7 dependent DRAM misses per Occ (BPTree::rank's levels,
+    include/bwt/BPTree.h:69-129) show; the cache-resident fixture above hides them."""
+    import ctypes as C
+    import tempfile
+    import torch
+    import oracle_binding
+    import readserver_amd as rsb
+    L = rsb.lib()
+    out = {}
+    try:
+        R2 = int(a.ref_out_of_cache_runs)
+        seed = STREAM_STYLE[a.stream] | (a.seed * 1000003 + 424242)
+        d_runs = torch.empty(R2, dtype=torch.uint8, device=dev)
+        assert L.rsbwt_synth_runs_dev(ptr(d_runs), R2, seed, dev.index or 0, None) == 0
+        torch.cuda.synchronize()
+        tail = (d_runs[-400000:] & 31).cpu().numpy().astype(np.int64)
+        n_all = int((d_runs & 31).sum(dtype=torch.int64).item())
+        # drop trailing runs until D2 holds, then see that D1 does
+        drop = 0
+        while drop < 1000:
+            n2, last = n_all - int(tail[tail.size - drop:].sum()), int(tail[tail.size - 1 - drop])
+            if n2 // 65536 == (n2 - last) // 65536:
+                break
+            drop += 1
+        R2 -= drop
+        n2 = n_all - int(tail[tail.size - drop:].sum())
+        back = np.cumsum(tail[:tail.size - drop][::-1])
+        runs_in_last_window = int(np.searchsorted(back, n2 - ((n2 - 1) // 65536) * 65536, side="left")) + 1
+        d1 = ((R2 - runs_in_last_window) >> 20) == ((R2 - 1) >> 20)
+        out.update({"run_bytes": R2, "symbols": n2, "sound_for_the_reference": {"D1_last_window_in_one_2^20_run_bucket": bool(d1), "D2_no_65536_multiple_inside_the_last_run": True}})
+        if not d1:
+            out["error"] = "the last window straddles a 2^20-run bucket: the reference is unsound on this stream (SURVEY 8c)"
+            return out
+        Q, k = 1_000_000, 31
+        gen = torch.Generator(device=dev).manual_seed(a.seed + 4711)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        d_km = lut[torch.randint(0, 4, (Q, k), generator=gen, device=dev, dtype=torch.uint8).long()]
+        present = 0
+        try:  # half of them drawn from the index (needs ~5 GB of HBM for a moment)
+            with rsb.GpuBWT(device_runs=(d_runs.data_ptr(), R2), device=dev.index or 0, ktab_depth=None) as g2:
+                d_p = torch.empty((Q // 2, k), dtype=torch.uint8, device=dev)
+                assert L.rsbwt_sample_present_kmers_dev(g2.handle, Q // 2, k, k, a.seed + 99, ptr(d_p), None) == 0
+                torch.cuda.synchronize()
+                d_km[::2] = d_p
+                present = Q // 2
+        except Exception as e:  # noqa: BLE001  (HBM is full of shards: random k-mers only)
+            out["present_kmers_skipped"] = repr(e)
+        km = np.unique(d_km.cpu().numpy(), axis=0)  # distinct
+        km = km[np.random.default_rng(a.seed).permutation(km.shape[0])]
+        Q = km.shape[0]
+        host = d_runs[:R2].cpu().numpy()
+        del d_runs
+        torch.cuda.empty_cache()
+        R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_bwt.so"))
+        R.ref_open.restype = C.c_void_p
+        R.ref_open.argtypes = [C.c_char_p]
+        R.ref_close.argtypes = [C.c_void_p]
+        R.ref_find_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "out_of_cache.bwt")
+            with open(path, "wb") as f:  # the 30-byte SGA header + the run bytes (rlebwt_reader.cpp:27-48)
+                f.write((0xCACA).to_bytes(2, "little") + (0).to_bytes(8, "little") + n2.to_bytes(8, "little") + R2.to_bytes(8, "little") + (0).to_bytes(4, "little"))
+                f.write(memoryview(host))
+            del host
+            t0 = time.perf_counter()
+            h = R.ref_open(path.encode())
+            out["reference_open_s"] = round(time.perf_counter() - t0, 2)
+            t0 = time.perf_counter()
+            oix = oracle_binding.load().load(path)
+            out["port_open_s"] = round(time.perf_counter() - t0, 2)
+        out["kmers"] = {"distinct": Q, "drawn_from_the_index": present}
+        lo, up = np.empty(Q, np.uint64), np.empty(Q, np.uint64)
+        for t, m in ((1, Q // 10), (threads, Q)):
+            sub = np.ascontiguousarray(km[:m] if t != 1 else km[Q - m:])  # (the one-thread run on k-mers nobody has searched yet)
+            t0 = time.perf_counter()
+            R.ref_find_intervals(h, sub.ctypes.data, m, k, k, lo.ctypes.data, up.ctypes.data, t)
+            tr = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            olo, oup = oix.find_intervals(sub, nthreads=t)
+            to = time.perf_counter() - t0
+            out["%d_threads" % t] = {"kmers": m, "reference_queries_per_s": m / tr, "port_queries_per_s": m / to, "reference_over_port": to / tr,
+                                     "same_answers": bool(np.array_equal(lo[:m], olo) and np.array_equal(up[:m], oup))}
+        R.ref_close(h)
+        oix.close()
+        return out
+    except Exception as e:  # the checker's checker must not take the bench line down
+        out["error"] = repr(e)
+        return out
 
 
 if __name__ == "__main__":

@@ -71,3 +71,25 @@ def test_inside_a_launcher_it_does_not_launch_again():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and "launching" not in out.stderr
+
+
+def test_cxx_host_is_one_process_and_the_second_leg_of_an_n_gpu_run(monkeypatch):
+    """`--host cxx` is the C++ host's shape: ONE process over all --gpus devices, so it must NOT start ranks; and an
+    N > 1 run of the default host re-runs the same workload under it as a second leg (config.cxx_host), started by
+    rank 0 as a child with the run's own sizes."""
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--host", "cxx", "--gpus", "4", "--runs", "3e8", "--queries", "2e5", "--steps", "3"])
+    a = b.parse()
+    assert a.host == "cxx" and a.gpus == 4
+    launched, ran = [], []
+    monkeypatch.setattr(b, "self_launch", lambda *x: launched.append(x))
+    monkeypatch.setattr(b, "run_exact_cxx", lambda a_: ran.append(a_) or {"ok": True})
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    b.main()
+    assert ran and not launched  # no torch.distributed.run, no ranks
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2", "--runs", "2e10", "--queries", "1e7"])
+    cmd = b.cxx_leg_cmd(b.parse())
+    assert cmd[:2] == [sys.executable, os.path.join(ROOT, "bench.py")]
+    for flag, val in (("--host", "cxx"), ("--gpus", "8"), ("--steps", "7"), ("--warmup", "2"), ("--shards-per-gpu", "8"), ("--mix", "population")):
+        assert cmd[cmd.index(flag) + 1] == val
+    assert float(cmd[cmd.index("--runs") + 1]) == 2e10 and float(cmd[cmd.index("--queries") + 1]) == 1e7

@@ -570,3 +570,48 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
     ss.close()
     for g in shards:
         g.close()
+
+
+@pytest.mark.parametrize("devices", [1, 2])
+def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices):
+    """readserver_amd/onehost.py -- the C++ host's shape, what `bench.py --host cxx` times: per device pack + ONE fused
+    launch over its shards + 10-byte records on a stream of its own, the records gathered onto the first device by
+    rsbwt_set_gather_intervals_dev (ncclSend / ncclRecv) on a second stream, double-buffered.  Every device's pairs
+    against the oracle; with two devices the root's blocks against what the devices searched (skipped on a one-GPU box:
+    RCCL needs distinct devices)."""
+    import torch
+    from readserver_amd import onehost
+    if torch.cuda.device_count() < devices:
+        pytest.skip(f"{devices} GPUs needed")
+    L = rsb.lib()
+    rng = np.random.default_rng(11)
+    Q, k = 30000, 31
+    by_dev, oixs = [], []
+    for d in range(devices):
+        sh = []
+        for i in range(3):
+            R = [150000, 40000, 260000][i]
+            runs = np.empty(R, np.uint8)
+            assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, (1 << 62) | (77 + 10 * d + i)) == 0
+            sh.append(rsb.GpuBWT(runs=runs, device=d, ktab_depth=None))
+            oixs.append(oracle.from_runs(runs))
+        by_dev.append(sh)
+    host = onehost.OneProcessHost(by_dev, Q, k)
+    host.attach_tables(6)
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (Q, k))].copy()
+    km[::3, :20] = km[0, :20]  # (some shared prefixes)
+    d_km = [torch.from_numpy(km).to(torch.device("cuda", d)) for d in range(devices)]
+    for _ in range(5):  # (past the double buffers)
+        host.step(d_km)
+    host.synchronize()
+    for d in range(devices):
+        pr = host.last_pairs(d).cpu().numpy().view(np.uint64)
+        for i in range(3):
+            elo, eup = oixs[3 * d + i].find_intervals(km, nthreads=4)
+            assert np.array_equal(pr[i, :, 0], elo) and np.array_equal(pr[i, :, 1], eup), (d, i)
+    ok = host.verify_last_gather()
+    assert ok is None if devices == 1 else ok is True
+    host.close()
+    for sh in by_dev:
+        for g in sh:
+            g.close()
