@@ -62,6 +62,9 @@ def parse():
                     help="third leg of a one-GPU run: the same search on a VALID population BWT built on the GPU (tools/popbwt_bench.py), "
                          "this many symbols per shard before dedup (8 shards); 0 = skip; default: 3e9 (1.7e10 symbols in all, ~80 s to "
                          "build) on a full-size run, skipped when --runs is below 1e10")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="N = 1: batches alternate between two streams (buffers of their own), so that batch i + 1's packing, start "
+                         "records and ramp run under batch i's tail -- what two of a service's pool threads calling the handle do")
     ap.add_argument("--piped-start", action="store_true",
                     help="prepare batch i + 1 (packing, start records) on a second stream while batch i is searched, instead of "
                          "pack, start records and search one after the other on one stream (measured slower on the headline mix)")
@@ -376,6 +379,11 @@ def run_exact(a, c, mix, steps, warmup, headline):
         prep_done = [torch.cuda.Event(), torch.cuda.Event()]
         searched = [torch.cuda.Event(), torch.cuda.Event()]
         prepared_for = [None, None]
+    two = a.two_streams and world == 1 and not piped and not (a.counts or a.separate_arrays)
+    if two:
+        two_st = [c.stream, torch.cuda.Stream(device=dev)]
+        two_pk = [d_packed, torch.empty_like(d_packed)]
+        two_ok = [d_valid, torch.empty_like(d_valid)]
     size_tables(a, c, sset, shards, S)
     t_build = time.time() - t_build0
     make_batch(a, c, shards, mix, Q, k, d_kmers)
@@ -420,6 +428,13 @@ def run_exact(a, c, mix, steps, warmup, headline):
             if host_pair is not None and not wire_packed:
                 host_pair.copy_(pair)
             gat.submit(i, source=pair if wire_packed else None)
+            return
+        if two:
+            jj = i % 2
+            spj = C.c_void_p(two_st[jj].cuda_stream)
+            ok(c, L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(two_pk[jj]), ptr(two_ok[jj]), local, spj))
+            ok(c, L.rsbwt_set_find_interval_pairs_dev(sset._s, ptr(two_pk[jj]), ptr(two_ok[jj]), Q, k, ptr(pair), spj))
+            gat.submit(i, source=None)
             return
         ok(c, L.rsbwt_pack_kmers_dev(ptr(d_kmers), Q, k, k, ptr(d_packed), ptr(d_valid), local, sp))
         if a.counts:
@@ -550,6 +565,7 @@ def run_exact(a, c, mix, steps, warmup, headline):
         "single_shard_check": single,
         "step": ("search kernel on the main stream; the next batch's packing and start records on a second stream beside it "
                  "(rsbwt_set_prepare_dev / rsbwt_set_find_interval_pairs_prepared_dev)" if piped else
+                 "pack + start records + search, batches alternating between two streams" if two else
                  "pack + start records + search, one after the other on one stream"),
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

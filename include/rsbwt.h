@@ -424,6 +424,13 @@ int rsbwt_zmq_available(void); /* 1 when libzmq could be bound */
 void rsbwt_transport_free(rsbwt_transport_t *t);
 int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_t n); /* in-process only */
 int rsbwt_transport_pop_reply(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us);
+/* The same in bulk (in-process only; one lock per call instead of one per message): `count` Requests, message j =
+ * base[off[j] .. off[j + 1]); up to max_msgs Replies of a channel back to back into buf (message j at off[j] ..
+ * off[j + 1], off has max_msgs + 1 entries; *count = how many, 0 after timeout_us without one; a Reply that does not
+ * fit `cap` any more stays queued). */
+int rsbwt_transport_push_requests(rsbwt_transport_t *t, const uint8_t *base, const uint64_t *off, size_t count);
+int rsbwt_transport_pop_replies(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, uint64_t *off, size_t max_msgs,
+                                size_t *count, int64_t timeout_us);
 void rsbwt_transport_close(rsbwt_transport_t *t); /* the loop ends once what was pushed is answered */
 
 /* The recv loop (service.cpp:1521-1577) with a micro-batch window: the first Request opens a window
@@ -438,6 +445,11 @@ typedef void (*rsbwt_service_other_fn)(void *arg, const uint8_t *request, size_t
 int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch,
                          int per_partition, rsbwt_service_t **out);
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg);
+/* The loop is a pipeline: the thread that runs it receives and cuts the windows, `workers` threads answer a whole
+ * window each (decode, one batched search per query length, Reply bytes -- the set's entry points are re-entrant),
+ * a sender thread sends the windows' Replies in window order, so replies still leave in arrival order.  Default 8,
+ * the threads of the reference's query pool (src/service/service.cpp:88,1505); before rsbwt_service_run / _start. */
+void rsbwt_service_set_workers(rsbwt_service_t *s, int workers);
 int rsbwt_service_run(rsbwt_service_t *s);   /* on the calling thread, until the transport closes */
 int rsbwt_service_start(rsbwt_service_t *s); /* on a thread of its own */
 int rsbwt_service_stop(rsbwt_service_t *s);  /* at once; after rsbwt_transport_close: once all that was pushed is answered */

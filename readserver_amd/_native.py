@@ -122,6 +122,9 @@ SIGNATURES = {
     "rsbwt_transport_pop_reply": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int64]),
     "rsbwt_transport_close": (None, [_vp]),
     "rsbwt_service_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "rsbwt_service_set_workers": (None, [_vp, C.c_int]),
+    "rsbwt_transport_push_requests": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rsbwt_transport_pop_replies": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int64]),
     "rsbwt_service_set_other_handler": (None, [_vp, _vp, _vp]),
     "rsbwt_service_run": (C.c_int, [_vp]),
     "rsbwt_service_start": (C.c_int, [_vp]),

@@ -7,7 +7,7 @@ mkdir -p "$here/lib"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wall -Wno-unused-function \
   -I"$here/../include" \
-  "$src/kernels.hip" "$src/search_lines.hip" "$src/extract_lines.hip" "$src/build_lines.hip" "$src/capi.hip" "$src/sets.hip" "$src/bwt_file.cpp" "$src/bpi2.cpp" "$src/synth.cpp" "$src/service_slice.cpp" "$src/service_loop.cpp" "$src/layout_host.cpp" \
+  "$src/kernels.hip" "$src/search_lines.hip" "$src/extract_lines.hip" "$src/mm1_worklist.hip" "$src/build_lines.hip" "$src/capi.hip" "$src/sets.hip" "$src/bwt_file.cpp" "$src/bpi2.cpp" "$src/synth.cpp" "$src/service_slice.cpp" "$src/service_loop.cpp" "$src/layout_host.cpp" \
   -ldl -lpthread -o "$here/lib/librsbwt.so" "$@"
 # index_rlebwt: the twin of the reference's src/util/index_rlebwt.cpp (writes "<bwt>.bpi2"); host code only
 "${CXX:-g++}" -O2 -std=c++17 -Wall -I"$here/../include" "$src/index_rlebwt_main.cpp" "$src/bpi2.cpp" "$src/bwt_file.cpp" \

@@ -65,6 +65,11 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
 inline bool view_is_narrow(const shard_view &v, uint32_t k) {
     return v.ktab && v.ktab_depth >= 2u && k >= v.ktab_depth && ((v.n >> (2u * v.ktab_depth)) << 2) <= v.sp.S;
 }
+// the worklist launch of a set's 1-mismatch search (kernels.h), metered like search_launch; the counters ACCUMULATE
+// onto what the traced launch and the branch kernel left
+int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_worklists,
+                           const void *d_counts, size_t wl_cap, size_t result_slots, uint32_t k, void *d_sparse, void *d_hit_bits,
+                           hipStream_t stream);
 int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
 // 1-mismatch hit list of one shard from variants expanded once for the whole batch (sets.hip: every shard of a set
 // searches the same variants)

@@ -45,34 +45,6 @@ namespace rsb {
 constexpr int XWG_WAVES = RSB_WALK_WG_WAVES;
 
 
-// the header fields a lane-private parse needs
-struct line_head {
-    uint32_t s1, s2, s3, span, kind;
-};
-__device__ __forceinline__ line_head read_head(const staged_line &L) {
-    const uint4 h0 = L.u4(0);
-    const uint32_t m0 = h0.y >> 8, m1 = h0.w >> 8;
-    line_head h;
-    h.s1 = m0 & 0x3FFu;
-    h.s2 = (m0 >> 10) & 0x7FFu;
-    h.s3 = h.s2 + (m1 & 0x3FFu);
-    h.span = h.s3 + ((m1 >> 10) & 0x3FFu);
-    h.kind = (m1 >> 20) & 3u;
-    return h;
-}
-__device__ __forceinline__ uint64_t read_count(const staged_line &L, uint32_t b) {  // b = 1..4
-    const uint2 cw = L.u2(2u * (b - 1u));
-    return ((uint64_t)(cw.y & 0xFFu) << 32) | cw.x;
-}
-__device__ __forceinline__ uint32_t read_half(const staged_line &L, uint32_t b) {
-    const uint32_t hm = L.dword(5u + 2u * ((b - 1u) >> 1)) >> 8;
-    return (hm >> (11u * ((b - 1u) & 1u))) & 0x7FFu;
-}
-__device__ __forceinline__ uint32_t read_chunk_dword(const staged_line &L) {
-    const uint32_t m2 = L.dword(5) >> 8, m3 = L.dword(7) >> 8;
-    return 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
-}
-
 // Hands rows to the lanes that have none.  A wave draws chunks of ROW_CHUNK consecutive rows from the
 // global counter (one atomic per chunk, not per pass: the atomic's round trip would otherwise sit in
 // front of every pass's line fetch) and gives the next one to whichever lane is free.

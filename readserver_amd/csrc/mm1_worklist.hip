@@ -1,0 +1,329 @@
+// mm1_worklist.hip -- the 1-mismatch search of a shard set as a WORKLIST of live searches (gfx950).
+//
+// BASELINE configs[3]; not in the reference, defined by composition: the result is the exact findInterval
+// (src/bwt/query.cpp:24-41) of every k-mer and of each of its 3k single-substitution variants.  Rounds 2-3 ran every
+// variant as a search of its own, resumed from its k-mer's traced interval where the substitution lies left of the
+// k-mer table's reach.  Measured on 8 x 20 GB shards (T = 14, k = 31): of a k-mer's 94 variant searches per shard the
+// 51 resumed ones live 1.05 steps -- 19 in 20 die on the substituted symbol itself -- and the three substitutions of
+// one position look up the SAME two positions (the traced interval's ends) for three different symbols.  So:
+//
+//   1. the k-mers are searched once, traced (search_lines.hip): trace[s][q][j] = the interval of suffix j+1.. of k-mer q;
+//   2. wl_branch_kernel: one lane per (shard, k-mer, position j < tn) takes the step of ALL THREE substituted symbols
+//      off one fetch of the interval's line(s) -- one line where the old launch read three -- and only the variants
+//      that SURVIVE the step (1 in 20) become searches: a worklist record with their interval after the step;
+//   3. wl_table_kernel: the variants substituted inside the k-mer table's reach start from their own table entry
+//      (findInterval's answer for their last T symbols), one record each, at a slot of their own (no atomics: nearly
+//      every entry is a live interval when 4^T << n);
+//   4. search_solo_kernel<WL> (search_solo.h) runs the worklists: a take-up is one 32-byte record, no start-record
+//      launch, no variants spelled out in memory; results go to the variant's canonical index (sparse results + hit
+//      map), so the ordered hit lists come out of the same compaction as before;
+//   5. wl_own_kernel: the k-mers' own intervals (the traced launch's results) are variant 0's hits.
+//
+// Worklist record (32 B): x = lower (40 bits) | next symbol j << 40 (16 bits) | WL_DEAD << 63;  y = upper;
+//                         z = canonical search index q * (3k+1) + v;  w = the variant's packed word (k <= 32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "line_format.h"
+#include "rank_device.h"
+#include "wave_lines.h"
+
+namespace rsb {
+
+namespace {
+
+constexpr uint64_t WLREC_DEAD = 1ull << 63;
+#define COUNT_WORK_BRANCH(w) ((w) != nullptr)  // (wave-uniform: the counters cost a branch when they are off)
+
+__global__ void wl_init_counts_kernel(unsigned long long *__restrict__ counts, uint32_t nshards, unsigned long long first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nshards) counts[i] = first;
+}
+
+struct wl_rec {
+    ulonglong2 a, b;
+};
+
+__device__ __forceinline__ void wl_store(ulonglong2 *wl, size_t slot, uint64_t lo, uint32_t j, uint64_t hi, uint64_t canon, uint64_t word) {
+    wl[2u * slot] = make_ulonglong2((lo & COUNT_MASK) | ((uint64_t)(j & 0xFFFFu) << COUNT_BITS), hi);
+    wl[2u * slot + 1u] = make_ulonglong2(canon, word);
+}
+
+// ---- 3. the variants substituted inside the table's reach: thread per (k-mer, r = 3 * (position - tn) + alternative,
+// shard), adjacent lanes = the shards of one variant (interleaved k-mer tables: one stretch per variant).  Slot
+// (q * 3T + r) of shard s's worklist; a variant whose entry is empty (or whose k-mer is invalid) leaves a dead record.
+__global__ void __launch_bounds__(256)
+wl_table_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                const uint8_t *__restrict__ valid, size_t m, uint32_t k, uint32_t tn, ulonglong2 *__restrict__ wl, size_t wl_cap,
+                ulonglong2 *__restrict__ sparse, unsigned long long *__restrict__ hit_bits, size_t mv) {
+    const uint32_t T = k - tn, per = 3u * T;
+    const size_t t_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_ >= m * per * nshards) return;
+    const size_t i = t_ / nshards;
+    const uint32_t s = (uint32_t)(t_ - i * nshards);
+    const size_t q = i / per;
+    const uint32_t r = (uint32_t)(i - q * per);
+    const uint32_t p = tn + r / 3u, d = r % 3u;
+    const shard_view &ix = shards[s];
+    ulonglong2 *wl_s = wl + (size_t)s * wl_cap * 2u;
+    const uint64_t V = 3ull * k + 1ull;
+    const uint64_t canon = q * V + 1ull + 3ull * p + d;
+    const uint64_t word = packed[q];
+    const uint32_t orig = (uint32_t)((word >> (2u * p)) & 3u);
+    const uint32_t alt = d < orig ? d : d + 1u;
+    const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * p));
+    bool live = valid[q] != 0;
+    uint64_t lo = 0, hi = 0;
+    uint32_t j = 0;
+    if (live) {
+        const uint64_t code = (vword >> (2u * tn)) & ((1ull << (2u * T)) - 1ull);
+        const uint64_t e = ix.ktab[code * ix.ktab_stride];
+        const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+        if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix.n) {
+            lo = e & COUNT_MASK;
+            hi = lo + width - 1ull;
+            live = width != 0u;
+            j = tn - 1u;  // (tn >= 1: with nothing left of the table's reach this pipeline is not used)
+        } else {  // not tabulated (or not an interval of this BWT): initInterval, query.cpp:18-21
+            const uint32_t b = (uint32_t)((vword >> (2u * (k - 1u))) & 3u) + 1u;
+            lo = ix.C[b];
+            hi = ix.C[b] + ix.total[b] - 1ull;
+            live = ix.total[b] != 0ull;
+            j = k - 2u;
+        }
+    }
+    const size_t slot = q * per + r;
+    if (live) wl_store(wl_s, slot, lo, j, hi, canon, vword);
+    else wl_s[2u * slot] = make_ulonglong2(WLREC_DEAD, 0ull);
+    (void)sparse; (void)hit_bits; (void)mv;
+}
+
+// ---- 5. variant 0 = the k-mer itself: its traced search's result
+__global__ void __launch_bounds__(256)
+wl_own_kernel(const ulonglong2 *__restrict__ own, const uint8_t *__restrict__ valid, uint32_t nshards, size_t m, uint32_t k,
+              ulonglong2 *__restrict__ sparse, unsigned long long *__restrict__ hit_bits, size_t mv) {
+    const size_t t_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_ >= m * nshards) return;
+    const size_t s = t_ / m, q = t_ - s * m;
+    const ulonglong2 o = own[t_];
+    if (valid[q] == 0 || o.x > o.y) return;
+    const size_t canon = q * (3ull * k + 1ull);
+    sparse[s * mv + canon] = o;
+    atomicOr(hit_bits + s * hit_map_words(mv) + (canon >> 6), 1ull << (canon & 63u));
+}
+
+// Occ of symbol b (1..4) up to offset o (1-based, within the line's own pieces: o <= span) of a staged line
+__device__ __forceinline__ uint64_t staged_occ(const staged_line &L, const line_head &h, uint32_t cq, uint32_t start,
+                                               const uint32_t r6[6], uint32_t o, uint32_t b) {
+    const uint32_t hb = read_half(L, b);
+    const uint32_t mq = matched24(L, HDR_DWORDS + 6u * (cq & 2u), b);
+    const char_rank cr = char_rank24(r6, o - start, b);
+    (void)h;
+    return read_count(L, b) + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? mq : 0u) + cr.occ;
+}
+
+// ---- 2. the step of the three substituted symbols at every traced position
+// One lane per (k-mer, position) item of the wave's current shard; items are dealt statically (every item costs the
+// same: one or two line fetches).  Pass A fetches the line of lower - 1 (of upper when lower = 0); pass B the line of
+// upper when that is another one.  A position past its line's own pieces (a spill chunk / far line, ~1.5 % of the
+// lookups) is not chased here: the item's three variants go to the worklist UNSTEPPED and the search kernel takes
+// the step itself, continuation included.
+__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                 const uint8_t *__restrict__ valid, size_t m, uint32_t k, uint32_t tn, const ulonglong2 *__restrict__ trace,
+                 ulonglong2 *__restrict__ wl, size_t wl_cap, unsigned long long *__restrict__ wl_counts,
+                 ulonglong2 *__restrict__ sparse, unsigned long long *__restrict__ hit_bits, size_t mv,
+                 unsigned long long *__restrict__ work) {
+    __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4 *stage = s_stage[wave];
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
+    const staged_line L = {own_stage_row(stage, lane), lane & 7u};
+    const uint64_t V = 3ull * k + 1ull;
+    const size_t items = m * tn;  // per shard (< 2^32: the caller's condition)
+    const uint32_t waves_total = gridDim.x * WG_WAVES, wave_id = blockIdx.x * WG_WAVES + wave;
+    unsigned long long w_lines = 0, w_items = 0, w_surv = 0, w_unstepped = 0;
+    for (uint32_t sid = 0; sid < nshards; ++sid) {
+        const shard_view *sv = shards + sid;
+        const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
+        const uint32_t S = sv->sp.S, nlines = (uint32_t)sv->nlines;
+        const double inv = sv->sp.inv;
+        const uint64_t c1 = sv->C[1], c2 = sv->C[2], c3 = sv->C[3], c4 = sv->C[4];
+        const ulonglong2 *trace_s = trace + (size_t)sid * items;
+        ulonglong2 *wl_s = wl + (size_t)sid * wl_cap * 2u;
+        ulonglong2 *sparse_s = sparse + (size_t)sid * mv;
+        unsigned long long *bits_s = hit_bits + (size_t)sid * hit_map_words(mv);
+        unsigned long long *count = wl_counts + sid;
+        for (size_t t0 = (size_t)wave_id * 64u; t0 < items; t0 += (size_t)waves_total * 64u) {
+            const size_t t = t0 + lane;
+            bool have = t < items;
+            uint32_t q = 0, j = 0;
+            uint64_t lo = 0, hi = 0, word = 0;
+            if (have) {
+                q = (uint32_t)(t / tn);
+                j = (uint32_t)(t - (size_t)q * tn);
+                const ulonglong2 tr = trace_s[t];
+                lo = tr.x;
+                hi = tr.y;
+                // an invalid k-mer's trace was never written; an absent suffix, or the reference's (0, 2^64-1) carry
+                // (query.cpp:35, rlebwt.cpp:269), has no variant that occurs
+                have = valid[q] != 0 && lo <= hi && hi != ~0ull;
+                if (have) word = packed[q];
+            }
+            if (COUNT_WORK_BRANCH(work)) w_items += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
+            // ---- the two positions and their windows
+            uint32_t wL = 0, oL = 0, wU = 0, oU = 0;
+            {
+                uint32_t pin;
+                if (have && lo != 0ull) {
+                    wL = fast_window(lo - 1ull, S, inv, pin);
+                    oL = pin + 1u;
+                }
+                if (have) {
+                    wU = fast_window(hi, S, inv, pin);
+                    oU = pin + 1u;
+                }
+            }
+            const bool needL = have && lo != 0ull;
+            uint64_t occL[4] = {0, 0, 0, 0}, occU[4] = {0, 0, 0, 0};
+            bool gotU = false, spill = false;
+            // ---- pass A: the line of lower - 1 (or, at lower = 0, of upper)
+            {
+                const uint32_t wA = needL ? wL : wU;
+                uint32_t line = wA + (wA >> GROUP_SHIFT);
+                if (line >= nlines) line = 0;
+                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
+                glds_fetch(lines_bytes, have ? line : ~0u, lane, stage_lds);
+                glds_wait();
+                if (have) {
+                    const line_head h = read_head(L);
+                    if (needL) {
+                        if (oL > h.span) spill = true;
+                        else {
+                            const uint32_t cq = (oL > h.s1 ? 1u : 0u) + (oL > h.s2 ? 1u : 0u) + (oL > h.s3 ? 1u : 0u);
+                            const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
+                            uint32_t r6[6];
+                            load24(L, HDR_DWORDS + 6u * cq, r6);
+#pragma unroll
+                            for (uint32_t b = 1; b <= 4u; ++b) occL[b - 1u] = staged_occ(L, h, cq, start, r6, oL, b);
+                        }
+                    }
+                    if (!spill && (!needL || wU == wL)) {  // upper out of the same staged line
+                        if (oU > h.span) spill = true;
+                        else {
+                            const uint32_t cq = (oU > h.s1 ? 1u : 0u) + (oU > h.s2 ? 1u : 0u) + (oU > h.s3 ? 1u : 0u);
+                            const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
+                            uint32_t r6[6];
+                            load24(L, HDR_DWORDS + 6u * cq, r6);
+#pragma unroll
+                            for (uint32_t b = 1; b <= 4u; ++b) occU[b - 1u] = staged_occ(L, h, cq, start, r6, oU, b);
+                            gotU = true;
+                        }
+                    }
+                }
+            }
+            // ---- pass B: the line of upper where it is another one (a wave-uniform skip when nobody needs it)
+            const bool needB = have && !spill && !gotU;
+            if (__builtin_amdgcn_ballot_w64(needB) != 0ull) {
+                uint32_t line = wU + (wU >> GROUP_SHIFT);
+                if (line >= nlines) line = 0;
+                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(needB));
+                glds_fetch(lines_bytes, needB ? line : ~0u, lane, stage_lds);
+                glds_wait();
+                if (needB) {
+                    const line_head h = read_head(L);
+                    if (oU > h.span) spill = true;
+                    else {
+                        const uint32_t cq = (oU > h.s1 ? 1u : 0u) + (oU > h.s2 ? 1u : 0u) + (oU > h.s3 ? 1u : 0u);
+                        const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
+                        uint32_t r6[6];
+                        load24(L, HDR_DWORDS + 6u * cq, r6);
+#pragma unroll
+                        for (uint32_t b = 1; b <= 4u; ++b) occU[b - 1u] = staged_occ(L, h, cq, start, r6, oU, b);
+                    }
+                }
+            }
+            // ---- the three substitutions of position j: updateInterval (query.cpp:11-15) with the substituted symbol
+            const uint32_t orig = (uint32_t)((word >> (2u * j)) & 3u);
+#pragma unroll
+            for (uint32_t d = 0; d < 3u; ++d) {
+                const uint32_t alt = d < orig ? d : d + 1u;  // the d-th base of ACGT without the original one
+                const uint64_t cb = alt == 0u ? c1 : alt == 1u ? c2 : alt == 2u ? c3 : c4;
+                const uint64_t oL_ = alt == 0u ? occL[0] : alt == 1u ? occL[1] : alt == 2u ? occL[2] : occL[3];
+                const uint64_t oU_ = alt == 0u ? occU[0] : alt == 1u ? occU[1] : alt == 2u ? occU[2] : occU[3];
+                const uint64_t nlo = cb + oL_, nhi = cb + oU_ - 1ull;
+                const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * j));
+                const uint64_t canon = (uint64_t)q * V + 1ull + 3ull * j + d;
+                const bool stepped_live = have && !spill && nlo <= nhi;
+                const bool final_hit = stepped_live && j == 0u;
+                const bool enqueue = (stepped_live && j != 0u) || (have && spill);
+                if (final_hit) {
+                    sparse_s[canon] = make_ulonglong2(nlo, nhi);
+                    atomicOr(bits_s + (canon >> 6), 1ull << (canon & 63u));
+                }
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(enqueue);
+                if (mask != 0ull) {
+                    unsigned long long base = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(count, (unsigned long long)__builtin_popcountll(mask));
+                    const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), src) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, src);
+                    if (enqueue) {
+                        const size_t slot = (size_t)base + (size_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                        if (slot < wl_cap) {  // (room for every variant: the caller's sizing)
+                            if (spill) wl_store(wl_s, slot, lo, j, hi, canon, vword);            // the step is the search kernel's
+                            else wl_store(wl_s, slot, nlo, j - 1u, nhi, canon, vword);           // already taken
+                        }
+                    }
+                    if (COUNT_WORK_BRANCH(work)) {
+                        w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enqueue && !spill));
+                        w_unstepped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enqueue && spill));
+                    }
+                }
+                if (COUNT_WORK_BRANCH(work)) w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(final_hit));
+            }
+        }
+    }
+    // (into the search launches' counters, search_lines.hip WORK_*: an item is the step of three variants off two lookups)
+    if (work != nullptr && lane == 0u) {
+        atomicAdd(&work[0], 3ull * w_items);   // WORK_STEPS
+        atomicAdd(&work[1], 2ull * w_items);   // WORK_OCC
+        atomicAdd(&work[2], w_lines);          // WORK_LINES
+        atomicAdd(&work[13], w_surv);          // variants alive after the step
+        atomicAdd(&work[14], w_unstepped);     // variants passed on unstepped (a position past its line's own pieces)
+    }
+}
+
+}  // namespace
+
+hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t m,
+                                uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,
+                                void *d_counts, void *d_sparse, void *d_hit_bits, int num_cus, hipStream_t stream,
+                                unsigned long long *d_branch_work) {
+    if (m == 0 || nshards == 0) return hipSuccess;
+    if (tn == 0 || tn >= k || k > 32u) return hipErrorInvalidValue;
+    const uint32_t T = k - tn;
+    const size_t mv = m * (3 * (size_t)k + 1);
+    // the table part fills slots 0 .. m * 3T of every shard's list; the survivors of the branch step are appended
+    // behind them: the lists' lengths start there
+    hipLaunchKernelGGL(wl_init_counts_kernel, dim3((nshards + 255u) / 256u), dim3(256), 0, stream, (unsigned long long *)d_counts, nshards,
+                       (unsigned long long)(m * 3u * T));
+    const size_t nt = m * 3u * T * nshards;
+    hipLaunchKernelGGL(wl_table_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, d_shards, nshards,
+                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, m, k, tn, (ulonglong2 *)d_worklists, wl_cap,
+                       (ulonglong2 *)d_sparse, (unsigned long long *)d_hit_bits, mv);
+    const size_t no = m * nshards;
+    hipLaunchKernelGGL(wl_own_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream, (const ulonglong2 *)d_own,
+                       (const uint8_t *)d_valid, nshards, m, k, (ulonglong2 *)d_sparse, (unsigned long long *)d_hit_bits, mv);
+    const size_t items = m * (size_t)tn;
+    size_t g = (items + 64 * WG_WAVES - 1) / (64 * WG_WAVES);
+    const size_t cap = (size_t)num_cus * RSB_MIN_WGS_PER_CU;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(wl_branch_kernel, dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards, nshards, (const uint64_t *)d_packed,
+                       (const uint8_t *)d_valid, m, k, tn, (const ulonglong2 *)d_trace, (ulonglong2 *)d_worklists, wl_cap,
+                       (unsigned long long *)d_counts, (ulonglong2 *)d_sparse, (unsigned long long *)d_hit_bits, mv, d_branch_work);
+    return hipGetLastError();
+}
+
+}  // namespace rsb

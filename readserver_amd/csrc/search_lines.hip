@@ -561,17 +561,20 @@ static int search_kernel_choice() {
 
 template <bool CW, bool CO>
 static void launch_solo(int grid, hipStream_t stream, const shard_view *shards, uint32_t nshards, const uint64_t *pk,
-                        const ulonglong2 *init, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
+                        const ulonglong2 *init, const uint8_t *valid, unsigned long long *ctr, size_t Q, uint32_t k, uint32_t wpq,
                         uint64_t *lo, uint64_t *up, unsigned long long *work, ulonglong2 *trace, uint32_t trace_n,
-                        uint32_t pairs) {
+                        uint32_t pairs, bool fused) {
     uint32_t qchunk = 1024;
     while (qchunk > 64u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
-    if (wpq > 1)
+    if (fused)  // (one shard, k <= 32, a k-mer table, no trace: the kernel makes its own start records)
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+    else if (wpq > 1)
         hipLaunchKernelGGL((search_solo_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
     else
         hipLaunchKernelGGL((search_solo_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
 }
 
 template <bool CW, bool CO>
@@ -651,7 +654,11 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     // start records of this batch + the shards' query counters: scratch of this launch sequence
     // alone, so concurrent calls do not share state
     const size_t nrec = Q * nshards;
-    const bool prepared = extra && extra->d_init;  // the start records exist already: only the counters are scratch
+    // a full batch on one shard behind a deep k-mer table (extra->narrow says there is one and k reaches it): the
+    // one-lane kernel makes its own start records (search_solo.h, FUSED) -- no start-record launch, no records
+    static const bool no_fused_start = getenv("RSBWT_NO_FUSED_START") != nullptr;  // A/B knob (tools/README.md)
+    const bool fused = solo && nshards == 1 && extra && extra->narrow && !extra->d_init && !resumed && !trace && wpq == 1 && !no_fused_start;
+    const bool prepared = (extra && extra->d_init) || fused;  // the start records exist already / are not needed: only the counters are scratch
     scratch_cache::lease mem;
     hipError_t e = scratch.take((prepared ? 0 : nrec * sizeof(ulonglong2)) + nshards * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
@@ -662,7 +669,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
             return e;
         }
     }
-    ulonglong2 *init = prepared ? (ulonglong2 *)extra->d_init : (ulonglong2 *)mem.p;
+    ulonglong2 *init = fused ? nullptr : prepared ? (ulonglong2 *)extra->d_init : (ulonglong2 *)mem.p;
     unsigned long long *ctr = prepared ? (unsigned long long *)mem.p : (unsigned long long *)(init + nrec);
     e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
@@ -685,11 +692,11 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
                            nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, qchunk, 0u);
     } else if (solo) {
         if (d_work) {
-            if (counts_only) launch_solo<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
-            else launch_solo<true, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+            if (counts_only) launch_solo<true, true>(grid, stream, d_shards, nshards, pk, init, vd, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs, fused);
+            else launch_solo<true, false>(grid, stream, d_shards, nshards, pk, init, vd, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs, fused);
         } else {
-            if (counts_only) launch_solo<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
-            else launch_solo<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
+            if (counts_only) launch_solo<false, true>(grid, stream, d_shards, nshards, pk, init, vd, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs, fused);
+            else launch_solo<false, false>(grid, stream, d_shards, nshards, pk, init, vd, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs, fused);
         }
     } else if (d_work) {
         if (counts_only) launch_k<true, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
@@ -698,6 +705,48 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         if (counts_only) launch_k<false, true>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
         else launch_k<false, false>(grid, stream, d_shards, nshards, pk, init, ctr, Q, k, wpq, lo, up, d_work, trace, trace_n, pairs);
     }
+    e = hipGetLastError();
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    scratch.give(mem, stream);
+    return e;
+}
+
+// The worklists of a set's 1-mismatch search (mm1_worklist.hip): every record a live search, the lists' lengths known
+// to the device only -- the grid is what the GPU holds at once, the pools end where the counts say.
+hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_worklists,
+                                  const void *d_counts, size_t wl_cap, size_t result_slots, uint32_t k, void *d_sparse, void *d_hit_bits,
+                                  unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (nshards == 0 || wl_cap == 0) return hipSuccess;
+    if (k > 32u) return hipErrorInvalidValue;
+    static const int wgs_per_cu = [] {
+        const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : RSB_MIN_WGS_PER_CU;
+    }();
+    size_t g = (wl_cap * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
+    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    if (g > cap) g = cap;
+    scratch_cache::lease mem;
+    hipError_t e = scratch.take(nshards * sizeof(unsigned long long), stream, &mem);
+    if (e != hipSuccess) return e;
+    unsigned long long *ctr = (unsigned long long *)mem.p;
+    e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) {
+        scratch.give(mem, stream);
+        return e;
+    }
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    const uint32_t qchunk = 256;
+    if (d_work)
+        hipLaunchKernelGGL((search_solo_kernel<true, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
+                           nshards, (const uint64_t *)nullptr, (const ulonglong2 *)d_worklists, (const uint8_t *)nullptr, ctr, result_slots, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, 0u, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap);
+    else
+        hipLaunchKernelGGL((search_solo_kernel<false, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
+                           nshards, (const uint64_t *)nullptr, (const ulonglong2 *)d_worklists, (const uint8_t *)nullptr, ctr, result_slots, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, 0u, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap);
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);
     scratch.give(mem, stream);

@@ -11,19 +11,37 @@
 // searches per wave keep 64 lookups in flight whatever the intervals' width; a wide interval costs
 // two passes per step instead of one, which a request-bound launch does not feel.
 // Same start records, results, trace and counters as search_lines_kernel.
+//
+// FUSED (a single shard behind a k-mer table, k <= 32, no trace): the kernel computes the start records itself -- no
+// start-record launch before it, no 16 bytes written and read back per search.  The record of a search is its k-mer
+// table entry (findInterval's answer for its last T symbols, src/bwt/query.cpp:18-21,24-41): a lane takes its NEXT
+// search into reserve in two stages, one per pass -- the packed word and the validity byte, then the table entry the
+// word names -- both loads flying with those passes' line fetches, so the dependent pair is never in front of a
+// fetch; the search is taken up once the entry has landed.  On one shard the start-record kernel made three
+// requests per search (table entry, record written, record read): this makes one.
+//
+// WL (the 1-mismatch search of a set, sets.hip): the searches are the records of a WORKLIST per shard -- 32 bytes
+// each: {lower | next symbol << 40, upper, result index, packed word} -- of a length only the device knows
+// (wl_counts[s], written by the kernels that filled the list): a take-up is one 32-byte read, the result goes to
+// the record's own index (sparse results + hit map, as `pairs == 2`), and a record flagged WL_DEAD is a slot its
+// producer left empty.
 #ifndef RSBWT_SEARCH_SOLO_H
 #define RSBWT_SEARCH_SOLO_H
 
 namespace rsb {
 
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK>
+constexpr uint64_t WL_DEAD = 1ull << 63;  // worklist record: an empty slot (bit 63 of its first word)
+
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK, bool FUSED = false, bool WL = false>
 __global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
 search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
-                   const ulonglong2 *__restrict__ init, unsigned long long *__restrict__ next_query,
+                   const ulonglong2 *__restrict__ init, const uint8_t *__restrict__ valid,
+                   unsigned long long *__restrict__ next_query,
                    size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work,
-                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs) {
+                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs,
+                   const unsigned long long *__restrict__ wl_counts = nullptr, size_t wl_cap = 0) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -45,12 +63,14 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const bool ktab = view_uses_ktab(*sv, k);
         const int j_table = ktab ? (int)(k - sv->ktab_depth) - 1 : (int)k - 2;
         const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
-        const ulonglong2 *init_s = init + (size_t)sid * Q;
+        // WL: `init` is the worklists, [nshards][wl_cap] records of two ulonglong2; wl_counts their lengths
+        const ulonglong2 *init_s = WL ? init + (size_t)sid * wl_cap * 2u : init + (size_t)sid * Q;
+        const size_t Qs = WL ? (size_t)(wl_counts[sid] < wl_cap ? wl_counts[sid] : wl_cap) : Q;  // searches of this shard
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;
         // per shard, as in search_lines_kernel: traces [s][Q][trace_n], hit maps [s][hit_map_words(Q)]
-        ulonglong2 *trace_s = trace ? trace + (size_t)sid * Q * trace_n : nullptr;
+        ulonglong2 *trace_s = (trace && !WL) ? trace + (size_t)sid * Q * trace_n : nullptr;
         unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
         // C[1..4] in lanes 0..3, picked with ds_bpermute (scalar loads: see search_lines_kernel)
         uint32_t ctab_lo, ctab_hi;
@@ -62,6 +82,13 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             ctab_hi = (uint32_t)(cv >> 32);
         }
 
+        // FUSED: what start_record() reads of the shard, in scalar registers
+        const uint64_t *__restrict__ ktab_p = sv->ktab;
+        const uint32_t ktab_T = sv->ktab_depth, ktab_stride = sv->ktab_stride;
+        const uint64_t ix_n = sv->n;
+        const uint64_t sc1 = sv->C[1], sc2 = sv->C[2], sc3 = sv->C[3], sc4 = sv->C[4];
+        const uint64_t st1 = sv->total[1], st2 = sv->total[2], st3 = sv->total[3], st4 = sv->total[4];
+
         const uint32_t QCHUNK = qchunk;
         uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
         bool drained = false;
@@ -71,6 +98,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         bool has_n = false;
         ulonglong2 nrec = {0, 0};
         uint64_t nword = 0;
+        uint32_t nstage = 0;  // FUSED: 1 = the reserve's word and validity byte are in, 2 = its table entry too (in nrec.x)
         int j = 0;
         uint64_t word = 0, lo = 0, hi = 0;
         // the step under way: sub 0 = looking up Occ(b, lower - 1), 1 = Occ(b, upper) with occL held;
@@ -82,7 +110,38 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         for (;;) {
             // ---- a lane whose query ended in the last pass takes up the one it had prefetched
             bool done = false;
-            if (!has_q && has_n) {
+            if (FUSED && !has_q && has_n && nstage == 2u) {
+                // start_record() (search_lines.hip) on the entry the reserve brought: an entry that is not an interval
+                // of this BWT's rows (a damaged table) is not believed -- initInterval instead (query.cpp:18-21)
+                const uint64_t e = nrec.x;
+                const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+                if (nrec.y == 0ull) {
+                    nrec.x = INIT_INVALID;
+                } else if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix_n) {
+                    nrec.x = e & COUNT_MASK;
+                    nrec.y = nrec.x + width - 1ull;
+                } else {
+                    const uint32_t bl = (uint32_t)((nword >> (2u * ((k - 1u) & 31u))) & 3u);
+                    const uint64_t cb = bl == 0u ? sc1 : bl == 1u ? sc2 : bl == 2u ? sc3 : sc4;
+                    const uint64_t tb = bl == 0u ? st1 : bl == 1u ? st2 : bl == 2u ? st3 : st4;
+                    nrec.x = cb | INIT_FALLBACK;
+                    nrec.y = cb + tb - 1ull;
+                }
+            }
+            if (WL && !has_q && has_n) {
+                has_q = true;
+                has_n = false;
+                q = nq;  // (the record's result index)
+                sub = 0;
+                cont = 0;
+                lo = nrec.x & COUNT_MASK;
+                hi = nrec.y;
+                j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                word = nword;
+                done = (nrec.x & WL_DEAD) != 0ull || lo > hi;
+                if (done) { lo = 1; hi = 0; }
+            }
+            if (!WL && !has_q && has_n && (!FUSED || nstage == 2u)) {
                 has_q = true;
                 has_n = false;
                 q = nq;
@@ -122,8 +181,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
                     __builtin_amdgcn_readfirstlane((uint32_t)c);
                 pool_next = c;
-                pool_end = c + QCHUNK < Q ? c + QCHUNK : Q;
-                if (c >= Q) { drained = true; pool_next = pool_end = 0; }
+                pool_end = c + QCHUNK < Qs ? c + QCHUNK : Qs;
+                if (c >= Qs) { drained = true; pool_next = pool_end = 0; }
             }
             bool got_n = false;
             {
@@ -137,14 +196,35 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 const uint64_t taken = pool_next + (uint32_t)__builtin_popcountll(want_mask);
                 pool_next = taken < pool_end ? taken : pool_end;
             }
-            if (__builtin_amdgcn_ballot_w64(has_q || got_n) == 0ull) {
+            // (FUSED: a reserve whose table entry is still to come keeps the pass going -- it is taken up two passes
+            // after it was drawn, and a wave whose lanes hold nothing else would otherwise spin here, or leave with it)
+            if (__builtin_amdgcn_ballot_w64(has_q || got_n || (FUSED && has_n)) == 0ull) {
                 if (drained) break;
                 continue;  // pool exhausted mid-pass: refill at the top
             }
             // the two start-up loads of a query taken into reserve fly with this pass's line fetches
             ulonglong2 rec = {0, 0};
             uint64_t first_word = 0;
-            if (got_n) {
+            const bool stage_b = FUSED && has_n && nstage == 1u;  // the reserve's word is in: its table entry now
+            uint64_t entry = 0;
+            uint64_t wl_index = 0;
+            if (WL) {
+                if (got_n) {
+                    rec = init_s[2u * nq];
+                    const ulonglong2 r2 = init_s[2u * nq + 1u];
+                    wl_index = r2.x;
+                    first_word = r2.y;
+                }
+            } else if (FUSED) {
+                if (got_n) {
+                    rec.y = valid[nq];
+                    first_word = packed[nq];
+                }
+                if (stage_b) {
+                    const uint64_t code = (nword >> (2u * (k - ktab_T))) & ((1ull << (2u * ktab_T)) - 1ull);
+                    entry = ktab_p[code * ktab_stride];
+                }
+            } else if (got_n) {
                 rec = init_s[nq];
                 first_word = packed[nq * wpq + w_table];
             }
@@ -341,10 +421,16 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 done = (lo > hi) || (j < 0);  // query.cpp:35-37
                 sub = 0;
             }
+            if (FUSED && stage_b) {
+                nrec.x = entry;
+                nstage = 2u;
+            }
             if (got_n) {
                 nrec = rec;
                 nword = first_word;
                 has_n = true;
+                nstage = 1u;
+                if (WL) nq = (size_t)wl_index;  // from here on the search is known by its result index
             }
             if (alive && done) {
                 if (trace) {

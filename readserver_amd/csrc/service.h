@@ -43,6 +43,14 @@ class transport {
     // next Request message; waits at most timeout_us (< 0: until one arrives or the transport
     // closes).  false = nothing arrived in time, or closed.
     virtual bool recv(std::vector<uint8_t> *msg, int64_t timeout_us) = 0;
+    // up to `max` messages appended to *out: waits at most timeout_us for the first, takes whatever else is queued
+    // already; the number taken (0: nothing arrived in time, or closed)
+    virtual size_t recv_many(std::vector<std::vector<uint8_t>> *out, size_t max, int64_t timeout_us) {
+        std::vector<uint8_t> m;
+        if (max == 0 || !recv(&m, timeout_us)) return 0;
+        out->push_back(std::move(m));
+        return 1;
+    }
     virtual bool closed() = 0;   // closed AND nothing left to receive
     virtual bool closing() = 0;  // close was asked for: what is queued is still answered
     enum channel { PUSH = 0, PUSH_COUNT = 1 };

@@ -159,6 +159,19 @@ class inproc_transport : public transport {
         in_.pop_front();
         return true;
     }
+    size_t recv_many(std::vector<std::vector<uint8_t>> *out, size_t max, int64_t timeout_us) override {
+        std::unique_lock<std::mutex> lock(mu_);
+        auto ready = [&] { return !in_.empty() || closed_; };
+        if (timeout_us < 0) cv_.wait(lock, ready);
+        else if (!cv_.wait_for(lock, std::chrono::microseconds(timeout_us), ready)) return 0;
+        size_t n = 0;
+        while (n < max && !in_.empty()) {  // (one lock for the lot: a lock and a wake-up per message bound the loop at ~1e6 Requests/s)
+            out->push_back(std::move(in_.front()));
+            in_.pop_front();
+            ++n;
+        }
+        return n;
+    }
     bool closed() override {
         std::lock_guard<std::mutex> lock(mu_);
         return closed_ && in_.empty();
@@ -187,6 +200,29 @@ class inproc_transport : public transport {
             in_.emplace_back(data, data + n);
         }
         cv_.notify_all();
+    }
+    void push_requests(const uint8_t *base, const uint64_t *off, size_t count) {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            for (size_t j = 0; j < count; ++j) in_.emplace_back(base + off[j], base + off[j + 1]);
+        }
+        cv_.notify_all();
+    }
+    // up to max_msgs replies of channel c, back to back into buf (message j at off[j] .. off[j + 1]); a reply that no
+    // longer fits stays queued.  The number taken; 0 after timeout_us without one.
+    size_t pop_replies(int c, uint8_t *buf, size_t cap, uint64_t *off, size_t max_msgs, int64_t timeout_us) {
+        std::unique_lock<std::mutex> lock(mu_out_);
+        if (!cv_out_.wait_for(lock, std::chrono::microseconds(timeout_us), [&] { return !out_[c].empty(); })) return 0;
+        size_t n = 0, at = 0;
+        off[0] = 0;
+        while (n < max_msgs && !out_[c].empty() && at + out_[c].front().size() <= cap) {
+            const std::vector<uint8_t> &m = out_[c].front();
+            if (!m.empty()) memcpy(buf + at, m.data(), m.size());
+            at += m.size();
+            off[++n] = at;
+            out_[c].pop_front();
+        }
+        return n;
     }
     bool pop_reply(int c, std::vector<uint8_t> *msg, int64_t timeout_us) {
         std::unique_lock<std::mutex> lock(mu_out_);
@@ -356,102 +392,201 @@ struct rsbwt_transport {
     zmq_transport *zmq = nullptr;        // same object when ZeroMQ
 };
 
+// The loop as a pipeline (the reference answers from a pool of 8 threads on one shared index:
+// src/service/service.cpp:88,1505,1532-1561):
+//   receiver (the thread that called run): gathers Requests into micro-batch windows, numbers them;
+//   `workers` threads: a whole window each -- decode, ONE batched search per query length over the shard set
+//       (the set's entry points are re-entrant: concurrent windows run on contexts / streams of their own), Reply
+//       bytes;
+//   sender: the windows' Replies in window order -- so replies leave in arrival order, as with one thread.
+// With one thread doing all of it (rounds 2-3) nobody received while the GPU answered a window and nobody used the GPU
+// while Replies were encoded: 1.0e6 Requests/s against a kernel that resolves 4e8 queries/s.
+struct window_job {
+    uint64_t seq = 0;
+    std::vector<std::vector<uint8_t>> msgs;
+    std::vector<service_request> rq;
+    std::vector<char> parsed, handled;
+    reply_arena rep;
+    bool done = false;
+};
+
 struct rsbwt_service {
     rsbwt_set_t *set = nullptr;
     transport *tr = nullptr;
     int64_t window_us = 200;
     size_t max_batch = 4096;
     bool per_partition = true;
+    int workers = 8;  // service.cpp:88
     rsbwt_service_other_fn other = nullptr;
     void *other_arg = nullptr;
     std::atomic<bool> stop{false};
     std::thread worker;
     // statistics
     std::atomic<uint64_t> requests{0}, count_requests{0}, batches{0}, replies{0}, malformed{0}, max_batch_seen{0};
+    std::mutex err_mu;
     int last_rc = RSBWT_OK;
     std::string last_err;
 
-    // one window: gather, answer, send.  false = the transport closed with nothing pending
-    bool window() {
-        std::vector<std::vector<uint8_t>> msgs;
-        std::vector<uint8_t> m;
-        if (!tr->recv(&m, 50000)) return !tr->closed() && !stop.load();
-        msgs.push_back(std::move(m));
+    // the pipeline's queues: windows waiting for a worker, windows in flight (in window order) for the sender
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_room;
+    std::deque<window_job *> todo;
+    std::deque<window_job *> inflight;
+    bool no_more = false;
+
+    // receiver: one window.  false = the transport closed with nothing pending
+    bool gather(std::vector<std::vector<uint8_t>> *msgs) {
+        if (tr->recv_many(msgs, max_batch, 50000) == 0) return !tr->closed() && !stop.load();
         const auto t0 = std::chrono::steady_clock::now();
-        while (msgs.size() < max_batch) {
+        while (msgs->size() < max_batch) {
             const int64_t spent = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
             if (spent >= window_us) break;
-            if (!tr->recv(&m, window_us - spent)) break;
-            msgs.push_back(std::move(m));
+            if (tr->recv_many(msgs, max_batch - msgs->size(), window_us - spent) == 0) break;
         }
-        const size_t n = msgs.size();
-        std::vector<service_request> rq(n);
-        std::vector<char> parsed(n, 0);
+        return true;
+    }
+
+    // worker: decode, search, Reply bytes
+    void answer(window_job &job) {
+        const size_t n = job.msgs.size();
+        job.rq.resize(n);
+        job.parsed.assign(n, 0);
         for (size_t i = 0; i < n; ++i) {
-            parsed[i] = service_decode(msgs[i].data(), msgs[i].size(), &rq[i]) ? 1 : 0;
-            if (!parsed[i]) { rq[i].t = 0; malformed++; }
+            job.parsed[i] = service_decode(job.msgs[i].data(), job.msgs[i].size(), &job.rq[i]) ? 1 : 0;
+            if (!job.parsed[i]) { job.rq[i].t = 0; malformed++; }
         }
-        reply_arena rep;
-        std::vector<char> handled;
-        const int rc = service_count_batch(set, rq, per_partition, &rep, &handled);
-        if (rc != RSBWT_OK) {
-            // The front-end has no timeout (server.cpp:403,469,480): a request must not go unanswered.
-            // A failed batch is answered with zero counts and the error kept for the operator.
+        const int rc = service_count_batch(set, job.rq, per_partition, &job.rep, &job.handled);
+        if (rc == RSBWT_OK) return;
+        // The front-end has no timeout (server.cpp:403,469,480): a request must not go unanswered.
+        // A failed batch is answered with zero counts and the error kept for the operator.
+        {
+            std::lock_guard<std::mutex> lock(err_mu);
             last_rc = rc;
             last_err = rsbwt_last_error();
             fprintf(stderr, "rsbwt service: batch of %zu requests failed: %s\n", n, last_err.c_str());
-            const size_t rows = per_partition ? rsbwt_set_size(set) : 1;
-            for (size_t i = 0; i < n; ++i) {
-                const bool is_count = rq[i].t == 1 || (rq[i].t == 2 && rq[i].rt == 1);
-                if (!is_count) continue;
-                for (size_t r = 0; r < rows; ++r)
-                    for (int strand = 0; strand < 2; ++strand) {
-                        uint8_t buf[1024];
-                        std::vector<uint8_t> big;
-                        size_t len = rsbwt_proto_encode_count_reply(buf, sizeof buf, rq[i].t, rq[i].q.data(), rq[i].q.size(), strand, 0);
-                        const uint8_t *p = buf;
-                        if (len > sizeof buf) {
-                            big.resize(len);
-                            rsbwt_proto_encode_count_reply(big.data(), len, rq[i].t, rq[i].q.data(), rq[i].q.size(), strand, 0);
-                            p = big.data();
-                        }
-                        tr->send(rq[i].t == 1 ? transport::PUSH_COUNT : transport::PUSH, p, len);
-                        replies++;
-                    }
-            }
-        } else {
-            // in arrival order; consecutive messages for the same socket go out in one call.
-            // CountReads answers on push_count, ExactMatch-Count on push (service.cpp:1549-1554,1567-1570)
-            size_t run0 = 0, run1 = 0;
-            transport::channel run_ch = transport::PUSH_COUNT;
-            auto flush = [&] {
-                if (run1 > run0) tr->send_many(run_ch, rep.bytes.data(), rep.off.data() + run0, run1 - run0);
-                replies += run1 - run0;
-                run0 = run1;
-            };
-            for (size_t i = 0; i < n; ++i) {
-                if (handled[i]) {
-                    count_requests++;
-                    const transport::channel ch = rq[i].t == 1 ? transport::PUSH_COUNT : transport::PUSH;
-                    if (ch != run_ch) { flush(); run_ch = ch; }
-                    run0 = run1 > run0 ? run0 : rep.first[i];
-                    run1 = rep.first[i + 1];
-                } else if (parsed[i] && other) {
-                    flush();
-                    other(other_arg, msgs[i].data(), msgs[i].size());  // KmerMatch, SiteMatch, ExactMatch with reads: the caller's
-                }
-            }
-            flush();
         }
+        const size_t rows = per_partition ? rsbwt_set_size(set) : 1;
+        job.handled.assign(n, 0);
+        job.rep.bytes.clear();
+        job.rep.off.assign(1, 0);
+        job.rep.first.assign(n + 1, 0);
+        for (size_t i = 0; i < n; ++i) {
+            job.rep.first[i] = job.rep.off.size() - 1;
+            const bool is_count = job.rq[i].t == 1 || (job.rq[i].t == 2 && job.rq[i].rt == 1);
+            if (!is_count) continue;
+            job.handled[i] = 1;
+            for (size_t r = 0; r < rows; ++r)
+                for (int strand = 0; strand < 2; ++strand) {
+                    const size_t len = rsbwt_proto_encode_count_reply(nullptr, 0, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                    const size_t at = job.rep.bytes.size();
+                    job.rep.bytes.resize(at + len);
+                    rsbwt_proto_encode_count_reply(job.rep.bytes.data() + at, len, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                    job.rep.off.push_back(job.rep.bytes.size());
+                }
+        }
+        job.rep.first[n] = job.rep.off.size() - 1;
+    }
+
+    // sender: in arrival order; consecutive messages for the same socket go out in one call.
+    // CountReads answers on push_count, ExactMatch-Count on push (service.cpp:1549-1554,1567-1570)
+    void emit(window_job &job) {
+        const size_t n = job.msgs.size();
+        const reply_arena &rep = job.rep;
+        size_t run0 = 0, run1 = 0;
+        transport::channel run_ch = transport::PUSH_COUNT;
+        auto flush = [&] {
+            if (run1 > run0) tr->send_many(run_ch, rep.bytes.data(), rep.off.data() + run0, run1 - run0);
+            replies += run1 - run0;
+            run0 = run1;
+        };
+        for (size_t i = 0; i < n; ++i) {
+            if (job.handled[i]) {
+                count_requests++;
+                const transport::channel ch = job.rq[i].t == 1 ? transport::PUSH_COUNT : transport::PUSH;
+                if (ch != run_ch) { flush(); run_ch = ch; }
+                run0 = run1 > run0 ? run0 : rep.first[i];
+                run1 = rep.first[i + 1];
+            } else if (job.parsed[i] && other) {
+                flush();
+                other(other_arg, job.msgs[i].data(), job.msgs[i].size());  // KmerMatch, SiteMatch, ExactMatch with reads: the caller's
+            }
+        }
+        flush();
         requests += n;
         batches++;
         uint64_t seen = max_batch_seen.load();
         while (n > seen && !max_batch_seen.compare_exchange_weak(seen, n)) {}
-        return true;
+    }
+
+    void worker_loop() {
+        for (;;) {
+            window_job *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_work.wait(lock, [&] { return !todo.empty() || no_more; });
+                if (todo.empty()) return;
+                job = todo.front();
+                todo.pop_front();
+            }
+            answer(*job);
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                job->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+
+    void sender_loop() {
+        for (;;) {
+            window_job *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_done.wait(lock, [&] { return (!inflight.empty() && inflight.front()->done) || (no_more && inflight.empty()); });
+                if (inflight.empty()) return;
+                job = inflight.front();
+                inflight.pop_front();
+            }
+            cv_room.notify_all();
+            emit(*job);
+            delete job;
+        }
     }
 
     void run() {
-        while (!stop.load() && window()) {}
+        const int nw = workers < 1 ? 1 : workers > 64 ? 64 : workers;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            no_more = false;
+        }
+        std::vector<std::thread> pool;
+        for (int i = 0; i < nw; ++i) pool.emplace_back([this] { worker_loop(); });
+        std::thread sender([this] { sender_loop(); });
+        uint64_t seq = 0;
+        while (!stop.load()) {
+            window_job *job = new (std::nothrow) window_job();
+            if (!job) break;
+            if (!gather(&job->msgs)) { delete job; break; }
+            if (job->msgs.empty()) { delete job; continue; }  // nothing arrived in time: ask again
+            job->seq = seq++;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                // at most two windows per worker in flight: a sender that cannot keep up holds the receiver back
+                cv_room.wait(lock, [&] { return inflight.size() < 2 * (size_t)nw; });
+                todo.push_back(job);
+                inflight.push_back(job);
+            }
+            cv_work.notify_one();
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            no_more = true;
+        }
+        cv_work.notify_all();
+        cv_done.notify_all();
+        for (std::thread &t : pool) t.join();
+        cv_done.notify_all();
+        sender.join();
     }
 };
 
@@ -569,6 +704,25 @@ int rsbwt_transport_push_request(rsbwt_transport_t *t, const uint8_t *msg, size_
 }
 
 
+int rsbwt_transport_push_requests(rsbwt_transport_t *t, const uint8_t *base, const uint64_t *off, size_t count) {
+    return guarded("rsbwt_transport_push_requests", [&]() -> int {
+        if (!t || !t->inproc || ((!base || !off) && count)) return fail(RSBWT_EINVAL, "not an in-process transport");
+        for (size_t j = 0; j < count; ++j)
+            if (off[j + 1] < off[j]) return fail(RSBWT_EINVAL, "request offsets must ascend");
+        t->inproc->push_requests(base, off, count);
+        return RSBWT_OK;
+    });
+}
+
+int rsbwt_transport_pop_replies(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, uint64_t *off, size_t max_msgs,
+                                size_t *count, int64_t timeout_us) {
+    return guarded("rsbwt_transport_pop_replies", [&]() -> int {
+        if (!t || !t->inproc || !buf || !off || !count || channel < 0 || channel > 1) return fail(RSBWT_EINVAL, "not an in-process transport");
+        *count = t->inproc->pop_replies(channel, buf, cap, off, max_msgs, timeout_us);
+        return RSBWT_OK;
+    });
+}
+
 static int rsbwt_transport_pop_reply_body(rsbwt_transport_t *t, int channel, uint8_t *buf, size_t cap, size_t *n, int64_t timeout_us) {
     if (!t || !t->inproc || !n || channel < 0 || channel > 1) return fail(RSBWT_EINVAL, "not an in-process transport");
     std::vector<uint8_t> m;
@@ -607,6 +761,10 @@ int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_
     return guarded("rsbwt_service_create", [&]() -> int { return rsbwt_service_create_body(set, t, window_us, max_batch, per_partition, out); });
 }
 
+
+void rsbwt_service_set_workers(rsbwt_service_t *s, int workers) {
+    if (s && workers >= 1) s->workers = workers > 64 ? 64 : workers;
+}
 
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg) {
     if (!s) return;

@@ -8,6 +8,7 @@
 //   shards  = [ "<prefix of shard 0>", ... ];     one .bwt per suffix partition (64)
 //   devices = [ "0", "0", ..., "7" ];             HIP device of each shard (default: shard s -> GPU s * ndev / nshards)
 //   batch_window_us = "200";  batch_max = "4096";  replies = "per_partition" | "summed";
+//   query_threads = "8";                          windows answered at once (the reference's query pool: service.cpp:88)
 // and then sends 2 x shards replies per request (front-end `workers` = 2 x shards) or 2 (`summed`).
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,6 +70,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "%s\n", rsbwt_last_error());
         return EXIT_FAILURE;
     }
+    rsbwt_service_set_workers(svc, atoi(get(cfg, "query_threads", "8")));
     printf("ready to serve from %s\n", get(cfg, "suffix", ""));
     fflush(stdout);
     const int rc = rsbwt_service_run(svc);  // forever (service.cpp:1521)

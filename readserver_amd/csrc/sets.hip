@@ -605,6 +605,10 @@ static size_t side_by_side_below() {
 struct fused_1mm_layout {
     uint32_t tn;
     size_t trace, own, sparse, bits, blocks, total;  // byte sizes of the parts behind the variants, each 256-aligned
+    // the hit lists by WORKLIST (mm1_worklist.hip): k <= 32 with something left of the tables' reach -- the variants'
+    // searches are records of live searches (a record per variant at most), no variants spelled out, no start records
+    bool worklist;
+    size_t wl_cap, wl, counts;
 };
 static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L) {
     static const bool off = getenv("RSBWT_SET_1MM_UNFUSED") != nullptr;  // A/B knob (tools/README.md)
@@ -620,7 +624,12 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
     L->sparse = al(S * mv * 16);
     L->bits = al(S * hit_map_words(mv) * 8);
     L->blocks = al(S * compact_hits_block_words(mv) * 8);
-    L->total = L->trace + L->own + L->sparse + L->bits + L->blocks;
+    static const bool no_worklist = getenv("RSBWT_SET_1MM_NO_WORKLIST") != nullptr;  // A/B knob (tools/README.md): round 3's launches
+    L->worklist = !no_worklist && tn > 0 && tn < k && k <= 32u && m * (size_t)tn < 0xFFFFFFFFull;
+    L->wl_cap = L->worklist ? m * 3u * (size_t)k : 0;
+    L->wl = L->worklist ? al(S * L->wl_cap * 32) : 0;
+    L->counts = L->worklist ? al(S * 8) : 0;
+    L->total = L->trace + L->own + L->sparse + L->bits + L->blocks + L->wl + L->counts;
     return true;
 }
 
@@ -912,7 +921,23 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
     uint8_t *d_trace = d_parts, *d_own = d_trace + L.trace, *d_sparse = d_own + L.own, *d_bits = d_sparse + L.sparse;
     uint8_t *d_blocks = d_bits + L.bits;
     HIP_OK(hipMemsetAsync(d_bits, 0, (size_t)S * hit_map_words(mv) * 8, st));
-    const int rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);
+    int rc;
+    if (L.worklist) {
+        // the k-mers traced; the step of the three substitutions of every traced position off one fetch, the variants
+        // inside the tables' reach from their table entries: worklists of live searches; then ONE launch runs them
+        uint8_t *d_wl = d_blocks + L.blocks, *d_counts = d_wl + L.wl;
+        search_extra traced;
+        traced.d_trace_out = d_trace;
+        traced.trace_n = L.tn;
+        traced.pairs = true;
+        if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced)) != RSBWT_OK) return rc;
+        const hipError_t ew = launch_mm1_worklists(g->d_views, S, d_packed, d_valid, m, k, L.tn, d_trace, d_own, d_wl, L.wl_cap, d_counts,
+                                                   d_sparse, d_bits, g->num_cus, st, g->counting ? g->d_work : nullptr);
+        if (ew != hipSuccess) return fail_hip(ew, "worklist kernels");
+        rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_wl, d_counts, L.wl_cap, mv, k, d_sparse, d_bits, st);
+    } else {
+        rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);
+    }
     if (rc) return rc;
     const hipError_t e = launch_compact_hits(d_bits, d_sparse, mv, d_hits, cap_per_shard, d_totals, d_blocks, st, S);
     return e == hipSuccess ? RSBWT_OK : fail_hip(e, "hit list kernels");
@@ -938,9 +963,11 @@ int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_v
     const bool side = !turns_only && S > 1 && m * (3 * (size_t)k + 1) < SIDE_BY_SIDE_BELOW;
     const size_t one = hits_1mm_scratch_one(s, m, k);
     uint8_t *d_var = (uint8_t *)d_scratch, *d_slots = d_var + ((variants_bytes(m, k) + 255) & ~(size_t)255);
-    if ((rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
     fused_1mm_layout FL;
-    if (!turns_only && fused_1mm_applies(s, m, k, &FL))
+    const bool fused = !turns_only && fused_1mm_applies(s, m, k, &FL);
+    // (the worklist form spells no variants out)
+    if (!(fused && FL.worklist) && (rc = variants_of_batch_dev(d_packed, d_valid, m, k, d_var, (hipStream_t)stream)) != RSBWT_OK) return rc;
+    if (fused)
         return set_hits_1mm_fused(s, g, FL, d_packed, d_valid, m, k, d_hits, cap_per_shard, d_totals, d_var, d_slots, (hipStream_t)stream);
     auto one_shard = [&](size_t i, uint8_t *slot, hipStream_t st) {
         return hits_1mm_dev_shared(s->shards[i], d_packed, d_valid, m, k, (uint8_t *)d_hits + i * cap_per_shard * 32, cap_per_shard,

@@ -2,15 +2,20 @@
 // process: a producer thread pushes serialised CountReads Requests into the in-process transport, the
 // loop batches them (window / max batch), searches all shards of the set on the GPU and sends 2 x P
 // Replies per request, a consumer thread pops them.  What a ZeroMQ deployment adds is the sockets.
-//   tools/bin/service_bench [requests=200000] [shards=1] [run_bytes=2e8] [window_us=200] [max_batch=4096] [closed=0]
+//   tools/bin/service_bench [requests=200000] [shards=1] [run_bytes=2e8] [window_us=200] [max_batch=4096] [closed=0] [workers=8] [zmq=0]
+// zmq=1: the same open loop over REAL ZeroMQ sockets on tcp loopback -- this program plays the front-end (binds a PUB
+// and two PULL sockets, src/service/server.cpp:118-124), the service connects SUB / PUSH / PUSH (libzmq bound at run
+// time on both sides).
 // closed=1: one request in flight at a time (push, wait for its 2 x P replies): the latency of a lone
 // request, printed beside the latency of the library calls under it (rsbwt_set_find_intervals and
 // rsbwt_find_intervals with one k-mer).
 // build: g++ -O2 -std=c++17 -Iinclude tools/service_bench.cpp -Lreadserver_amd/lib -lrsbwt -lpthread
 //            -Wl,-rpath,'$ORIGIN/../../readserver_amd/lib' -Wl,-rpath,/opt/rocm/lib -o tools/bin/service_bench
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -35,6 +40,8 @@ int main(int argc, char **argv) {
     const int64_t window = argc > 4 ? atoll(argv[4]) : 200;
     const size_t max_batch = argc > 5 ? (size_t)atoll(argv[5]) : 4096;
     const bool closed_loop = argc > 6 && atoi(argv[6]) != 0;
+    const int workers = argc > 7 ? atoi(argv[7]) : 8;
+    const bool over_zmq = argc > 8 && atoi(argv[8]) != 0;
     const uint32_t k = 31;
     std::vector<rsbwt_t *> shards;
     {
@@ -52,8 +59,50 @@ int main(int argc, char **argv) {
     rsbwt_set_t *set = nullptr;
     rsbwt_transport_t *tr = nullptr;
     rsbwt_service_t *svc = nullptr;
-    if (rsbwt_set_from_handles(shards.data(), P, &set) || rsbwt_transport_inproc(&tr) ||
-        rsbwt_service_create(set, tr, window, max_batch, 1, &svc) || rsbwt_service_start(svc)) {
+    // zmq=1: the front-end's sockets, bound here on tcp loopback
+    struct {
+        void *lib = nullptr, *ctx = nullptr, *pub = nullptr, *pull = nullptr, *pull_count = nullptr;
+        void *(*ctx_new)() = nullptr;
+        void *(*socket)(void *, int) = nullptr;
+        int (*bind)(void *, const char *) = nullptr;
+        int (*getsockopt)(void *, int, void *, size_t *) = nullptr;
+        int (*setsockopt)(void *, int, const void *, size_t) = nullptr;
+        int (*send)(void *, const void *, size_t, int) = nullptr;
+        int (*recv)(void *, void *, size_t, int) = nullptr;
+    } z;
+    char ep[3][256] = {{0}, {0}, {0}};
+    if (over_zmq) {
+        for (const char *name : {(const char *)getenv("RSBWT_LIBZMQ"), "libzmq.so.5", "libzmq.so", "/usr/local/lib/libzmq.so.5", "/opt/conda/lib/libzmq.so.5"})
+            if (name && *name && !z.lib) z.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!z.lib || !rsbwt_zmq_available()) { fprintf(stderr, "no libzmq here\n"); return 3; }
+#define ZS(f, n) z.f = reinterpret_cast<decltype(z.f)>(dlsym(z.lib, n))
+        ZS(ctx_new, "zmq_ctx_new"); ZS(socket, "zmq_socket"); ZS(bind, "zmq_bind"); ZS(getsockopt, "zmq_getsockopt");
+        ZS(setsockopt, "zmq_setsockopt"); ZS(send, "zmq_send"); ZS(recv, "zmq_recv");
+#undef ZS
+        z.ctx = z.ctx_new();
+        void **socks[3] = {&z.pub, &z.pull, &z.pull_count};
+        const int types[3] = {1 /* ZMQ_PUB */, 7 /* ZMQ_PULL */, 7};
+        for (int i = 0; i < 3; ++i) {
+            *socks[i] = z.socket(z.ctx, types[i]);
+            const int zero = 0, tmo = 20000, hwm = 0;
+            z.setsockopt(*socks[i], 17 /* ZMQ_LINGER */, &zero, sizeof zero);
+            z.setsockopt(*socks[i], 27 /* ZMQ_RCVTIMEO */, &tmo, sizeof tmo);
+            z.setsockopt(*socks[i], 23 /* ZMQ_SNDHWM */, &hwm, sizeof hwm);  // (an open loop: nothing may be dropped at the publisher)
+            z.setsockopt(*socks[i], 24 /* ZMQ_RCVHWM */, &hwm, sizeof hwm);
+            size_t n = sizeof ep[i];
+            if (z.bind(*socks[i], "tcp://127.0.0.1:*") != 0 || z.getsockopt(*socks[i], 32 /* ZMQ_LAST_ENDPOINT */, ep[i], &n) != 0) {
+                fprintf(stderr, "cannot bind the front-end's sockets\n");
+                return 3;
+            }
+        }
+    }
+    if (rsbwt_set_from_handles(shards.data(), P, &set) || (over_zmq ? rsbwt_transport_zmq(ep[0], ep[1], ep[2], &tr) : rsbwt_transport_inproc(&tr)) ||
+        rsbwt_service_create(set, tr, window, max_batch, 1, &svc)) {
+        fprintf(stderr, "%s\n", rsbwt_last_error());
+        return 1;
+    }
+    rsbwt_service_set_workers(svc, workers);
+    if (rsbwt_service_start(svc)) {
         fprintf(stderr, "%s\n", rsbwt_last_error());
         return 1;
     }
@@ -139,18 +188,61 @@ int main(int argc, char **argv) {
         for (rsbwt_t *h : shards) rsbwt_close(h);
         return 0;
     }
+    if (over_zmq) {
+        // PUB/SUB drops what is published before the subscription has arrived: probe until one is answered, then drain
+        uint8_t buf[512];
+        bool up = false;
+        const int short_tmo = 200, long_tmo = 20000;
+        z.setsockopt(z.pull_count, 27, &short_tmo, sizeof short_tmo);
+        for (int tries = 0; tries < 100 && !up; ++tries) {
+            z.send(z.pub, msgs[0].data(), msgs[0].size(), 0);
+            up = z.recv(z.pull_count, buf, sizeof buf, 0) >= 0;
+        }
+        if (!up) { fprintf(stderr, "the service never subscribed\n"); return 3; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(300));
+        while (z.recv(z.pull_count, buf, sizeof buf, 0) >= 0) {}
+        z.setsockopt(z.pull_count, 27, &long_tmo, sizeof long_tmo);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::thread producer([&] {
-        for (size_t i = 0; i < N; ++i) rsbwt_transport_push_request(tr, (const uint8_t *)msgs[i].data(), msgs[i].size());
+        if (over_zmq) {
+            for (size_t i = 0; i < N; ++i) z.send(z.pub, msgs[i].data(), msgs[i].size(), 0);
+            return;
+        }
+        // the in-process transport in bulk: a few hundred Requests per call
+        const size_t CH = 512;
+        std::vector<uint8_t> flat;
+        std::vector<uint64_t> off;
+        for (size_t i0 = 0; i0 < N; i0 += CH) {
+            const size_t m = std::min(CH, N - i0);
+            flat.clear();
+            off.assign(1, 0);
+            for (size_t i = i0; i < i0 + m; ++i) {
+                flat.insert(flat.end(), msgs[i].begin(), msgs[i].end());
+                off.push_back(flat.size());
+            }
+            rsbwt_transport_push_requests(tr, flat.data(), off.data(), m);
+        }
     });
     size_t got = 0, bytes = 0;
     std::thread consumer([&] {
-        uint8_t buf[512];
+        if (over_zmq) {
+            uint8_t buf[512];
+            while (got < 2 * P * N) {
+                const int n = z.recv(z.pull_count, buf, sizeof buf, 0);
+                if (n < 0) break;
+                ++got;
+                bytes += (size_t)n;
+            }
+            return;
+        }
+        std::vector<uint8_t> buf(1 << 20);
+        std::vector<uint64_t> off(8193);
         size_t n = 0;
         while (got < 2 * P * N) {
-            if (rsbwt_transport_pop_reply(tr, 1, buf, sizeof buf, &n, 30000000) != RSBWT_OK) break;
-            ++got;
-            bytes += n;
+            if (rsbwt_transport_pop_replies(tr, 1, buf.data(), buf.size(), off.data(), 8192, &n, 30000000) != RSBWT_OK || n == 0) break;
+            got += n;
+            bytes += off[n];
         }
     });
     producer.join();
@@ -162,9 +254,11 @@ int main(int argc, char **argv) {
     rsbwt_service_stats(svc, st);
     printf("{\"requests\": %zu, \"partitions\": %zu, \"replies\": %zu, \"reply_bytes\": %zu, \"seconds\": %.4f, "
            "\"requests_per_s\": %.1f, \"searches_per_s\": %.1f, \"windows\": %llu, \"mean_requests_per_window\": %.1f, "
-           "\"largest_window\": %llu, \"window_us\": %lld, \"max_batch\": %zu, \"run_bytes_per_shard\": %llu}\n",
+           "\"largest_window\": %llu, \"window_us\": %lld, \"max_batch\": %zu, \"run_bytes_per_shard\": %llu, \"workers\": %d, "
+           "\"transport\": \"%s\"}\n",
            N, P, got, bytes, dt, N / dt, 2.0 * P * N / dt, (unsigned long long)st[2], (double)st[0] / (double)(st[2] ? st[2] : 1),
-           (unsigned long long)st[5], (long long)window, max_batch, (unsigned long long)R);
+           (unsigned long long)st[5], (long long)window, max_batch, (unsigned long long)R, workers,
+           over_zmq ? "ZeroMQ PUB/SUB + PUSH/PULL over tcp loopback (this program = the front-end)" : "in-process queue pair, bulk push / pop");
     rsbwt_service_free(svc);
     rsbwt_transport_free(tr);
     rsbwt_set_close(set);
