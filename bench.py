@@ -78,6 +78,9 @@ def parse():
                     help="--mode extract: rows come as runs of this many consecutive SA rows (the rows of an interval: "
                          "query.cpp:94-96 extracts lower..upper; 8 = the final width measured on the valid popBWT)")
     ap.add_argument("--stride", type=int, default=256, help="--mode extract: bytes per read buffer")
+    ap.add_argument("--verify-rows", type=int, default=200,
+                    help="--mode 1mm / extract at N = 1: after the timed region, this many k-mers' hit lists / this many reads of shard 0 "
+                         "are held to the oracle (its index over shard 0's 2e10 run bytes takes ~30 s to build); 0 = skip")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
@@ -729,6 +732,27 @@ def main():
         c.dist.destroy_process_group()
 
 
+def oracle_of_shard0(a, c, mix):
+    """The oracle's index over shard 0's run bytes (test infrastructure, the checker of the rows modes' outputs): the
+    stream is synthesised again slice by slice on the GPU (HBM is full of shards: no room for 20 GB of run bytes) and
+    copied to the host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    torch, L = c.torch, c.L
+    R, S = int(a.runs), a.shards_per_gpu
+    seed = shard_seed(a, mix, c.rank, S, 0)
+    host = np.empty(R, np.uint8)
+    CH = min(R, 1 << 29)
+    d = torch.empty(CH, dtype=torch.uint8, device=c.dev)
+    for i0 in range(0, R, CH):
+        n = min(CH, R - i0)
+        ok(c, L.rsbwt_synth_runs_dev_at(ptr(d), i0, n, seed, c.local, c.sp))
+        torch.cuda.synchronize()
+        host[i0:i0 + n] = d[:n].cpu().numpy()
+    del d
+    return oracle_binding.load().from_runs(host)
+
+
 def run_rows(a, c):
     """--mode 1mm (configs[3]) and --mode extract (configs[4]) over the shards of every GPU of the job: what
     each rank's shards give is gathered on rank 0 and laid side by side in global shard order, the way the
@@ -845,6 +869,26 @@ def run_rows(a, c):
                 rec, first = sharded.concat_hit_lists(blocks, [t.cpu() for t in totals])
                 verified = (all(int(blocks[r].sum(dtype=torch.int64).item()) == int(sums[r][0].item()) for r in range(world))
                             and int(first[-1]) == sum(int(x[1].item()) for x in sums) and rec.shape[0] == int(first[-1]))
+        overflowed = bool((tot_local > cap).any().item())  # (a list longer than its buffer keeps its count and drops records)
+        if world == 1 and a.verify_rows > 0:
+            # shard 0's list of the last batch against the oracle's exact search of every variant of the first k-mers
+            oix = oracle_of_shard0(a, c, mix)
+            nv = int(min(a.verify_rows, M))
+            acgt = np.frombuffer(b"ACGT", np.uint8)
+            kmh = d_km[:nv].cpu().numpy()
+            sp_ = np.repeat(kmh[:, None, :], V, axis=1)
+            for pos in range(k):
+                for q_ in range(nv):
+                    sp_[q_, 1 + 3 * pos:4 + 3 * pos, pos] = [x for x in acgt if x != kmh[q_, pos]][:3]
+            vlo, vup = oix.find_intervals(sp_.reshape(-1, k), nthreads=usable_cpus())
+            n0 = int(oix.bwlen())
+            want = [(int(vlo[i]), int(vup[i]), i) for i in range(nv * V) if vup[i] >= vlo[i] and vup[i] < n0]
+            h0 = (d_h[last % 2] if d_h is not None else gat_h.acquire(last))[0]
+            rec0 = h0[:min(int(tot_local[0].item()), cap)].cpu().numpy().view(np.uint64)
+            got = [(int(r_[0]), int(r_[1]), int(r_[2])) for r_ in rec0 if r_[2] < nv * V]
+            verified = (got == want) and not overflowed
+            oix.close()
+        hits_local = int(torch.minimum(tot_local, torch.full_like(tot_local, cap)).sum().item())  # (what the lists hold)
         alg = w[2] * LINE_BYTES + S * M * V * 24 + hits_local * 48
         # below 2^26 variant searches per shard the set's shards work side by side on streams of their own
         # (csrc/sets.hip): their kernels overlap, so the sum of their durations says nothing -- the step is priced
@@ -947,6 +991,24 @@ def run_rows(a, c):
         dt = max_over_ranks(time.perf_counter() - t1)
         k_ms = ev0.elapsed_time(ev1) / a.steps  # the walk kernels of one batch (current stream; the gather runs beside them)
         verified = None
+        if world == 1 and a.verify_rows > 0:
+            # reads of shard 0 of the last batch against the oracle's extractPrefix + extractPostfix of the same rows
+            oix = oracle_of_shard0(a, c, mix)
+            lastb = (step_no[0] - 1) % 2
+            pick = np.unique(np.linspace(0, NR - 1, int(min(a.verify_rows, NR))).astype(np.int64))
+            pick_t = torch.from_numpy(pick).to(dev)
+            o_h = d_full[lastb][0][pick_t].cpu().numpy()
+            l_h = d_lenb[lastb][0][pick_t].cpu().numpy().view(np.uint32)
+            r_h = rows[0][pick_t].cpu().numpy()
+            verified = True
+            for i_ in range(pick.size):
+                pre, post = oix.extract(int(r_h[i_]), cap=8192)
+                if len(pre) + len(post) <= stride:
+                    verified = verified and l_h[i_] == len(pre) + len(post) and o_h[i_, :l_h[i_]].tobytes().decode() == pre + post
+                else:
+                    verified = verified and l_h[i_] == 0xFFFFFFFF
+            verified = bool(verified)
+            oix.close()
         if world > 1:
             last = step_no[0] - 1
             sent, sent_l = gat_o.acquire(last), gat_l.acquire(last)

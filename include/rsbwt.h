@@ -263,6 +263,9 @@ int rsbwt_last_search_phases(rsbwt_t *h, uint64_t *cycles6, uint64_t *passes);
 #define RSBWT_SYNTH_LONG_RUNS (1ull << 63)
 int rsbwt_synth_runs_dev(void *d_runs, uint64_t num_runs, uint64_t seed, int device, void *stream);
 int rsbwt_synth_runs_host(uint8_t *runs, uint64_t num_runs, uint64_t seed);
+/* A slice of the same stream: d_runs[i] = byte first + i (a 20 GB stream piece by piece, for a checker that has no
+ * room for it in HBM). */
+int rsbwt_synth_runs_dev_at(void *d_runs, uint64_t first, uint64_t num_runs, uint64_t seed, int device, void *stream);
 /* Draw Q k-mers that are present in the index (LF walks from random rows, so every one of the
  * k-1 updateInterval steps keeps a non-empty interval) into d_kmers (ASCII, stride bytes). */
 int rsbwt_sample_present_kmers_dev(rsbwt_t *h, size_t Q, uint32_t k, size_t stride, uint64_t seed,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rsbwt_last_search_phases": (C.c_int, [_vp, _u64p, _u64p]),
     "rsbwt_last_search_ktab_lookups": (C.c_int, [_vp, _u64p]),
     "rsbwt_synth_runs_dev": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "rsbwt_synth_runs_dev_at": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "rsbwt_synth_runs_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "rsbwt_sample_present_kmers_dev": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint64, _vp, _vp]),
     "rsbwt_bpi2_write": (C.c_int, [C.c_char_p, C.c_char_p]),

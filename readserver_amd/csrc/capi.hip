@@ -1529,6 +1529,15 @@ int rsbwt_synth_runs_dev(void *d_runs, uint64_t num_runs, uint64_t seed, int dev
     return RSBWT_OK;
 }
 
+int rsbwt_synth_runs_dev_at(void *d_runs, uint64_t first, uint64_t num_runs, uint64_t seed, int device, void *stream) {
+    if (!d_runs && num_runs) return fail(RSBWT_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipError_t e = launch_synth_runs(d_runs, num_runs, seed, (hipStream_t)stream, first);
+    if (e != hipSuccess) return fail_hip(e, "synth kernel launch");
+    return RSBWT_OK;
+}
+
 int rsbwt_sample_present_kmers_dev(rsbwt_t *h, size_t Q, uint32_t k, size_t stride, uint64_t seed,
                                    void *d_kmers, void *stream) {
     if (!h || (!d_kmers && Q)) return fail(RSBWT_EINVAL, "null argument");

@@ -87,11 +87,14 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
 uint32_t trace_entries(const shard_view &ix, uint32_t k);
 // The 1-mismatch search of a set as worklists of live searches (mm1_worklist.hip; k <= 32, 0 < tn < k, one table depth
 // k - tn for all shards).  launch_mm1_worklists fills them from the traced search's output (d_trace [nshards][m][tn],
-// d_own [nshards][m] pairs): d_worklists [nshards][wl_cap] x 32 B, wl_cap >= m * 3k, d_counts u64[nshards] their lengths;
+// d_own [nshards][m] pairs): d_worklists [nshards][wl_cap] x 32 B, wl_cap >= m * 3k, d_counts u64[nshards * WL_COUNT_STRIDE] their lengths (entry s at s * WL_COUNT_STRIDE);
 // hits that need no further step go straight to d_sparse [nshards][mv] / d_hit_bits.  d_branch_work (optional, zeroed
 // by the caller): the search launches' counter words (WORK_*): steps += 3 per item, lookups += 2, lines fetched; word 13 =
 // variants alive after the step, 14 = variants passed on unstepped.
 // launch_search_worklist then runs them (search_solo.h, WL): results at the records' own indices.
+// (the lists' lengths sit WL_COUNT_STRIDE u64 apart: appended to by every wave of the branch kernel, they must not share
+// a cache line -- eight counters in one line serialised the kernel at one atomic at a time: 10 ms instead of 2)
+constexpr uint32_t WL_COUNT_STRIDE = 32;
 hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t m,
                                 uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,
                                 void *d_counts, void *d_sparse, void *d_hit_bits, int num_cus, hipStream_t stream,
@@ -153,7 +156,7 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
 // query / query_exactmatch (query.cpp:87-120) over extracted reads
 hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, uint32_t stride, const void *d_owner,
                               const void *d_kmers, uint32_t k, size_t kstride, void *d_flags, hipStream_t stream);
-hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream);
+hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream, uint64_t first = 0);
 hipError_t launch_sample_present(const shard_view &ix, size_t Q, uint32_t k, size_t stride,
                                  uint64_t seed, void *d_kmers, hipStream_t stream);
 

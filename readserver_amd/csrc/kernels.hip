@@ -279,8 +279,8 @@ occ_at_batch_kernel(const shard_view ix, const uint64_t *__restrict__ sel, uint6
 // ------------------------------------------------------------------------------------------
 // Synthetic inputs.
 // ------------------------------------------------------------------------------------------
-__global__ void synth_runs_kernel(uint8_t *__restrict__ runs, uint64_t num_runs, uint64_t seed) {
-    // 16 run bytes per thread, stored as one uint4
+__global__ void synth_runs_kernel(uint8_t *__restrict__ runs, uint64_t num_runs, uint64_t seed, uint64_t first) {
+    // 16 run bytes per thread, stored as one uint4; runs[i] = byte first + i of the stream
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nvec = num_runs / 16;
@@ -291,12 +291,12 @@ __global__ void synth_runs_kernel(uint8_t *__restrict__ runs, uint64_t num_runs,
             uint32_t x = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                x |= (uint32_t)synth_run_byte(seed, v * 16 + (uint64_t)(d * 4 + k)) << (8 * k);
+                x |= (uint32_t)synth_run_byte(seed, first + v * 16 + (uint64_t)(d * 4 + k)) << (8 * k);
             wds[d] = x;
         }
         reinterpret_cast<uint4 *>(runs)[v] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
     }
-    if (gid < (num_runs & 15)) runs[nvec * 16 + gid] = synth_run_byte(seed, nvec * 16 + gid);
+    if (gid < (num_runs & 15)) runs[nvec * 16 + gid] = synth_run_byte(seed, first + nvec * 16 + gid);
 }
 
 // K-mers that occur in the index: start at a random row r, emit F(r) as the last symbol, then
@@ -898,10 +898,10 @@ hipError_t launch_match_reads(const void *d_reads, const void *d_len, size_t n, 
     return hipGetLastError();
 }
 
-hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream) {
+hipError_t launch_synth_runs(void *d_runs, uint64_t num_runs, uint64_t seed, hipStream_t stream, uint64_t first) {
     if (num_runs == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_runs_kernel, dim3(grid_for(256 * 16, num_runs, 16384)), dim3(256), 0,
-                       stream, (uint8_t *)d_runs, num_runs, seed);
+                       stream, (uint8_t *)d_runs, num_runs, seed, first);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ constexpr uint64_t WLREC_DEAD = 1ull << 63;
 
 __global__ void wl_init_counts_kernel(unsigned long long *__restrict__ counts, uint32_t nshards, unsigned long long first) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nshards) counts[i] = first;
+    if (i < nshards) counts[(size_t)i * WL_COUNT_STRIDE] = first;
 }
 
 struct wl_rec {
@@ -113,14 +113,51 @@ wl_own_kernel(const ulonglong2 *__restrict__ own, const uint8_t *__restrict__ va
     atomicOr(hit_bits + s * hit_map_words(mv) + (canon >> 6), 1ull << (canon & 63u));
 }
 
-// Occ of symbol b (1..4) up to offset o (1-based, within the line's own pieces: o <= span) of a staged line
-__device__ __forceinline__ uint64_t staged_occ(const staged_line &L, const line_head &h, uint32_t cq, uint32_t start,
-                                               const uint32_t r6[6], uint32_t o, uint32_t b) {
-    const uint32_t hb = read_half(L, b);
-    const uint32_t mq = matched24(L, HDR_DWORDS + 6u * (cq & 2u), b);
-    const char_rank cr = char_rank24(r6, o - start, b);
-    (void)h;
-    return read_count(L, b) + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? mq : 0u) + cr.occ;
+// Occ of the THREE symbols other than `skip` (0..3 = A..T) up to offset o (1-based, within the line's own pieces:
+// o <= span) of a staged line: out[a] for a = 0..3 (out[skip] is left alone).  One look at the quarter's 24 pieces for
+// all of them: the running symbol totals, the dword holding the position and its prefix sums do not depend on the
+// symbol (rank_device.h, char_rank24, taken apart).
+__device__ __forceinline__ void staged_occ3(const staged_line &L, const line_head &h, uint32_t o, uint32_t skip, uint64_t out[4]) {
+    const uint32_t cq = (o > h.s1 ? 1u : 0u) + (o > h.s2 ? 1u : 0u) + (o > h.s3 ? 1u : 0u);
+    const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
+    const uint32_t rem = o - start;  // >= 1
+    uint32_t r[6], e[6];  // the quarter holding the position; the earlier quarter of its half (added whole when cq is odd)
+    load24(L, HDR_DWORDS + 6u * cq, r);
+    load24(L, HDR_DWORDS + 6u * (cq & 2u), e);
+    uint32_t cum[6];
+    cum[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cum[i + 1] = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, 0x01010101u, cum[i], false);
+    uint32_t x = r[0], base = 0, di = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        const bool past = rem > cum[i];
+        x = past ? r[i] : x;
+        base = past ? cum[i] : base;
+        di = past ? (uint32_t)i : di;
+    }
+    const uint32_t rd = rem - base;
+    const uint32_t ps = (x & 0x1F1F1F1Fu) * 0x01010101u;
+    const uint32_t jj = (rd > (ps & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 8) & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 16) & 0xFFu) ? 1u : 0u);
+    const uint32_t here = (x >> (8u * jj + 5u)) & 7u;
+    const uint32_t pj = jj ? __builtin_amdgcn_ubfe(ps, 8u * jj - 8u, 8u) : 0u;
+    const uint32_t xm = x & ((1u << (8u * jj)) - 1u);
+    const uint32_t reach = rd <= (ps >> 24) ? rd - pj : (ps >> 24) - pj;
+#pragma unroll
+    for (uint32_t a = 0; a < 4u; ++a) {
+        if (a == skip) continue;
+        const uint32_t b = a + 1u, bb = splat_byte(b);
+        uint32_t before = 0, mc = 0, me = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            mc = dword_matched(r[i], bb, mc);
+            before = (uint32_t)(i + 1) <= di ? mc : before;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) me = dword_matched(e[i], bb, me);
+        const uint32_t inner = dword_matched(xm, bb, 0u);
+        out[a] = read_count(L, b) + (cq >= 2u ? read_half(L, b) : 0u) + ((cq & 1u) ? me : 0u) + before + inner + (here == b ? reach : 0u);
+    }
 }
 
 // ---- 2. the step of the three substituted symbols at every traced position
@@ -144,7 +181,10 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
     const size_t items = m * tn;  // per shard (< 2^32: the caller's condition)
     const uint32_t waves_total = gridDim.x * WG_WAVES, wave_id = blockIdx.x * WG_WAVES + wave;
     unsigned long long w_lines = 0, w_items = 0, w_surv = 0, w_unstepped = 0;
-    for (uint32_t sid = 0; sid < nshards; ++sid) {
+    // (workgroups start on different shards: the lists' counters are one address per shard, and every wave appending
+    // to the same one at the same time serialises on it -- 30 ms for 5e7 items before this and the single atomic below)
+    uint32_t sid = blockIdx.x % nshards;
+    for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
         const shard_view *sv = shards + sid;
         const char *lines_bytes = reinterpret_cast<const char *>(sv->lines);
         const uint32_t S = sv->sp.S, nlines = (uint32_t)sv->nlines;
@@ -154,7 +194,7 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
         ulonglong2 *wl_s = wl + (size_t)sid * wl_cap * 2u;
         ulonglong2 *sparse_s = sparse + (size_t)sid * mv;
         unsigned long long *bits_s = hit_bits + (size_t)sid * hit_map_words(mv);
-        unsigned long long *count = wl_counts + sid;
+        unsigned long long *count = wl_counts + (size_t)sid * WL_COUNT_STRIDE;
         for (size_t t0 = (size_t)wave_id * 64u; t0 < items; t0 += (size_t)waves_total * 64u) {
             const size_t t = t0 + lane;
             bool have = t < items;
@@ -186,6 +226,7 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                 }
             }
             const bool needL = have && lo != 0ull;
+            const uint32_t orig = (uint32_t)((word >> (2u * j)) & 3u);  // (its own step is the traced search's: not taken again)
             uint64_t occL[4] = {0, 0, 0, 0}, occU[4] = {0, 0, 0, 0};
             bool gotU = false, spill = false;
             // ---- pass A: the line of lower - 1 (or, at lower = 0, of upper)
@@ -200,24 +241,12 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                     const line_head h = read_head(L);
                     if (needL) {
                         if (oL > h.span) spill = true;
-                        else {
-                            const uint32_t cq = (oL > h.s1 ? 1u : 0u) + (oL > h.s2 ? 1u : 0u) + (oL > h.s3 ? 1u : 0u);
-                            const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
-                            uint32_t r6[6];
-                            load24(L, HDR_DWORDS + 6u * cq, r6);
-#pragma unroll
-                            for (uint32_t b = 1; b <= 4u; ++b) occL[b - 1u] = staged_occ(L, h, cq, start, r6, oL, b);
-                        }
+                        else staged_occ3(L, h, oL, orig, occL);
                     }
                     if (!spill && (!needL || wU == wL)) {  // upper out of the same staged line
                         if (oU > h.span) spill = true;
                         else {
-                            const uint32_t cq = (oU > h.s1 ? 1u : 0u) + (oU > h.s2 ? 1u : 0u) + (oU > h.s3 ? 1u : 0u);
-                            const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
-                            uint32_t r6[6];
-                            load24(L, HDR_DWORDS + 6u * cq, r6);
-#pragma unroll
-                            for (uint32_t b = 1; b <= 4u; ++b) occU[b - 1u] = staged_occ(L, h, cq, start, r6, oU, b);
+                            staged_occ3(L, h, oU, orig, occU);
                             gotU = true;
                         }
                     }
@@ -234,54 +263,55 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                 if (needB) {
                     const line_head h = read_head(L);
                     if (oU > h.span) spill = true;
-                    else {
-                        const uint32_t cq = (oU > h.s1 ? 1u : 0u) + (oU > h.s2 ? 1u : 0u) + (oU > h.s3 ? 1u : 0u);
-                        const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
-                        uint32_t r6[6];
-                        load24(L, HDR_DWORDS + 6u * cq, r6);
-#pragma unroll
-                        for (uint32_t b = 1; b <= 4u; ++b) occU[b - 1u] = staged_occ(L, h, cq, start, r6, oU, b);
-                    }
+                    else staged_occ3(L, h, oU, orig, occU);
                 }
             }
             // ---- the three substitutions of position j: updateInterval (query.cpp:11-15) with the substituted symbol
-            const uint32_t orig = (uint32_t)((word >> (2u * j)) & 3u);
+            uint64_t nlo[3], nhi[3];
+            bool enq[3];
+            uint64_t masks[3];
 #pragma unroll
             for (uint32_t d = 0; d < 3u; ++d) {
                 const uint32_t alt = d < orig ? d : d + 1u;  // the d-th base of ACGT without the original one
                 const uint64_t cb = alt == 0u ? c1 : alt == 1u ? c2 : alt == 2u ? c3 : c4;
                 const uint64_t oL_ = alt == 0u ? occL[0] : alt == 1u ? occL[1] : alt == 2u ? occL[2] : occL[3];
                 const uint64_t oU_ = alt == 0u ? occU[0] : alt == 1u ? occU[1] : alt == 2u ? occU[2] : occU[3];
-                const uint64_t nlo = cb + oL_, nhi = cb + oU_ - 1ull;
-                const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * j));
-                const uint64_t canon = (uint64_t)q * V + 1ull + 3ull * j + d;
-                const bool stepped_live = have && !spill && nlo <= nhi;
+                nlo[d] = cb + oL_;
+                nhi[d] = cb + oU_ - 1ull;
+                const bool stepped_live = have && !spill && nlo[d] <= nhi[d];
                 const bool final_hit = stepped_live && j == 0u;
-                const bool enqueue = (stepped_live && j != 0u) || (have && spill);
+                enq[d] = (stepped_live && j != 0u) || (have && spill);
                 if (final_hit) {
-                    sparse_s[canon] = make_ulonglong2(nlo, nhi);
+                    const uint64_t canon = (uint64_t)q * V + 1ull + 3ull * j + d;
+                    sparse_s[canon] = make_ulonglong2(nlo[d], nhi[d]);
                     atomicOr(bits_s + (canon >> 6), 1ull << (canon & 63u));
                 }
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(enqueue);
-                if (mask != 0ull) {
-                    unsigned long long base = 0;
-                    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(count, (unsigned long long)__builtin_popcountll(mask));
-                    const uint32_t src = (uint32_t)__builtin_ctzll(mask);
-                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), src) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, src);
-                    if (enqueue) {
-                        const size_t slot = (size_t)base + (size_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                        if (slot < wl_cap) {  // (room for every variant: the caller's sizing)
-                            if (spill) wl_store(wl_s, slot, lo, j, hi, canon, vword);            // the step is the search kernel's
-                            else wl_store(wl_s, slot, nlo, j - 1u, nhi, canon, vword);           // already taken
-                        }
-                    }
-                    if (COUNT_WORK_BRANCH(work)) {
-                        w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enqueue && !spill));
-                        w_unstepped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enqueue && spill));
-                    }
+                masks[d] = __builtin_amdgcn_ballot_w64(enq[d]);
+                if (COUNT_WORK_BRANCH(work)) {
+                    w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64((enq[d] && !spill) || final_hit));
+                    w_unstepped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enq[d] && spill));
                 }
-                if (COUNT_WORK_BRANCH(work)) w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(final_hit));
+            }
+            // ONE append per wave and pass for the three rounds together
+            const uint32_t n0 = (uint32_t)__builtin_popcountll(masks[0]), n1 = (uint32_t)__builtin_popcountll(masks[1]);
+            const uint32_t total = n0 + n1 + (uint32_t)__builtin_popcountll(masks[2]);
+            if (total != 0u) {
+                unsigned long long base = 0;
+                if (lane == 0u) base = atomicAdd(count, (unsigned long long)total);
+                base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+                for (uint32_t d = 0; d < 3u; ++d) {
+                    if (!enq[d]) continue;
+                    const size_t slot = (size_t)base + (d >= 1u ? n0 : 0u) + (d >= 2u ? n1 : 0u) + (size_t)__builtin_popcountll(masks[d] & lt);
+                    if (slot >= wl_cap) continue;  // (room for every variant: the caller's sizing)
+                    const uint32_t alt = d < orig ? d : d + 1u;
+                    const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * j));
+                    const uint64_t canon = (uint64_t)q * V + 1ull + 3ull * j + d;
+                    if (spill) wl_store(wl_s, slot, lo, j, hi, canon, vword);              // the step is the search kernel's
+                    else wl_store(wl_s, slot, nlo[d], j - 1u, nhi[d], canon, vword);       // already taken
+                }
             }
         }
     }

@@ -65,7 +65,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
         // WL: `init` is the worklists, [nshards][wl_cap] records of two ulonglong2; wl_counts their lengths
         const ulonglong2 *init_s = WL ? init + (size_t)sid * wl_cap * 2u : init + (size_t)sid * Q;
-        const size_t Qs = WL ? (size_t)(wl_counts[sid] < wl_cap ? wl_counts[sid] : wl_cap) : Q;  // searches of this shard
+        const size_t Qs = WL ? (size_t)(wl_counts[(size_t)sid * WL_COUNT_STRIDE] < wl_cap ? wl_counts[(size_t)sid * WL_COUNT_STRIDE] : wl_cap) : Q;  // searches of this shard
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;

@@ -628,7 +628,7 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
     L->worklist = !no_worklist && tn > 0 && tn < k && k <= 32u && m * (size_t)tn < 0xFFFFFFFFull;
     L->wl_cap = L->worklist ? m * 3u * (size_t)k : 0;
     L->wl = L->worklist ? al(S * L->wl_cap * 32) : 0;
-    L->counts = L->worklist ? al(S * 8) : 0;
+    L->counts = L->worklist ? al(S * 8 * (size_t)WL_COUNT_STRIDE) : 0;
     L->total = L->trace + L->own + L->sparse + L->bits + L->blocks + L->wl + L->counts;
     return true;
 }
