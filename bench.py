@@ -223,6 +223,9 @@ def setup(a):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=c.dev)
+            # a CPU-side group for the waits around the second leg (--host cxx as rank 0's child): an RCCL barrier would
+            # leave a kernel spinning on every GPU for as long as the leg runs on them
+            c.cpu_group = dist.new_group(backend="gloo")
     c.L = rsb.lib()
     c.stream = torch.cuda.current_stream()
     c.sp = C.c_void_p(c.stream.cuda_stream)
@@ -711,21 +714,24 @@ def main():
         }
         if "shards_matching_oracle" in head:
             out["config"]["shards_matching_oracle"] = head["shards_matching_oracle"]
-        if world > 1 and not a.no_cxx_leg and not a.rehearse_on_one_gpu:
+        if world > 1 and not a.no_cxx_leg:
             # second leg: the same workload driven by ONE process over all the GPUs (the C++ host's shape).  Every rank has
             # closed its shards; rank 0 starts the leg as a child with a time limit and the others wait -- whatever happens
             # to it, the line above stands.
             c.torch.cuda.synchronize()
-            c.dist.barrier()
+            c.dist.barrier(group=getattr(c, "cpu_group", None))
             if c.rank == 0:
                 import subprocess
                 try:
-                    r = subprocess.run(cxx_leg_cmd(a), capture_output=True, text=True, timeout=a.cxx_leg_timeout)
+                    cmd = cxx_leg_cmd(a)
+                    if a.rehearse_on_one_gpu:  # (one device: the leg's control flow, not its gather)
+                        cmd[cmd.index("--gpus") + 1] = "1"
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.cxx_leg_timeout)
                     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     out["config"]["cxx_host"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-800:]}
                 except Exception as e:  # noqa: BLE001
                     out["config"]["cxx_host"] = {"error": repr(e)}
-            c.dist.barrier()
+            c.dist.barrier(group=getattr(c, "cpu_group", None))
     if c.rank == 0:
         print(json.dumps(out), flush=True)
     if c.world > 1:
@@ -765,7 +771,7 @@ def run_rows(a, c):
     t0 = time.time()
     shards, sset, _ = build_shards(a, c, mix)
     n_sym = min(int(g.getBWLen()) for g in shards)
-    if a.mode == "extract":  # the select samples of every shard first (built by a shard's first extraction)
+    if a.mode == "extract" and not L.rsbwt_opened_for_reads(shards[0].handle):  # the plain layout builds a shard's select samples on its first extraction: before the timed region
         one = torch.zeros(1, dtype=torch.int64, device=dev)
         o1 = torch.empty((1, 512), dtype=torch.uint8, device=dev)
         l1 = torch.empty(2, dtype=torch.int32, device=dev)

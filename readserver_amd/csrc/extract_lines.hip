@@ -493,11 +493,15 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
                     if (cnt >= bc) move = -1;
                 }
                 t = bc - cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(bc - cnt);
-                const uint32_t c1 = matched24(L, HDR_DWORDS, f), c2 = read_half(L, f);
-                const uint32_t c3 = c2 + matched24(L, HDR_DWORDS + 12u, f);
+                // which quarter holds the t-th f: the header says what the first half holds (c2); ONE whole-quarter sum
+                // -- of quarter 0 or of quarter 2, whichever half the argument falls in -- settles the rest
+                const uint32_t c2 = read_half(L, f);
                 const uint32_t tt = t > 4095u ? 4095u : t;
-                const uint32_t cq = (tt > c1 ? 1u : 0u) + (tt > c2 ? 1u : 0u) + (tt > c3 ? 1u : 0u);
-                const uint32_t before = cq == 0u ? 0u : cq == 1u ? c1 : cq == 2u ? c2 : c3;
+                const bool late = tt > c2;
+                const uint32_t mq = matched24(L, HDR_DWORDS + (late ? 12u : 0u), f);
+                const uint32_t cm = late ? c2 + mq : mq;  // f's in quarters 0..2 (late) / in quarter 0
+                const uint32_t cq = (late ? 2u : 0u) + (tt > cm ? 1u : 0u);
+                const uint32_t before = cq == 0u ? 0u : cq == 1u ? cm : cq == 2u ? c2 : cm;
                 const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
                 uint32_t r6[6], left = 0;
                 load24(L, HDR_DWORDS + 6u * cq, r6);
