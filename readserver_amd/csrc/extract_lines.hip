@@ -357,7 +357,7 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
     uint32_t otry = 0;  // windows tried past an open hint's reach
     // the psi hint of the window line last parsed (the line the walk now stands in)
     bool hv = false;
-    uint32_t hw0 = 0, hkk = 0;
+    uint32_t hw0 = 0, hkk = 0, roff = 0;  // (roff: where in its window the walk stands -- the row's offset among the hint's rows)
     uint64_t samp = 0;
     uint32_t cont = 0, cblk = 0, cdw = 0;
     const uint32_t nwin = (uint32_t)sv->nwin;
@@ -451,6 +451,7 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
         if (asking) {
             uint32_t pin;
             const uint32_t hwin = fast_window(idx, S, inv, pin);
+            roff = pin;
             line = hwin + (hwin >> GROUP_SHIFT);
             if (line >= nlines) line = 0;
         }
@@ -513,7 +514,8 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
                     // (nothing of this line is of use)
                 } else if (left == 0u && start + p < h.span) {
                     found = true;
-                    pos = (uint64_t)wcur * S + poff + start + p;
+                    roff = poff + start + p;
+                    pos = (uint64_t)wcur * S + roff;
                 } else if (h.kind == KIND_FAR) {
                     cblk = L.dword(LINE_DWORDS - 1u);
                     if (cblk >= nlines) cblk = 0;
@@ -540,7 +542,8 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
                 const uint32_t p = select_in24(r6, f, tc > 4095u ? 4095u : tc, &left);
                 const uint32_t csym = (hd.x >> 24) | ((hd.y >> 24) << 8);  // symbols the chunk holds; the next chunk follows
                 found = tc != 0u && left == 0u && p < csym;
-                pos = (uint64_t)wcur * S + poff + p;
+                roff = poff + p;
+                pos = (uint64_t)wcur * S + roff;
                 if (!found) move = 1;
             }
             bool to_sample = false;
@@ -639,10 +642,9 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
                 // row lies in f's block too.
                 bool via_hint = false;
                 if (hv && hw0 != HINT_NONE) {
-                    uint32_t pin;
-                    const uint64_t r0 = (uint64_t)fast_window(idx, S, inv, pin) * S;  // (the walk stands in idx's window)
-                    if (r0 >= cf && idx >= r0 && idx - r0 < S) {
-                        const hint_range hr = hint_windows(hw0, hkk, (uint32_t)(idx - r0), hshift);
+                    const uint64_t r0 = idx - roff;  // the first row of the window the walk stands in
+                    if (r0 >= cf && roff < S) {
+                        const hint_range hr = hint_windows(hw0, hkk, roff, hshift);
                         if (hr.hi < nwin && hr.lo <= hr.hi) {
                             wlo = hr.lo;
                             whi = hr.hi;

@@ -83,15 +83,16 @@ wl_table_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const u
         if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix.n) {
             lo = e & COUNT_MASK;
             hi = lo + width - 1ull;
-            live = width != 0u;
             j = tn - 1u;  // (tn >= 1: with nothing left of the table's reach this pipeline is not used)
         } else {  // not tabulated (or not an interval of this BWT): initInterval, query.cpp:18-21
             const uint32_t b = (uint32_t)((vword >> (2u * (k - 1u))) & 3u) + 1u;
             lo = ix.C[b];
             hi = ix.C[b] + ix.total[b] - 1ull;
-            live = ix.total[b] != 0ull;
             j = k - 2u;
         }
+        // the reference's unsigned compare (query.cpp:35): an empty interval at row 0 is (0, 2^64 - 1) and LIVES -- a
+        // BWT without '$' carries it through every further step and reports it; every other empty interval ends here
+        live = lo <= hi;
     }
     const size_t slot = q * per + r;
     if (live) wl_store(wl_s, slot, lo, j, hi, canon, vword);
@@ -206,9 +207,10 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                 const ulonglong2 tr = trace_s[t];
                 lo = tr.x;
                 hi = tr.y;
-                // an invalid k-mer's trace was never written; an absent suffix, or the reference's (0, 2^64-1) carry
-                // (query.cpp:35, rlebwt.cpp:269), has no variant that occurs
-                have = valid[q] != 0 && lo <= hi && hi != ~0ull;
+                // an invalid k-mer's trace was never written; an absent suffix has no variant that occurs.  (The
+                // reference's (0, 2^64 - 1) carry -- query.cpp:35, rlebwt.cpp:269 -- is a live interval by its unsigned
+                // compare: Occ(b, -1) = 0 on both sides, no line is needed)
+                have = valid[q] != 0 && lo <= hi;
                 if (have) word = packed[q];
             }
             if (COUNT_WORK_BRANCH(work)) w_items += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
@@ -220,30 +222,32 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                     wL = fast_window(lo - 1ull, S, inv, pin);
                     oL = pin + 1u;
                 }
-                if (have) {
+                if (have && hi != ~0ull) {
                     wU = fast_window(hi, S, inv, pin);
                     oU = pin + 1u;
                 }
             }
             const bool needL = have && lo != 0ull;
+            const bool needU = have && hi != ~0ull;  // (Occ(b, 2^64 - 1) = Occ(b, -1) = 0: rlebwt.cpp:269)
             const uint32_t orig = (uint32_t)((word >> (2u * j)) & 3u);  // (its own step is the traced search's: not taken again)
             uint64_t occL[4] = {0, 0, 0, 0}, occU[4] = {0, 0, 0, 0};
-            bool gotU = false, spill = false;
+            bool gotU = !needU, spill = false;
             // ---- pass A: the line of lower - 1 (or, at lower = 0, of upper)
             {
                 const uint32_t wA = needL ? wL : wU;
                 uint32_t line = wA + (wA >> GROUP_SHIFT);
                 if (line >= nlines) line = 0;
-                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
-                glds_fetch(lines_bytes, have ? line : ~0u, lane, stage_lds);
+                const bool fetchA = needL || needU;
+                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fetchA));
+                glds_fetch(lines_bytes, fetchA ? line : ~0u, lane, stage_lds);
                 glds_wait();
-                if (have) {
+                if (fetchA) {
                     const line_head h = read_head(L);
                     if (needL) {
                         if (oL > h.span) spill = true;
                         else staged_occ3(L, h, oL, orig, occL);
                     }
-                    if (!spill && (!needL || wU == wL)) {  // upper out of the same staged line
+                    if (!spill && needU && (!needL || wU == wL)) {  // upper out of the same staged line
                         if (oU > h.span) spill = true;
                         else {
                             staged_occ3(L, h, oU, orig, occU);

@@ -615,3 +615,43 @@ def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices):
     for sh in by_dev:
         for g in sh:
             g.close()
+
+
+def test_gpu_set_hits_1mm_worklists_keep_the_references_unsigned_carry(rsb):
+    """A BWT without '$' whose rows all begin with one symbol: an empty interval at row 0 is (0, 2^64 - 1) and LIVES by
+    the reference's unsigned compare (query.cpp:35, rlebwt.cpp:269) -- every variant of every k-mer then 'occurs'.  The
+    set's hit lists (worklists: csrc/mm1_worklist.hip) must report exactly what each shard's own list (round 3's
+    launches) reports; found by the fuzz campaign (seed 77) on the first worklist build, which dropped the carry."""
+    import torch
+    L = rsb.lib()
+    k, m = 31, 60
+    rng = np.random.default_rng(5)
+    shards = [rsb.GpuBWT(runs=np.full(227, (4 << 5) | 31, np.uint8), ktab_depth=4),            # 7,037 x 'T', no '$'
+              rsb.GpuBWT(runs=((rng.integers(0, 5, 40000).astype(np.uint8) << 5) | rng.integers(1, 32, 40000).astype(np.uint8)), ktab_depth=4),
+              rsb.GpuBWT(runs=np.full(1, (2 << 5) | 31, np.uint8), ktab_depth=4)]               # 31 x 'C'
+    ss = rsb.ShardSet(shards)
+    assert L.rsbwt_set_hits_1mm_is_fused(ss._s, m, k) == 1
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (m, k))].copy()
+    km[0] = ord("T")
+    km[1] = ord("C")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    d_km = torch.from_numpy(km).cuda()
+    d_pk = torch.empty((m, 1), dtype=torch.int64, device="cuda")
+    d_ok = torch.empty(m, dtype=torch.uint8, device="cuda")
+    cap = m * (3 * k + 1)
+    d_h = torch.zeros((3, cap, 4), dtype=torch.int64, device="cuda")
+    d_t = torch.zeros(3, dtype=torch.int64, device="cuda")
+    d_s = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device="cuda")
+    assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+    assert L.rsbwt_set_hits_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_h), cap, p(d_t), p(d_s), None) == 0
+    torch.cuda.synchronize()
+    for si, g in enumerate(shards):
+        mine = rsb.hits_1mm_batch(g, km)
+        rec = d_h[si, :int(d_t[si].item())].cpu().numpy().view(np.uint64)
+        assert rec.shape[0] == len(mine), (si, rec.shape[0], len(mine))
+        assert np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
+        assert np.array_equal(rec[:, 2] // (3 * k + 1), mine["query"].astype(np.uint64))
+    assert int(d_t[0].item()) == cap  # (every variant 'occurs' in the shard whose rows all begin with 'T', the largest symbol: C[] = 0 throughout)
+    ss.close()
+    for g in shards:
+        g.close()

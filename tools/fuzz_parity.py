@@ -96,11 +96,14 @@ while time.time() < t_end:
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
                     ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
                            np.array_equal(slo[1], e2lo) and np.array_equal(sup[1], e2up))
+                    why = [] if ok2 else ["set intervals"]
                     # configs[3] / configs[4] over the set: every shard's own list / reads, side by side
                     if k <= 40:
                         sh, first = ss.hits_1mm(km[:60])
-                        ok2 = ok2 and np.array_equal(sh[int(first[0]):int(first[1])], rsb.hits_1mm_batch(g, km[:60]))
-                        ok2 = ok2 and np.array_equal(sh[int(first[1]):int(first[2])], rsb.hits_1mm_batch(g2, km[:60]))
+                        ok_h = np.array_equal(sh[int(first[0]):int(first[1])], rsb.hits_1mm_batch(g, km[:60])) and np.array_equal(sh[int(first[1]):int(first[2])], rsb.hits_1mm_batch(g2, km[:60]))
+                        if not ok_h:
+                            why.append("set hits_1mm (host) vs the shards' own lists")
+                        ok2 = ok2 and ok_h
                         # the device-resident form (fused launches when both tables have one depth) leaves the same lists
                         import torch
                         p_ = lambda t: C.c_void_p(t.data_ptr())
@@ -118,8 +121,11 @@ while time.time() < t_end:
                         for si in range(2):
                             mine = sh[int(first[si]):int(first[si + 1])]
                             rec = d_h[si, :int(d_t[si].item())].cpu().numpy().view(np.uint64)
-                            ok2 = ok2 and rec.shape[0] == len(mine) and np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
-                            ok2 = ok2 and np.array_equal(rec[:, 2] // (3 * k + 1), mine["query"].astype(np.uint64))
+                            ok_d = rec.shape[0] == len(mine) and np.array_equal(rec[:, 0], mine["lower"]) and np.array_equal(rec[:, 1], mine["upper"])
+                            ok_d = ok_d and np.array_equal(rec[:, 2] // (3 * k + 1), mine["query"].astype(np.uint64))
+                            if not ok_d:
+                                why.append(f"set hits_1mm_dev shard {si}: {rec.shape[0]} records against {len(mine)}")
+                            ok2 = ok2 and ok_d
                     # read extraction over the set, device-resident: ONE launch sequence walks the rows of both shards
                     # (csrc/extract_lines.hip), against each shard's own host call
                     import torch
@@ -138,8 +144,11 @@ while time.time() < t_end:
                         l1, p1 = np.empty(nr_, np.uint32), np.empty(nr_, np.uint32)
                         assert L.rsbwt_extract(gg.handle, rws[si].ctypes.data, nr_, o1.ctypes.data, 512, l1.ctypes.data, p1.ctypes.data) == 0
                         gl, gp, go = d_l[si].cpu().numpy().view(np.uint32), d_p[si].cpu().numpy().view(np.uint32), d_o[si].cpu().numpy()
-                        ok2 = ok2 and np.array_equal(gl, l1) and np.array_equal(gp[l1 != 0xFFFFFFFF], p1[l1 != 0xFFFFFFFF])
-                        ok2 = ok2 and all(np.array_equal(go[i, :l1[i]], o1[i, :l1[i]]) for i in range(nr_) if l1[i] != 0xFFFFFFFF)
+                        ok_x = np.array_equal(gl, l1) and np.array_equal(gp[l1 != 0xFFFFFFFF], p1[l1 != 0xFFFFFFFF])
+                        ok_x = ok_x and all(np.array_equal(go[i, :l1[i]], o1[i, :l1[i]]) for i in range(nr_) if l1[i] != 0xFFFFFFFF)
+                        if not ok_x:
+                            why.append(f"set extract_dev shard {si}")
+                        ok2 = ok2 and ok_x
                     # query() in every shard, lists concatenated per k-mer -- for k-mers whose intervals are narrow in
                     # both shards (every row of an interval is extracted into a 2 KB buffer: a 1-mer's would be gigabytes)
                     w1 = np.where(eup[:5000] >= elo[:5000], eup[:5000] - elo[:5000] + 1, 0)
@@ -159,10 +168,12 @@ while time.time() < t_end:
                                     except AssertionError:
                                         exp = None
                             if exp is not None and all(len(t) <= 2048 for _, t in exp):
+                                if lst != exp:
+                                    why.append("set query lists")
                                 ok2 = ok2 and lst == exp
                     ss.close()
                 oix2.close()
-                assert ok2, "shard set"
+                assert ok2, "shard set: " + "; ".join(sorted(set(why)))
                 cfg["set"] = True
             if k <= 40:
                 # (now and then enough variant searches for the resumed launch to take the one-lane-per-search kernel)
