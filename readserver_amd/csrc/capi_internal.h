@@ -67,9 +67,9 @@ inline bool view_is_narrow(const shard_view &v, uint32_t k) {
 }
 // the worklist launch of a set's 1-mismatch search (kernels.h), metered like search_launch; the counters ACCUMULATE
 // onto what the traced launch and the branch kernel left
-int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_worklists,
-                           const void *d_counts, size_t wl_cap, size_t result_slots, uint32_t k, void *d_sparse, void *d_hit_bits,
-                           hipStream_t stream);
+int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
+                           const void *d_valid, size_t nkmers, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
+                           uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream);
 int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
 // 1-mismatch hit list of one shard from variants expanded once for the whole batch (sets.hip: every shard of a set
 // searches the same variants)

@@ -85,24 +85,27 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr, const search_extra *extra = nullptr);
 uint32_t trace_entries(const shard_view &ix, uint32_t k);
-// The 1-mismatch search of a set as worklists of live searches (mm1_worklist.hip; k <= 32, 0 < tn < k, one table depth
-// k - tn for all shards).  launch_mm1_worklists fills them from the traced search's output (d_trace [nshards][m][tn],
-// d_own [nshards][m] pairs): d_worklists [nshards][wl_cap] x 32 B, wl_cap >= m * 3k, d_counts u64[nshards * WL_COUNT_STRIDE] their lengths (entry s at s * WL_COUNT_STRIDE);
-// hits that need no further step go straight to d_sparse [nshards][mv] / d_hit_bits.  d_branch_work (optional, zeroed
-// by the caller): the search launches' counter words (WORK_*): steps += 3 per item, lookups += 2, lines fetched; word 13 =
+// The 1-mismatch search of a set by worklist (mm1_worklist.hip; k <= 32, 0 < tn < k, one table depth k - tn for all
+// shards).  launch_mm1_worklists takes the step of the three substitutions of every traced position (d_trace
+// [nshards][m][tn], d_own [nshards][m] pairs: the traced search's output) and appends the variants that survive it to
+// d_worklists [nshards][wl_cap] x 32 B, wl_cap >= m * 3 * tn; d_counts u64[nshards * WL_COUNT_STRIDE] their lengths (entry s
+// at s * WL_COUNT_STRIDE); hits that need no further step go straight to d_sparse [nshards][mv] / d_hit_bits.  d_branch_work
+// (optional): the search launches' counter words (WORK_*): steps += 3 per item, lookups += 2, lines fetched; word 13 =
 // variants alive after the step, 14 = variants passed on unstepped.
-// launch_search_worklist then runs them (search_solo.h, WL): results at the records' own indices.
+// launch_search_worklist then runs, per shard, the m * 3 (k - tn) variants substituted inside the tables' reach -- no
+// records: the kernel spells them out and reads their table entries itself (search_solo.h, WL) -- and the appended
+// records: results at the variants' canonical indices.
 // (the lists' lengths sit WL_COUNT_STRIDE u64 apart: appended to by every wave of the branch kernel, they must not share
-// a cache line -- eight counters in one line serialised the kernel at one atomic at a time: 10 ms instead of 2)
+// a cache line -- eight counters in one line serialised the kernel at one atomic at a time: 10 ms instead of 3)
 constexpr uint32_t WL_COUNT_STRIDE = 32;
 hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t m,
                                 uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,
                                 void *d_counts, void *d_sparse, void *d_hit_bits, int num_cus, hipStream_t stream,
                                 unsigned long long *d_branch_work = nullptr);
-hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_worklists,
-                                  const void *d_counts, size_t wl_cap, size_t result_slots, uint32_t k, void *d_sparse, void *d_hit_bits,
-                                  unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,
-                                  hipEvent_t ev1 = nullptr);
+hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                                  const void *d_valid, size_t m, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
+                                  uint32_t k, void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus,
+                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 constexpr int WORK_WORDS = 16;  // counters of a counting launch (search_lines.hip, WORK_*)
 
 // k-mer table: fills d_entries[c * stride], c < 4^T, by searching every T-mer.  `view` is the host copy

@@ -11,12 +11,13 @@
 //   2. wl_branch_kernel: one lane per (shard, k-mer, position j < tn) takes the step of ALL THREE substituted symbols
 //      off one fetch of the interval's line(s) -- one line where the old launch read three -- and only the variants
 //      that SURVIVE the step (1 in 20) become searches: a worklist record with their interval after the step;
-//   3. wl_table_kernel: the variants substituted inside the k-mer table's reach start from their own table entry
-//      (findInterval's answer for their last T symbols), one record each, at a slot of their own (no atomics: nearly
-//      every entry is a live interval when 4^T << n);
-//   4. search_solo_kernel<WL> (search_solo.h) runs the worklists: a take-up is one 32-byte record, no start-record
-//      launch, no variants spelled out in memory; results go to the variant's canonical index (sparse results + hit
-//      map), so the ordered hit lists come out of the same compaction as before;
+//   3. the variants substituted inside the k-mer table's reach start from their own table entry (findInterval's
+//      answer for their last T symbols): they need no record -- search_solo_kernel<WL> spells them out of the k-mer's
+//      packed word and reads the entry itself, two passes ahead of taking the search up (the first version wrote a
+//      32-byte record per variant with a kernel of its own: 1.6 ms and a tenth of the search launch's requests);
+//   4. search_solo_kernel<WL> (search_solo.h) runs both: the implicit items, then the appended records -- a take-up
+//      is one 32-byte read, no start-record launch, no variants spelled out in memory; results go to the variant's
+//      canonical index (sparse results + hit map), so the ordered hit lists come out of the same compaction as before;
 //   5. wl_own_kernel: the k-mers' own intervals (the traced launch's results) are variant 0's hits.
 //
 // Worklist record (32 B): x = lower (40 bits) | next symbol j << 40 (16 bits) | WL_DEAD << 63;  y = upper;
@@ -33,7 +34,6 @@ namespace rsb {
 
 namespace {
 
-constexpr uint64_t WLREC_DEAD = 1ull << 63;
 #define COUNT_WORK_BRANCH(w) ((w) != nullptr)  // (wave-uniform: the counters cost a branch when they are off)
 
 __global__ void wl_init_counts_kernel(unsigned long long *__restrict__ counts, uint32_t nshards, unsigned long long first) {
@@ -48,56 +48,6 @@ struct wl_rec {
 __device__ __forceinline__ void wl_store(ulonglong2 *wl, size_t slot, uint64_t lo, uint32_t j, uint64_t hi, uint64_t canon, uint64_t word) {
     wl[2u * slot] = make_ulonglong2((lo & COUNT_MASK) | ((uint64_t)(j & 0xFFFFu) << COUNT_BITS), hi);
     wl[2u * slot + 1u] = make_ulonglong2(canon, word);
-}
-
-// ---- 3. the variants substituted inside the table's reach: thread per (k-mer, r = 3 * (position - tn) + alternative,
-// shard), adjacent lanes = the shards of one variant (interleaved k-mer tables: one stretch per variant).  Slot
-// (q * 3T + r) of shard s's worklist; a variant whose entry is empty (or whose k-mer is invalid) leaves a dead record.
-__global__ void __launch_bounds__(256)
-wl_table_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
-                const uint8_t *__restrict__ valid, size_t m, uint32_t k, uint32_t tn, ulonglong2 *__restrict__ wl, size_t wl_cap,
-                ulonglong2 *__restrict__ sparse, unsigned long long *__restrict__ hit_bits, size_t mv) {
-    const uint32_t T = k - tn, per = 3u * T;
-    const size_t t_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t_ >= m * per * nshards) return;
-    const size_t i = t_ / nshards;
-    const uint32_t s = (uint32_t)(t_ - i * nshards);
-    const size_t q = i / per;
-    const uint32_t r = (uint32_t)(i - q * per);
-    const uint32_t p = tn + r / 3u, d = r % 3u;
-    const shard_view &ix = shards[s];
-    ulonglong2 *wl_s = wl + (size_t)s * wl_cap * 2u;
-    const uint64_t V = 3ull * k + 1ull;
-    const uint64_t canon = q * V + 1ull + 3ull * p + d;
-    const uint64_t word = packed[q];
-    const uint32_t orig = (uint32_t)((word >> (2u * p)) & 3u);
-    const uint32_t alt = d < orig ? d : d + 1u;
-    const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * p));
-    bool live = valid[q] != 0;
-    uint64_t lo = 0, hi = 0;
-    uint32_t j = 0;
-    if (live) {
-        const uint64_t code = (vword >> (2u * tn)) & ((1ull << (2u * T)) - 1ull);
-        const uint64_t e = ix.ktab[code * ix.ktab_stride];
-        const uint32_t width = (uint32_t)(e >> COUNT_BITS);
-        if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix.n) {
-            lo = e & COUNT_MASK;
-            hi = lo + width - 1ull;
-            j = tn - 1u;  // (tn >= 1: with nothing left of the table's reach this pipeline is not used)
-        } else {  // not tabulated (or not an interval of this BWT): initInterval, query.cpp:18-21
-            const uint32_t b = (uint32_t)((vword >> (2u * (k - 1u))) & 3u) + 1u;
-            lo = ix.C[b];
-            hi = ix.C[b] + ix.total[b] - 1ull;
-            j = k - 2u;
-        }
-        // the reference's unsigned compare (query.cpp:35): an empty interval at row 0 is (0, 2^64 - 1) and LIVES -- a
-        // BWT without '$' carries it through every further step and reports it; every other empty interval ends here
-        live = lo <= hi;
-    }
-    const size_t slot = q * per + r;
-    if (live) wl_store(wl_s, slot, lo, j, hi, canon, vword);
-    else wl_s[2u * slot] = make_ulonglong2(WLREC_DEAD, 0ull);
-    (void)sparse; (void)hit_bits; (void)mv;
 }
 
 // ---- 5. variant 0 = the k-mer itself: its traced search's result
@@ -337,16 +287,8 @@ hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, co
                                 unsigned long long *d_branch_work) {
     if (m == 0 || nshards == 0) return hipSuccess;
     if (tn == 0 || tn >= k || k > 32u) return hipErrorInvalidValue;
-    const uint32_t T = k - tn;
     const size_t mv = m * (3 * (size_t)k + 1);
-    // the table part fills slots 0 .. m * 3T of every shard's list; the survivors of the branch step are appended
-    // behind them: the lists' lengths start there
-    hipLaunchKernelGGL(wl_init_counts_kernel, dim3((nshards + 255u) / 256u), dim3(256), 0, stream, (unsigned long long *)d_counts, nshards,
-                       (unsigned long long)(m * 3u * T));
-    const size_t nt = m * 3u * T * nshards;
-    hipLaunchKernelGGL(wl_table_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, d_shards, nshards,
-                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, m, k, tn, (ulonglong2 *)d_worklists, wl_cap,
-                       (ulonglong2 *)d_sparse, (unsigned long long *)d_hit_bits, mv);
+    hipLaunchKernelGGL(wl_init_counts_kernel, dim3((nshards + 255u) / 256u), dim3(256), 0, stream, (unsigned long long *)d_counts, nshards, 0ull);
     const size_t no = m * nshards;
     hipLaunchKernelGGL(wl_own_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream, (const ulonglong2 *)d_own,
                        (const uint8_t *)d_valid, nshards, m, k, (ulonglong2 *)d_sparse, (unsigned long long *)d_hit_bits, mv);

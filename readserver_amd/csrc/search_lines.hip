@@ -713,17 +713,19 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
 
 // The worklists of a set's 1-mismatch search (mm1_worklist.hip): every record a live search, the lists' lengths known
 // to the device only -- the grid is what the GPU holds at once, the pools end where the counts say.
-hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_worklists,
-                                  const void *d_counts, size_t wl_cap, size_t result_slots, uint32_t k, void *d_sparse, void *d_hit_bits,
-                                  unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    if (nshards == 0 || wl_cap == 0) return hipSuccess;
-    if (k > 32u) return hipErrorInvalidValue;
+hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                                  const void *d_valid, size_t m, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
+                                  uint32_t k, void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus,
+                                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (nshards == 0 || m == 0) return hipSuccess;
+    if (k > 32u || tn == 0 || tn >= k) return hipErrorInvalidValue;
     static const int wgs_per_cu = [] {
         const char *e = getenv("RSBWT_WAVE_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : RSB_MIN_WGS_PER_CU;
     }();
-    size_t g = (wl_cap * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
+    const size_t implicit = m * 3u * (size_t)(k - tn), mv = m * (3u * (size_t)k + 1u);
+    size_t g = ((implicit + wl_cap) * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;
     scratch_cache::lease mem;
@@ -736,17 +738,18 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
         return e;
     }
     if (ev0) (void)hipEventRecord(ev0, stream);
-    const uint32_t qchunk = 256;
+    uint32_t qchunk = 1024;
+    while (qchunk > 64u && (size_t)qchunk * g * WG_WAVES * 4u > implicit * nshards) qchunk >>= 1;
     if (d_work)
         hipLaunchKernelGGL((search_solo_kernel<true, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
-                           nshards, (const uint64_t *)nullptr, (const ulonglong2 *)d_worklists, (const uint8_t *)nullptr, ctr, result_slots, k, 1u,
-                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, 0u, qchunk, 2u,
-                           (const unsigned long long *)d_counts, wl_cap);
+                           nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, mv, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap, implicit);
     else
         hipLaunchKernelGGL((search_solo_kernel<false, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
-                           nshards, (const uint64_t *)nullptr, (const ulonglong2 *)d_worklists, (const uint8_t *)nullptr, ctr, result_slots, k, 1u,
-                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, 0u, qchunk, 2u,
-                           (const unsigned long long *)d_counts, wl_cap);
+                           nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, mv, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap, implicit);
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);
     scratch.give(mem, stream);

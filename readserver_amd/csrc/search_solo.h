@@ -20,11 +20,13 @@
 // fetch; the search is taken up once the entry has landed.  On one shard the start-record kernel made three
 // requests per search (table entry, record written, record read): this makes one.
 //
-// WL (the 1-mismatch search of a set, sets.hip): the searches are the records of a WORKLIST per shard -- 32 bytes
-// each: {lower | next symbol << 40, upper, result index, packed word} -- of a length only the device knows
-// (wl_counts[s], written by the kernels that filled the list): a take-up is one 32-byte read, the result goes to
-// the record's own index (sparse results + hit map, as `pairs == 2`), and a record flagged WL_DEAD is a slot its
-// producer left empty.
+// WL (the 1-mismatch search of a set, sets.hip / mm1_worklist.hip): a shard's searches are (1) wl_implicit items that
+// need no record at all -- item i = variant r = i % 3T of k-mer q = i / 3T, substituted inside the k-mer table's reach:
+// the lane spells the variant out of the k-mer's packed word and takes it into reserve in the two stages of FUSED
+// (packed word and validity byte, then the variant's own table entry) -- and (2) the records of a WORKLIST behind them,
+// 32 bytes each: {lower | next symbol << 40, upper, result index, packed word}, of a length only the device knows
+// (wl_counts[s], written by the kernel that appended them): one 32-byte read per take-up.  Results go to the
+// variant's canonical index (sparse results + hit map, as `pairs == 2`); a record flagged WL_DEAD is an empty slot.
 #ifndef RSBWT_SEARCH_SOLO_H
 #define RSBWT_SEARCH_SOLO_H
 
@@ -41,7 +43,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work,
                    ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs,
-                   const unsigned long long *__restrict__ wl_counts = nullptr, size_t wl_cap = 0) {
+                   const unsigned long long *__restrict__ wl_counts = nullptr, size_t wl_cap = 0, size_t wl_implicit = 0) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -65,7 +67,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
         // WL: `init` is the worklists, [nshards][wl_cap] records of two ulonglong2; wl_counts their lengths
         const ulonglong2 *init_s = WL ? init + (size_t)sid * wl_cap * 2u : init + (size_t)sid * Q;
-        const size_t Qs = WL ? (size_t)(wl_counts[(size_t)sid * WL_COUNT_STRIDE] < wl_cap ? wl_counts[(size_t)sid * WL_COUNT_STRIDE] : wl_cap) : Q;  // searches of this shard
+        const size_t Qs = WL ? wl_implicit + (size_t)(wl_counts[(size_t)sid * WL_COUNT_STRIDE] < wl_cap ? wl_counts[(size_t)sid * WL_COUNT_STRIDE] : wl_cap) : Q;  // searches of this shard
+        const uint32_t wl_tn = trace_n, wl_per = WL ? 3u * (k - trace_n) : 1u;  // (WL: trace_n carries tn; 3T implicit items per k-mer)
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + sid;
@@ -98,7 +101,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         bool has_n = false;
         ulonglong2 nrec = {0, 0};
         uint64_t nword = 0;
-        uint32_t nstage = 0;  // FUSED: 1 = the reserve's word and validity byte are in, 2 = its table entry too (in nrec.x)
+        uint32_t nstage = 0;  // FUSED / WL implicit items: 1 = the reserve's word and validity byte are in, 2 = its table entry too (in nrec.x)
+        bool nimp = false;    // WL: the reserve is an implicit item (nrec.y = validity | r << 8 | q << 32)
         int j = 0;
         uint64_t word = 0, lo = 0, hi = 0;
         // the step under way: sub 0 = looking up Occ(b, lower - 1), 1 = Occ(b, upper) with occL held;
@@ -128,17 +132,40 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     nrec.y = cb + tb - 1ull;
                 }
             }
-            if (WL && !has_q && has_n) {
+            if (WL && !has_q && has_n && nstage == 2u) {
                 has_q = true;
                 has_n = false;
-                q = nq;  // (the record's result index)
                 sub = 0;
                 cont = 0;
-                lo = nrec.x & COUNT_MASK;
-                hi = nrec.y;
-                j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
                 word = nword;
-                done = (nrec.x & WL_DEAD) != 0ull || lo > hi;
+                if (nimp) {
+                    // an implicit item: start_record() on the variant's own table entry (its word is spelled out already)
+                    const uint32_t r_ = (uint32_t)(nrec.y >> 8) & 0xFFu, q_ = (uint32_t)(nrec.y >> 32);
+                    const uint32_t pr = (r_ * 171u) >> 9;  // r / 3 (r < 96)
+                    q = (size_t)q_ * (3u * k + 1u) + 1u + 3u * (wl_tn + pr) + (r_ - 3u * pr);  // the variant's canonical index
+                    const uint64_t e = nrec.x;
+                    const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+                    if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix_n) {
+                        lo = e & COUNT_MASK;
+                        hi = lo + width - 1ull;
+                        j = (int)wl_tn - 1;
+                    } else {  // not tabulated (or not an interval of this BWT): initInterval, query.cpp:18-21
+                        const uint32_t bl = (uint32_t)((nword >> (2u * ((k - 1u) & 31u))) & 3u);
+                        const uint64_t cb = bl == 0u ? sc1 : bl == 1u ? sc2 : bl == 2u ? sc3 : sc4;
+                        const uint64_t tb = bl == 0u ? st1 : bl == 1u ? st2 : bl == 2u ? st3 : st4;
+                        lo = cb;
+                        hi = cb + tb - 1ull;
+                        j = (int)k - 2;
+                    }
+                    // (the reference's unsigned compare, query.cpp:35: an empty interval at row 0, (0, 2^64 - 1), lives)
+                    done = (nrec.y & 0xFFull) == 0ull || lo > hi || j < 0;
+                } else {
+                    q = nq;  // (the record's result index)
+                    lo = nrec.x & COUNT_MASK;
+                    hi = nrec.y;
+                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                    done = (nrec.x & WL_DEAD) != 0ull || lo > hi;
+                }
                 if (done) { lo = 1; hi = 0; }
             }
             if (!WL && !has_q && has_n && (!FUSED || nstage == 2u)) {
@@ -198,22 +225,40 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             }
             // (FUSED: a reserve whose table entry is still to come keeps the pass going -- it is taken up two passes
             // after it was drawn, and a wave whose lanes hold nothing else would otherwise spin here, or leave with it)
-            if (__builtin_amdgcn_ballot_w64(has_q || got_n || (FUSED && has_n)) == 0ull) {
+            if (__builtin_amdgcn_ballot_w64(has_q || got_n || ((FUSED || WL) && has_n)) == 0ull) {
                 if (drained) break;
                 continue;  // pool exhausted mid-pass: refill at the top
             }
             // the two start-up loads of a query taken into reserve fly with this pass's line fetches
             ulonglong2 rec = {0, 0};
             uint64_t first_word = 0;
-            const bool stage_b = FUSED && has_n && nstage == 1u;  // the reserve's word is in: its table entry now
+            const bool stage_b = (FUSED || WL) && has_n && nstage == 1u;  // the reserve's word is in: its table entry now
             uint64_t entry = 0;
-            uint64_t wl_index = 0;
+            uint64_t wl_index = 0, vword = 0;
+            bool imp = false;
             if (WL) {
                 if (got_n) {
-                    rec = init_s[2u * nq];
-                    const ulonglong2 r2 = init_s[2u * nq + 1u];
-                    wl_index = r2.x;
-                    first_word = r2.y;
+                    imp = nq < wl_implicit;
+                    if (imp) {
+                        const uint32_t i32 = (uint32_t)nq, q_ = i32 / wl_per, r_ = i32 - q_ * wl_per;
+                        first_word = packed[q_];
+                        rec.y = (uint64_t)valid[q_] | ((uint64_t)r_ << 8) | ((uint64_t)q_ << 32);
+                    } else {
+                        const size_t slot = nq - wl_implicit;
+                        rec = init_s[2u * slot];
+                        const ulonglong2 r2 = init_s[2u * slot + 1u];
+                        wl_index = r2.x;
+                        first_word = r2.y;
+                    }
+                }
+                if (stage_b) {  // spell the variant out, then its own table entry
+                    const uint32_t r_ = (uint32_t)(nrec.y >> 8) & 0xFFu;
+                    const uint32_t pr = (r_ * 171u) >> 9, d_ = r_ - 3u * pr, p_ = wl_tn + pr;
+                    const uint32_t orig = (uint32_t)((nword >> (2u * p_)) & 3u);
+                    const uint32_t alt = d_ < orig ? d_ : d_ + 1u;
+                    vword = nword ^ ((uint64_t)(orig ^ alt) << (2u * p_));
+                    const uint64_t code = (vword >> (2u * wl_tn)) & ((1ull << (2u * ktab_T)) - 1ull);
+                    entry = ktab_p[code * ktab_stride];
                 }
             } else if (FUSED) {
                 if (got_n) {
@@ -421,16 +466,18 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 done = (lo > hi) || (j < 0);  // query.cpp:35-37
                 sub = 0;
             }
-            if (FUSED && stage_b) {
+            if ((FUSED || WL) && stage_b) {
                 nrec.x = entry;
                 nstage = 2u;
+                if (WL) nword = vword;
             }
             if (got_n) {
                 nrec = rec;
                 nword = first_word;
                 has_n = true;
-                nstage = 1u;
-                if (WL) nq = (size_t)wl_index;  // from here on the search is known by its result index
+                nstage = (WL && !imp) ? 2u : 1u;
+                nimp = imp;
+                if (WL && !imp) nq = (size_t)wl_index;  // from here on the search is known by its result index
             }
             if (alive && done) {
                 if (trace) {

@@ -626,7 +626,7 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
     L->blocks = al(S * compact_hits_block_words(mv) * 8);
     static const bool no_worklist = getenv("RSBWT_SET_1MM_NO_WORKLIST") != nullptr;  // A/B knob (tools/README.md): round 3's launches
     L->worklist = !no_worklist && tn > 0 && tn < k && k <= 32u && m * (size_t)tn < 0xFFFFFFFFull;
-    L->wl_cap = L->worklist ? m * 3u * (size_t)k : 0;
+    L->wl_cap = L->worklist ? m * 3u * (size_t)tn : 0;  // (a record per variant substituted left of the tables' reach, at most)
     L->wl = L->worklist ? al(S * L->wl_cap * 32) : 0;
     L->counts = L->worklist ? al(S * 8 * (size_t)WL_COUNT_STRIDE) : 0;
     L->total = L->trace + L->own + L->sparse + L->bits + L->blocks + L->wl + L->counts;
@@ -934,7 +934,7 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
         const hipError_t ew = launch_mm1_worklists(g->d_views, S, d_packed, d_valid, m, k, L.tn, d_trace, d_own, d_wl, L.wl_cap, d_counts,
                                                    d_sparse, d_bits, g->num_cus, st, g->counting ? g->d_work : nullptr);
         if (ew != hipSuccess) return fail_hip(ew, "worklist kernels");
-        rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_wl, d_counts, L.wl_cap, mv, k, d_sparse, d_bits, st);
+        rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, L.tn, d_wl, d_counts, L.wl_cap, k, d_sparse, d_bits, st);
     } else {
         rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);
     }
