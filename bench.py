@@ -932,6 +932,18 @@ def run_rows(a, c):
         }
     else:
         NR, stride, run = int(a.rows), a.stride, max(1, a.row_run)
+        # N > 1: rank 0 also holds every rank's 2-bit reads of a batch; with 8 x 20 GB shards opened for reads (295.6 GB) what
+        # is left of the HBM bounds the batch: one gather in flight from 4 ranks on, and fewer rows per shard if even
+        # that does not fit (the same on every rank: the smallest that fits anywhere)
+        gdepth = 2 if world <= 2 else 1
+        if world > 1 and cdev == dev:
+            free_b = torch.cuda.mem_get_info(dev)[0] - (2 << 30)
+            need = lambda nr: 2 * S * nr * (stride + 4) + gdepth * S * nr * (stride // 4 + 4) * (1 + (world if rank == 0 else 0)) + S * nr * 16
+            while NR > 1 << 16 and need(NR) > free_b:
+                NR //= 2
+            tt = torch.tensor([NR], dtype=torch.int64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            NR = int(tt.item())
         gen = torch.Generator(device=dev)
         gen.manual_seed(a.seed + 99)
         # rows as the reference extracts them: the rows of intervals (query.cpp:94-96 walks lower..upper), here runs
@@ -944,8 +956,8 @@ def run_rows(a, c):
         # (rsbwt_pack_reads_dev: a quarter of the bytes) + the lengths, gathered behind the next batch's walks
         d_full = [torch.empty((S, NR, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
         d_lenb = [torch.empty((S, NR), dtype=torch.int32, device=dev) for _ in range(2)]
-        gat_o = sharded.BlockGatherer((S, NR, stride // 4), torch.uint8, cdev, depth=2) if world > 1 else None
-        gat_l = sharded.BlockGatherer((S, NR), torch.int32, cdev, depth=2) if world > 1 else None
+        gat_o = sharded.BlockGatherer((S, NR, stride // 4), torch.uint8, cdev, depth=gdepth) if world > 1 else None
+        gat_l = sharded.BlockGatherer((S, NR), torch.int32, cdev, depth=gdepth) if world > 1 else None
         d_pl = torch.empty((S, NR), dtype=torch.int32, device=dev)
         step_no = [0]
 

@@ -207,6 +207,9 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
                 }
             }
             // ---- pass B: the line of upper where it is another one (a wave-uniform skip when nobody needs it)
+#ifdef RSB_BRANCH_NO_PASS_B  // timing experiment (tools/build_variant.sh): such items go to the worklist unstepped instead
+            if (have && !spill && !gotU) spill = true;
+#endif
             const bool needB = have && !spill && !gotU;
             if (__builtin_amdgcn_ballot_w64(needB) != 0ull) {
                 uint32_t line = wU + (wU >> GROUP_SHIFT);
