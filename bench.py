@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may run on")
     ap.add_argument("--ktab-depth", type=int, default=0, help="k-mer table depth (0 = auto, -1 = none)")
+    ap.add_argument("--ktab-format", choices=["auto", "plain", "grouped"], default="auto",
+                    help="k-mer table format (include/rsbwt.h, rsbwt_attach_ktab_format): plain = 8 B per T-mer; grouped = 12 B per "
+                         "four sibling T-mers, one level deeper out of the same HBM; auto = grouped where that is deeper")
     ap.add_argument("--window-span", type=int, default=0, help="symbols per window line (0 = from the data)")
     ap.add_argument("--ref-out-of-cache-runs", type=float, default=2e9,
                     help="run bytes of the index the compiled reference is timed on OUT OF CACHE beside the port (cpu_baseline.reference_beside_port.out_of_cache; 0 = skip)")
@@ -132,6 +135,33 @@ def kernel_source_sha():
     for f in ("search_lines.hip", "search_solo.h", "wave_lines.h", "line_format.h", "rank_device.h"):
         h.update(open(os.path.join(ROOT, "readserver_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def pick_tables(a, free_b, S, n_sym, T):
+    """(depth, format) of the job's k-mer tables: from the auto depth T up while S tables still leave 8 GB of the free HBM
+    and the T-mers are still expected to occur; the grouped format (3 B per T-mer) where it gets a level deeper than
+    the plain one (8 B), its groups of four siblings fit their records and a T-mer still has 64 rows on average -- one that
+    does not occur is left to the search (csrc/capi_internal.h: ktab_grouped_sensible)."""
+    if T < 2:
+        return T, 0
+    Tp = Tg = T
+    while Tp < 16 and S * 8 * 4 ** (Tp + 1) <= free_b - (8 << 30) and 4 ** (Tp + 1) <= n_sym:
+        Tp += 1
+    if a.ktab_format == "plain":
+        return Tp, 0
+    while Tg < 17 and S * 3 * 4 ** (Tg + 1) <= free_b - (8 << 30) and 64 * 4 ** (Tg + 1) <= n_sym:
+        Tg += 1
+    if (a.ktab_format == "grouped" or Tg > Tp) and (n_sym >> (2 * (Tg - 1))) <= 2048 and (n_sym >> (2 * Tg)) >= 64:
+        return Tg, 1
+    return Tp, 0
+
+
+def ktab_config(shards):
+    """config keys that describe the tables the shards got"""
+    fmt, nbytes, left = shards[0].ktab_info()
+    T = shards[0].ktab_depth()
+    return {"ktab_depth": T, "ktab_format": "grouped (12 B per 4 sibling T-mers)" if fmt == 1 else "plain (8 B per T-mer)",
+            "ktab_bytes_per_shard": nbytes, "ktab_untabulated_frac": (left / 4 ** T) if T else 0.0}
 
 
 def search_kernel_name(nshards, n=0, ktab_depth=0, span=0):
@@ -294,14 +324,14 @@ def size_tables(a, c, sset, shards, S):
         free_b //= c.world
         while T >= 2 and S * 8 * 4 ** T > free_b // 2:
             T -= 1
-    while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
-        T += 1
-    if c.world > 1:
-        tt = torch.tensor([T], dtype=torch.int64, device=c.cdev)
+    T, fmt = pick_tables(a, free_b, S, n_sym, T)
+    if c.world > 1:  # one depth and one format for the whole job: the shallowest any rank can hold (plain if any must)
+        tt = torch.tensor([T, fmt], dtype=torch.int64, device=c.cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-        T = int(tt.item())
+        if int(tt[0].item()) != T or int(tt[1].item()) != fmt:
+            T, fmt = int(tt[0].item()), int(tt[1].item())
     if T >= 2:
-        ok(c, L.rsbwt_set_attach_ktabs(sset._s, T))
+        ok(c, L.rsbwt_set_attach_ktabs_format(sset._s, T, fmt))
 
 
 def make_batch(a, c, shards, mix, Q, k, d_kmers):
@@ -562,11 +592,11 @@ def run_exact(a, c, mix, steps, warmup, headline):
         "mix": mix, "value": value, "queries_per_s_all_shards": value / (world * S), "ms_per_step": ms_per_step,
         "steps": steps, "warmup": warmup,
         "mean_lf_steps_per_search": lf / (S * Q), "lines_per_lf_step": ln / max(lf, 1),
-        "ktab_depth": shards[0].ktab_depth(), "window_span": shards[0].window_span(),
+        **ktab_config(shards), "window_span": shards[0].window_span(),
         "symbols_per_shard": int(n_sym), "far_lines_per_shard": int(shards[0].far_lines()),
         "spilled_position_fraction": shards[0].spilled_symbols() / max(int(n_sym), 1),
         "index_hbm_bytes_per_gpu": hbm,
-        "index_bytes_per_run_byte": (hbm - sum(8 * 4 ** g.ktab_depth() for g in shards)) / (S * R),
+        "index_bytes_per_run_byte": (hbm - sum(g.ktab_info()[1] for g in shards)) / (S * R),
         "index_build_s": round(t_build, 2), "gather_verified": gather_verified, "wire_packed": wire_packed,
         "single_shard_check": single,
         "step": ("search kernel on the main stream; the next batch's packing and start records on a second stream beside it "
@@ -616,7 +646,7 @@ def cxx_leg_cmd(a):
     """The command of the second leg of an N > 1 run: this script as the one-process host over the same devices."""
     return [sys.executable, os.path.abspath(__file__), "--host", "cxx", "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
             "--runs", str(a.runs), "--queries", str(a.queries), "--k", str(a.k), "--shards-per-gpu", str(a.shards_per_gpu),
-            "--stream", a.stream, "--mix", a.mix, "--seed", str(a.seed), "--ktab-depth", str(a.ktab_depth), "--window-span", str(a.window_span)]
+            "--stream", a.stream, "--mix", a.mix, "--seed", str(a.seed), "--ktab-depth", str(a.ktab_depth), "--ktab-format", a.ktab_format, "--window-span", str(a.window_span)]
 
 
 def main():
@@ -695,7 +725,8 @@ def main():
                 "stream": STREAM_NOTE[a.stream],
                 "queries_per_batch": int(a.queries), "k": a.k, "present_fraction": a.present_frac,
                 "mean_lf_steps_per_search": head["mean_lf_steps_per_search"], "lines_per_lf_step": head["lines_per_lf_step"],
-                "ktab_depth": head["ktab_depth"],
+                "ktab_depth": head["ktab_depth"], "ktab_format": head.get("ktab_format"), "ktab_bytes_per_shard": head.get("ktab_bytes_per_shard"),
+                "ktab_untabulated_frac": head.get("ktab_untabulated_frac"),
                 "window_span": head["window_span"], "far_lines_per_shard": head["far_lines_per_shard"],
                 "spilled_position_fraction": head["spilled_position_fraction"],
                 "index_hbm_bytes_per_gpu": head["index_hbm_bytes_per_gpu"], "index_bytes_per_run_byte": head["index_bytes_per_run_byte"],
@@ -781,7 +812,7 @@ def run_rows(a, c):
     size_tables(a, c, sset, shards, S)
     t_build = time.time() - t0
     common = {"shards_per_gpu": S, "shards": world * S, "run_bytes_per_shard": R, "symbols_per_shard": n_sym,
-              "stream": STREAM_NOTE[a.stream], "mix": mix + ": " + MIX_NOTE[mix], "k": k, "ktab_depth": shards[0].ktab_depth(),
+              "stream": STREAM_NOTE[a.stream], "mix": mix + ": " + MIX_NOTE[mix], "k": k, **ktab_config(shards),
               "window_span": shards[0].window_span(), "index_build_s": round(t_build, 2),
               "layout": ("reads: a psi hint in every window line (RSBWT_OPEN_READS)" if L.rsbwt_opened_for_reads(shards[0].handle) else "plain"),
               "index_hbm_bytes_per_gpu": int(sum(int(L.rsbwt_hbm_bytes(g.handle)) for g in shards)),
@@ -1252,10 +1283,9 @@ def run_exact_cxx(a):
         n_sym = by_dev[0][0].getBWLen()
         T = host.auto_table_depth()
         free_b = min(torch.cuda.mem_get_info(g)[0] for g in range(G))
-        while T < 16 and T >= 2 and S * 8 * 4 ** (T + 1) <= free_b - (8 << 30) and 4 ** (T + 1) <= n_sym:
-            T += 1
+        T, fmt = pick_tables(a, free_b, S, n_sym, T)
         if T >= 2:
-            host.attach_tables(T)
+            host.attach_tables(T, fmt)
     t_build = time.time() - t0
     # the batch (device 0), then a copy on every device
     ctx0 = Ctx()
@@ -1306,7 +1336,7 @@ def run_exact_cxx(a):
                     "rsbwt_pack_interval_pairs_dev on a stream per device; rsbwt_set_gather_intervals_dev on a second one, batch i "
                     "travelling while batch i + 1 is searched): readserver_amd/onehost.py, csrc/sets.hip",
             "mix": a.mix, "shards_per_gpu": S, "shards": G * S, "run_bytes_per_shard": R, "queries_per_batch": Q, "k": k,
-            "ktab_depth": by_dev[0][0].ktab_depth(), "window_span": by_dev[0][0].window_span(), "index_build_s": round(t_build, 2),
+            **ktab_config(by_dev[0]), "window_span": by_dev[0][0].window_span(), "index_build_s": round(t_build, 2),
             "mean_lf_steps_per_search": lf / max(S * Q, 1), "gather_verified": verified,
             "gathered_as": None if G == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact",
             "multi_gpu": "measured" if G > 1 else "one GPU",

@@ -52,12 +52,16 @@ extern "C" {
  * Without the flag the layout is the denser one; the first extraction / getOccAt then builds a dense sample
  * table (n / 32 bytes) and writes hints into the lines that happen to have room (about 6 in 10) -- into the
  * resident lines, where no search reads them, but an index a search-only deployment never pays for.
- * bits 1..4: reserved (0).
+ * bit 1: RSBWT_OPEN_KTAB_GROUPED -- the k-mer table in its grouped format (below, rsbwt_attach_ktab_format): 3 B per
+ * T-mer instead of 8, so the same HBM holds a table one level deeper; with depth 0 the deepest grouped table that fits
+ * the budget and is deeper than the plain one would be (else the plain one).
+ * bits 2..4: reserved (0).
  * bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
  * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (the deepest table
  * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n; rsbwt_set_open
  * sizes the tables of one GPU's shards together), 31 = no table, else T = 2..16 (T = 16: 34 GB). */
 #define RSBWT_OPEN_READS 1u
+#define RSBWT_OPEN_KTAB_GROUPED 2u
 #define RSBWT_KTAB_SHIFT 5
 #define RSBWT_KTAB_MASK (0x1Fu << RSBWT_KTAB_SHIFT)
 #define RSBWT_KTAB_NONE (31u << RSBWT_KTAB_SHIFT)
@@ -119,6 +123,22 @@ uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi
 int rsbwt_opened_for_reads(const rsbwt_t *h);     /* 1: laid out with RSBWT_OPEN_READS */
 /* Builds the k-mer table of depth T (2..16) of an open handle that has none. */
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
+/* The same with the table's format named.  The table holds what findInterval (src/bwt/query.cpp:24-41) returns for
+ * every T-mer, so that a search of k >= T symbols starts T steps in (the reference has no such table: it takes every
+ * step, query.cpp:33-38).  PLAIN: 8 bytes per T-mer {lower:40, width:24}.  GROUPED: the four T-mers that differ in
+ * their LAST symbol only are neighbours in the BWT's rows; one 12-byte record holds the first row of the four and their
+ * running widths (14 bits each) = 3 bytes per T-mer, T up to 17.  A T-mer the record cannot describe -- one that does
+ * not occur (the reference's empty interval depends on the step the search died at), or a group of 16383 rows or more
+ * -- is searched from initInterval like an untabulated one: same answers, T more steps; rsbwt_ktab_info counts them.
+ * AUTO: grouped where 64 <= n / 4^T and n / 4^(T-1) <= 2048 -- the groups fit their records and a T-mer's interval is
+ * still many runs wide, so nearly every T-mer occurs (5.5e-5 of the 15-mers of a 1.17e11-symbol shard do not; at 7 rows
+ * per 17-mer 46 % do not, and a plain table answers those in no step at all) -- else plain. */
+#define RSBWT_KTAB_FORMAT_PLAIN 0u
+#define RSBWT_KTAB_FORMAT_GROUPED 1u
+#define RSBWT_KTAB_FORMAT_AUTO 2u
+int rsbwt_attach_ktab_format(rsbwt_t *h, uint32_t T, uint32_t format);
+/* format (RSBWT_KTAB_FORMAT_PLAIN / _GROUPED), bytes in HBM and -- grouped -- the T-mers left to the search; any may be NULL */
+int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_t *untabulated);
 int rsbwt_device(const rsbwt_t *h);
 
 /* query.h mirrors, batched (include/bwt/query.h:18-32) ---------------------------------
@@ -309,6 +329,9 @@ rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
  * that gives, over all devices: rsbwt_set_auto_ktab_depth) */
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth);
 uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s);
+/* the same with the format named (rsbwt_attach_ktab_format; rsbwt_set_attach_ktabs = PLAIN); grouped tables are
+ * interleaved like plain ones: a query's records for the S shards of a device are one stretch of 12 * S bytes */
+int rsbwt_set_attach_ktabs_format(rsbwt_set_t *s, uint32_t depth, uint32_t format);
 /* lower/upper: [num_shards][Q]; counts: [Q] summed over shards, the way the front-end sums
  * per-partition replies (src/service/server.cpp:184-197).  With several devices the per-device sums
  * are reduced onto the first device over RCCL (ncclReduce) and cross PCIe once. */
@@ -475,6 +498,11 @@ int rsbwt_layout_selftest_host(const uint8_t *runs, uint64_t num_runs, uint32_t 
  * hint, rows a hint settles (the others it bounds)}; *first_bad as above. */
 int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_runs, uint32_t window_span, uint64_t *stats4,
                                    uint64_t *first_bad);
+
+/* Test hook (host only, answers no query): the grouped k-mer table's record code (rsbwt_attach_ktab_format) -- `groups`
+ * x 4 sibling intervals in, the 4 entries each 12-byte record gives back out as {lower:40 | width:24} words, width
+ * 0xFFFFFF = left to the search. */
+int rsbwt_ktab_group_selftest_host(const uint64_t *lower, const uint64_t *upper, size_t groups, uint64_t *entries);
 
 /* Test hook (answers no query): overwrites n bytes of the index in HBM -- region 0: the window lines,
  * 1: the handle's own k-mer table -- so that tests can hold the kernels to what they do with a DAMAGED

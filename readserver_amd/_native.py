@@ -68,6 +68,8 @@ SIGNATURES = {
     "rsbwt_psi_hint_lines": (C.c_uint64, [_vp]),
     "rsbwt_opened_for_reads": (C.c_int, [_vp]),
     "rsbwt_attach_ktab": (C.c_int, [_vp, C.c_uint32]),
+    "rsbwt_attach_ktab_format": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "rsbwt_ktab_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), _u64p, _u64p]),
     "rsbwt_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
@@ -141,6 +143,7 @@ SIGNATURES = {
     "rsbwt_set_size": (C.c_size_t, [_vp]),
     "rsbwt_set_devices": (C.c_size_t, [_vp]),
     "rsbwt_set_attach_ktabs": (C.c_int, [_vp, C.c_uint32]),
+    "rsbwt_set_attach_ktabs_format": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rsbwt_set_auto_ktab_depth": (C.c_uint32, [_vp]),
     "rsbwt_set_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_set_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
@@ -163,6 +166,7 @@ SIGNATURES = {
     "rsbwt_set_last_search_counters": (C.c_int, [_vp, _u64p]),
     "rsbwt_layout_selftest_host": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u64p, _u64p]),
     "rsbwt_layout_selftest_psi_host": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u64p, _u64p]),
+    "rsbwt_ktab_group_selftest_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "rsbwt_debug_fast_window": (C.c_int, [_vp, C.c_size_t, C.c_uint32, _vp, _vp, C.c_int]),
     "rsbwt_debug_poke": (C.c_int, [_vp, C.c_int, C.c_uint64, _vp, C.c_size_t]),
     "rsbwt_set_shard": (_vp, [_vp, C.c_size_t]),

@@ -46,8 +46,9 @@ class GpuBWT:
     """
 
     def __init__(self, filename=None, device=0, *, runs=None, device_runs=None, num_strings=0,
-                 ktab_depth=0, window_span=0, for_reads=False):
-        """ktab_depth: depth of the k-mer table (0 = auto, None = no table).  window_span: symbols
+                 ktab_depth=0, window_span=0, for_reads=False, ktab_grouped=False):
+        """ktab_depth: depth of the k-mer table (0 = auto, None = no table); ktab_grouped: RSBWT_OPEN_KTAB_GROUPED
+        -- its 3-bytes-per-T-mer format (include/rsbwt.h).  window_span: symbols
         per window of the HBM layout (0 = from the data: ~88 run pieces per 128-byte line).
         for_reads: RSBWT_OPEN_READS -- a psi hint in every window line, built with the index
         (the layout for a shard that serves read extraction)."""
@@ -56,6 +57,7 @@ class GpuBWT:
         flags = (31 if ktab_depth is None else int(ktab_depth) & 0x1F) << 5
         flags |= (int(window_span) & 0xFFF) << 12
         flags |= 1 if for_reads else 0
+        flags |= 2 if ktab_grouped else 0
         if filename is not None:
             check(L.rsbwt_open(str(filename).encode(), device, flags, C.byref(self._h)))
         elif runs is not None:
@@ -155,6 +157,13 @@ class GpuBWT:
 
     def ktab_depth(self):
         return lib().rsbwt_ktab_depth(self._h)
+
+    def ktab_info(self):
+        """(format, bytes, untabulated): 0 = plain / 1 = grouped, the table's HBM bytes, the T-mers a grouped table
+        leaves to the search (rsbwt_ktab_info)."""
+        f, b, u = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        check(lib().rsbwt_ktab_info(self._h, C.byref(f), C.byref(b), C.byref(u)))
+        return f.value, b.value, u.value
 
     def window_span(self):
         return lib().rsbwt_window_span(self._h)

@@ -177,12 +177,28 @@ const char *rsbwt_strerror(int code) {
 
 namespace rsb {
 
-int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride) {
+// The deepest table of *fmt that fits `budget` bytes and whose T-mers are still expected to occur (4^T <= n; grouped:
+// 64 times over, a T-mer that does not occur being left to the search: ktab_grouped_sensible).  A grouped table that would not be deeper than the plain
+// one, or whose groups would overflow their records, is not worth its escapes: *fmt becomes KTAB_PLAIN.  0 = none.
+uint32_t auto_ktab_depth_for(uint64_t budget, uint64_t n, uint32_t *fmt) {
+    uint32_t Tp = 1;
+    while (Tp < KTAB_MAX_DEPTH_PLAIN && ktab_bytes(KTAB_PLAIN, Tp + 1u) <= budget && (1ull << (2u * (Tp + 1u))) <= n) ++Tp;
+    if (*fmt == KTAB_GROUPED) {
+        uint32_t Tg = 1;
+        while (Tg < KTAB_MAX_DEPTH_GROUPED && ktab_bytes(KTAB_GROUPED, Tg + 1u) <= budget && (64ull << (2u * (Tg + 1u))) <= n) ++Tg;
+        if (Tg > Tp && ktab_grouped_sensible(n, Tg)) return Tg;
+        *fmt = KTAB_PLAIN;
+    }
+    return Tp < 2u ? 0u : Tp;
+}
+
+int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride, uint32_t fmt) {
     int rc = use_device(h->device);
     if (rc) return rc;
     ctx_guard g(h->pool);
     if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
-    hipError_t e = build_ktable(h->view, T, d_table, stride, h->num_cus, g.c->st[0]);
+    uint64_t left = 0;
+    hipError_t e = build_ktable(h->view, T, d_table, stride, h->num_cus, g.c->st[0], fmt, &left);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail_hip(e, "building the k-mer table");
@@ -190,16 +206,20 @@ int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride) {
     h->view.ktab = d_table;
     h->view.ktab_depth = T;
     h->view.ktab_stride = stride;
-    h->hbm_bytes += 8ull << (2u * T);
+    h->view.ktab_fmt = fmt;
+    h->ktab_untabulated = left;
+    h->hbm_bytes += ktab_bytes(fmt, T);
     return upload_view(h);
 }
 
 int detach_ktab(rsbwt *h) {
     if (h->ktab_owned || !h->view.ktab) return RSBWT_OK;
-    h->hbm_bytes -= 8ull << (2u * h->view.ktab_depth);
+    h->hbm_bytes -= ktab_bytes(h->view.ktab_fmt, h->view.ktab_depth);
     h->view.ktab = nullptr;
     h->view.ktab_depth = 0;
     h->view.ktab_stride = 1;
+    h->view.ktab_fmt = KTAB_PLAIN;
+    h->ktab_untabulated = 0;
     h->ktab_owned = true;
     const int rc = use_device(h->device);
     return rc ? rc : upload_view(h);
@@ -209,21 +229,35 @@ int detach_ktab(rsbwt *h) {
 
 extern "C" {
 
-// Builds the k-mer table of depth T (2..16) for an open handle that has none.
-int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) {
+// Builds the k-mer table of depth T (2..16; grouped: ..17) for an open handle that has none.
+int rsbwt_attach_ktab_format(rsbwt_t *h, uint32_t T, uint32_t format) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (format > RSBWT_KTAB_FORMAT_AUTO) return fail(RSBWT_EINVAL, "k-mer table format %u", format);
     if (h->view.ktab || h->view.n == 0) return RSBWT_OK;
     if (T < 2u) T = 2;
-    if (T > 16u) T = 16;  // 8 B * 4^16 = 34 GB
+    // auto: the grouped records where they can say what four siblings hold, the plain entries elsewhere
+    uint32_t fmt = format == RSBWT_KTAB_FORMAT_AUTO ? (ktab_grouped_sensible(h->view.n, T) ? KTAB_GROUPED : KTAB_PLAIN) : format;
+    const uint32_t Tmax = fmt == KTAB_GROUPED ? KTAB_MAX_DEPTH_GROUPED : KTAB_MAX_DEPTH_PLAIN;
+    if (T > Tmax) T = Tmax;  // 8 B * 4^16 = 34 GB; 3 B * 4^17 = 52 GB
     int rc = use_device(h->device);
     if (rc) return rc;
     uint64_t *d_tab = nullptr;
-    hipError_t e = hipMalloc(&d_tab, 8ull << (2u * T));
+    hipError_t e = hipMalloc(&d_tab, ktab_bytes(fmt, T));
     if (e != hipSuccess) return fail_hip(e, "allocating the k-mer table");
-    rc = attach_ktab_into(h, T, d_tab, 1);
+    rc = attach_ktab_into(h, T, d_tab, 1, fmt);
     if (rc) (void)hipFree(d_tab);
     else h->ktab_owned = true;
     return rc;
+}
+int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) { return rsbwt_attach_ktab_format(h, T, RSBWT_KTAB_FORMAT_PLAIN); }
+
+int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_t *untabulated) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    const bool has = h->view.ktab != nullptr && h->view.ktab_depth != 0u;
+    if (format) *format = has ? h->view.ktab_fmt : 0u;
+    if (bytes) *bytes = has ? ktab_bytes(h->view.ktab_fmt, h->view.ktab_depth) : 0ull;
+    if (untabulated) *untabulated = has ? h->ktab_untabulated : 0ull;
+    return RSBWT_OK;
 }
 
 static int ensure_select_samples(rsbwt_t *h, hipStream_t stream);
@@ -295,17 +329,16 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     // single 8-byte read), and whose T-mers still have ~1 expected occurrence (4^T <= n).
     // 8 B * 4^16 = 34 GB is the ceiling.  (rsbwt_set_open sizes the tables of its shards together.)
     uint32_t T = (flags & RSBWT_KTAB_MASK) >> RSBWT_KTAB_SHIFT;
+    uint32_t fmt = (flags & RSBWT_OPEN_KTAB_GROUPED) ? KTAB_GROUPED : KTAB_PLAIN;
     if (T == 31u || h->view.n == 0) T = 0;
     else if (T == 0u) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         const uint64_t budget = std::min<uint64_t>(h->hbm_bytes + h->hbm_bytes / 4, free_b / 4);
-        T = 1;
-        while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= h->view.n) ++T;
-        if (T < 2u) T = 0;
+        T = auto_ktab_depth_for(budget, h->view.n, &fmt);
     }
     if (T) {
-        rc = rsbwt_attach_ktab(h, T);
+        rc = rsbwt_attach_ktab_format(h, T, fmt);
         if (rc) { rsbwt_close(h); return rc; }
     }
     *out = h;
@@ -453,7 +486,7 @@ int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes,
     // (a write into a published index: refused unless the process asked for the test hooks)
     if (getenv("RSBWT_ENABLE_TEST_HOOKS") == nullptr) return fail(RSBWT_EINVAL, "rsbwt_debug_poke is a test hook: set RSBWT_ENABLE_TEST_HOOKS=1");
     const uint64_t size = region == 0 ? h->view.nlines * (uint64_t)LINE_BYTES
-                          : region == 1 && h->view.ktab && h->ktab_owned ? 8ull << (2u * h->view.ktab_depth) : 0ull;
+                          : region == 1 && h->view.ktab && h->ktab_owned ? ktab_bytes(h->view.ktab_fmt, h->view.ktab_depth) : 0ull;
     if (offset > size || n > size - offset) return fail(RSBWT_ERANGE, "poke outside the region (%llu bytes)", (unsigned long long)size);
     if (n == 0) return RSBWT_OK;
     int rc = use_device(h->device);

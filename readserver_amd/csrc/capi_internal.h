@@ -90,13 +90,25 @@ struct rsbwt : rsb::search_meter {
     uint64_t *d_sel = nullptr;  // sampled select table, built on first use
     uint64_t psi_hint_lines = 0;  // window lines that carry a psi hint (written when the samples are built)
     bool ktab_owned = true;     // false: view.ktab points into a shard set's interleaved table
+    uint64_t ktab_untabulated = 0;  // grouped table: T-mers whose record leaves them to the search (empty, or a group too wide)
 };
 
 namespace rsb {
 int hits_1mm_dev_shared(rsbwt *h, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits, size_t cap,
                         void *d_total, void *d_scratch, void *stream, const void *d_variants);
 // Builds h's k-mer table of depth T into d_table[c * stride] (memory owned by the caller).
-int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride);
+// (fmt: rsb::KTAB_PLAIN / KTAB_GROUPED; d_table = this shard's first entry / record inside an interleaved allocation)
+int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride, uint32_t fmt = 0);
+// RSBWT_KTAB_FORMAT_* -> the format a table of depth T over n symbols gets (auto: the caller's plain / grouped choice)
+uint32_t auto_ktab_depth_for(uint64_t budget, uint64_t n, uint32_t *fmt);
+constexpr uint32_t KTAB_MAX_DEPTH_PLAIN = 16, KTAB_MAX_DEPTH_GROUPED = 17;
+// Where the grouped records pay: a record holds a group of < 16383 rows (so: four siblings expected to hold an eighth of
+// that at most), and a T-mer that does not occur is left to the search, T steps instead of none -- rare only while a
+// T-mer's interval is still many runs wide (measured on the bench's 1.17e11-symbol run stream: 5.5e-5 of the 15-mers at
+// 109 rows each, 0.46 of the 17-mers at 7 rows each: a context that narrow mostly has ONE preceding symbol).
+inline bool ktab_grouped_sensible(uint64_t n, uint32_t T) {
+    return T >= 2u && T <= 31u && (n >> (2u * (T - 1u))) <= 2048ull && (n >> (2u * T)) >= 64ull;
+}
 int detach_ktab(rsbwt *h);  // forgets a table it does not own
 int ensure_samples(rsbwt *h, hipStream_t stream);  // the select samples + psi hints of a shard (built once); its view then names them
 }  // namespace rsb

@@ -108,10 +108,11 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
                                   hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 constexpr int WORK_WORDS = 16;  // counters of a counting launch (search_lines.hip, WORK_*)
 
-// k-mer table: fills d_entries[c * stride], c < 4^T, by searching every T-mer.  `view` is the host copy
-// of the shard's view (no table yet).
+// k-mer table: fills d_entries[c * stride], c < 4^T, by searching every T-mer (fmt = KTAB_GROUPED: the 12-byte
+// records at d_entries + 12 * g * stride bytes, g < 4^(T-1); *untabulated = T-mers left to the search itself).
+// `view` is the host copy of the shard's view (no table yet).
 hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, uint32_t stride, int num_cus,
-                        hipStream_t stream);
+                        hipStream_t stream, uint32_t fmt = KTAB_PLAIN, uint64_t *untabulated = nullptr);
 
 // class BWT mirrors, batched
 hipError_t launch_occ_batch(const shard_view &ix, const void *d_syms, const void *d_index, size_t n,

@@ -111,6 +111,38 @@ __global__ void ktab_codes_kernel(uint64_t base, size_t m, uint64_t *__restrict_
     }
 }
 
+// grouped table: slice entry i = sibling i & 3 of group gbase + (i >> 2) (its last symbol in the code's high bits)
+__global__ void ktab_group_codes_kernel(uint64_t gbase, uint32_t gbits, size_t m, uint64_t *__restrict__ packed,
+                                        uint8_t *__restrict__ valid) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        packed[i] = ((uint64_t)(i & 3u) << gbits) | (gbase + (i >> 2));
+        valid[i] = 1;
+    }
+}
+
+__global__ void ktab_group_encode_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper, size_t groups,
+                                         uint32_t *__restrict__ records, uint32_t stride, unsigned long long *__restrict__ untabulated) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    uint64_t lo[4], up[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = lower[4 * g + i];
+        up[i] = upper[4 * g + i];
+    }
+    uint32_t rec[3];
+    ktab_group_encode(lo, up, rec);
+    uint32_t *r = records + g * stride * 3u;
+    r[0] = rec[0];
+    r[1] = rec[1];
+    r[2] = rec[2];
+    uint32_t left = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) left += (ktab_group_entry(rec[0], rec[1], rec[2], i) >> COUNT_BITS) == KTAB_WIDE ? 1u : 0u;
+    if (left) atomicAdd(untabulated, (unsigned long long)left);
+}
+
 __global__ void ktab_encode_kernel(const uint64_t *__restrict__ lower, const uint64_t *__restrict__ upper,
                                    size_t m, uint64_t *__restrict__ entries, uint32_t stride) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -659,16 +691,20 @@ size_t scratch_cache::held_bytes() {
 // Fills `d_entries` (4^T entries, `stride` apart) by searching every T-mer, in slices that bound the
 // temporary memory.  `view` must not have a table yet.
 hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries, uint32_t stride, int num_cus,
-                        hipStream_t stream) {
+                        hipStream_t stream, uint32_t fmt, uint64_t *untabulated) {
     const uint64_t total = 1ull << (2u * T);
     const size_t SL = (size_t)std::min<uint64_t>(total, 1ull << 24);
     uint64_t *d_pk = nullptr, *d_lo = nullptr, *d_up = nullptr, *d_half = nullptr;
+    unsigned long long *d_left = nullptr;
+    if (untabulated) *untabulated = 0;
+    if (fmt == KTAB_GROUPED && T < 2u) return hipErrorInvalidValue;
     uint8_t *d_ok = nullptr;
     shard_view *d_view = nullptr;
     shard_view plain = view;
     plain.ktab = nullptr;
     plain.ktab_depth = 0;
     plain.ktab_stride = 1;
+    plain.ktab_fmt = KTAB_PLAIN;
     hipError_t e = hipSuccess;
     scratch_cache scratch;
     auto cleanup = [&] {
@@ -679,10 +715,12 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
         if (d_ok) (void)hipFree(d_ok);
         if (d_half) (void)hipFree(d_half);
         if (d_view) (void)hipFree(d_view);
+        if (d_left) (void)hipFree(d_left);
     };
     if ((e = hipMalloc(&d_pk, SL * 8)) != hipSuccess || (e = hipMalloc(&d_lo, SL * 8)) != hipSuccess ||
         (e = hipMalloc(&d_up, SL * 8)) != hipSuccess || (e = hipMalloc(&d_ok, SL)) != hipSuccess ||
-        (e = hipMalloc(&d_view, sizeof(shard_view))) != hipSuccess) {
+        (e = hipMalloc(&d_view, sizeof(shard_view))) != hipSuccess || (e = hipMalloc(&d_left, 8)) != hipSuccess ||
+        (e = hipMemsetAsync(d_left, 0, 8, stream)) != hipSuccess) {
         cleanup();
         return e;
     }
@@ -697,6 +735,7 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
         }
         plain.ktab = d_half;
         plain.ktab_depth = T0;
+        plain.ktab_fmt = KTAB_PLAIN;
     }
     if ((e = hipMemcpy(d_view, &plain, sizeof plain, hipMemcpyHostToDevice)) != hipSuccess) {
         cleanup();
@@ -704,15 +743,23 @@ hipError_t build_ktable(const shard_view &view, uint32_t T, uint64_t *d_entries,
     }
     for (uint64_t base = 0; base < total && e == hipSuccess; base += SL) {
         const size_t m = (size_t)std::min<uint64_t>(SL, total - base);
-        hipLaunchKernelGGL(ktab_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base, m, d_pk, d_ok);
+        if (fmt == KTAB_GROUPED)  // (a slice = whole groups: SL is a multiple of 4, base / 4 the slice's first group)
+            hipLaunchKernelGGL(ktab_group_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base >> 2, 2u * (T - 1u), m, d_pk, d_ok);
+        else
+            hipLaunchKernelGGL(ktab_codes_kernel, dim3(blocks256(m)), dim3(256), 0, stream, base, m, d_pk, d_ok);
         search_extra role;
         role.table_build = true;
         e = launch_search(scratch, d_view, 1, d_pk, d_ok, m, T, d_lo, d_up, false, nullptr, num_cus, stream, nullptr, nullptr, &role);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m,
-                           d_entries + base * stride, stride);
+        if (fmt == KTAB_GROUPED)
+            hipLaunchKernelGGL(ktab_group_encode_kernel, dim3(blocks256(m >> 2)), dim3(256), 0, stream, d_lo, d_up, m >> 2,
+                               reinterpret_cast<uint32_t *>(d_entries) + (base >> 2) * stride * 3u, stride, d_left);
+        else
+            hipLaunchKernelGGL(ktab_encode_kernel, dim3(blocks256(m)), dim3(256), 0, stream, d_lo, d_up, m,
+                               d_entries + base * stride, stride);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && untabulated) e = hipMemcpyAsync(untabulated, d_left, 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     cleanup();
     return e;

@@ -241,3 +241,16 @@ extern "C" int rsbwt_layout_selftest_psi_host(const uint8_t *runs, uint64_t num_
     }
     return RSBWT_OK;
 }
+
+// TEST HOOK: the grouped k-mer table's record code (line_format.h: what ktab_group_encode_kernel writes and what
+// ktab_entry reads) on the host: `groups` x 4 (lower, upper) pairs in, the 4 entries each record gives back out, in
+// the plain table's form {lower:40 | width:24}, width RSBWT_KTAB_WIDE = left to the search.
+extern "C" int rsbwt_ktab_group_selftest_host(const uint64_t *lower, const uint64_t *upper, size_t groups, uint64_t *entries) {
+    if ((!lower || !upper || !entries) && groups) return RSBWT_EINVAL;
+    for (size_t g = 0; g < groups; ++g) {
+        uint32_t rec[3];
+        ktab_group_encode(lower + 4 * g, upper + 4 * g, rec);
+        for (uint32_t i = 0; i < 4u; ++i) entries[4 * g + i] = ktab_group_entry(rec[0], rec[1], rec[2], i);
+    }
+    return RSBWT_OK;
+}

@@ -61,6 +61,18 @@
 // query's start records for all S shards then come out of one 8S-byte stretch -- one request
 // instead of S random ones.
 //
+// GROUPED K-MER TABLE (KTAB_GROUPED: 12 B per four T-mers = 3 B per T-mer, which buys one level more -- one LF step
+// less of every search -- out of the same HBM): the four T-mers that share their first T - 1 symbols and differ in the
+// LAST one (the symbol backward search takes first, the high two bits of the code) are neighbours in the BWT's row
+// order, and their intervals tile one stretch of rows: one record holds the stretch's first row and the four running
+// widths.  Record of group g = code & (4^(T-1) - 1), 96 bits little-endian: bits 0..39 base (lower of the first
+// non-empty sibling), then c_0..c_3 of 14 bits each, c_i = rows of siblings 0..i.  Sibling i = code >> (2T - 2) holds
+// rows base + c_(i-1) .. base + c_i - 1.  What the record cannot say is left to the search itself (it starts from
+// initInterval, query.cpp:18-21, like an untabulated k-mer, and ends on the same rows): an EMPTY sibling (the
+// reference's empty interval depends on the step it died at), a group of 16383 rows or more, siblings that do not
+// tile (c_3 = 0x3FFF marks the whole record so).  Interleaved like the plain table: record of shard s at
+// [(g * S + s) * 12].
+//
 // Everything below is plain C++ usable on the host and in kernels: the layout logic (what the
 // builder writes, what a scalar reader finds) is one piece of code for both, so tests can hold it
 // to naive ranks on the CPU while all queries run on the GPU only.
@@ -97,6 +109,9 @@ constexpr uint64_t COUNT_MASK = (1ull << COUNT_BITS) - 1;
 constexpr uint64_t MAX_SYMBOLS = 1ull << 40;  // per shard; counts are 40-bit
 constexpr uint32_t MAX_SPAN = 2944;           // S <= 92 * 32: a line of full units never needs more
 constexpr uint32_t KTAB_WIDE = 0xFFFFFFu;
+constexpr uint32_t KTAB_PLAIN = 0, KTAB_GROUPED = 1;  // shard_view::ktab_fmt
+constexpr uint32_t KTAB_GROUP_BYTES = 12;
+constexpr uint32_t KTAB_CUM_BITS = 14, KTAB_CUM_ESCAPE = (1u << KTAB_CUM_BITS) - 1u;
 
 // w = p / S.  Kernels compute it as (uint32)((double)p * inv) plus one fix-up step: inv is 1/S
 // rounded down by 2^-50 relative, so for p < 2^40 the product's floor is w or w - 1, never above.
@@ -117,6 +132,8 @@ struct shard_view {
     uint32_t ktab_stride;   // entries between consecutive T-mers: 1, or the number of shards whose tables are
                             // interleaved (a shard set's shards on one GPU: entry(code) = ktab[code * stride])
     const uint64_t *ktab;
+    uint32_t ktab_fmt;      // KTAB_PLAIN (8-byte entries) / KTAB_GROUPED (12-byte records of four siblings)
+    uint32_t reserved0;
     uint64_t C[5];          // C[c] = # symbols with rank < c   (getPC)
     uint64_t total[5];      // occurrences of each symbol in the whole BWT
     uint32_t sel_shift;     // one select sample per 2^sel_shift occurrences of a symbol (SEL_SHIFT_DENSE / _SPARSE)
@@ -124,6 +141,42 @@ struct shard_view {
     const uint64_t *sel;    // the select samples, 5 x sel_stride words (nullptr until built: read extraction, getOccAt)
     uint64_t sel_stride;    // entries per symbol (select_stride)
 };
+
+// bytes of one shard's k-mer table of depth T
+RSB_HD uint64_t ktab_bytes(uint32_t fmt, uint32_t T) {
+    return fmt == KTAB_GROUPED ? (uint64_t)KTAB_GROUP_BYTES << (2u * (T - 1u)) : 8ull << (2u * T);
+}
+// The grouped record of four siblings from their (lower, upper) -- live[i] = lower <= upper -- as three dwords.
+RSB_HD void ktab_group_encode(const uint64_t lo[4], const uint64_t up[4], uint32_t rec[3]) {
+    uint64_t base = 0, next = 0, cum[4];
+    bool any = false, ok = true;
+    for (int i = 0; i < 4; ++i) {
+        if (lo[i] <= up[i] && up[i] != ~0ull) {
+            if (!any) { base = lo[i]; next = lo[i]; any = true; }
+            if (lo[i] != next) ok = false;  // the siblings do not tile: never for a sound BWT
+            next = up[i] + 1ull;
+        }
+        cum[i] = next - base;
+    }
+    if (!ok || cum[3] >= KTAB_CUM_ESCAPE || base > COUNT_MASK) {
+        base = 0;
+        cum[0] = cum[1] = cum[2] = cum[3] = KTAB_CUM_ESCAPE;
+    }
+    const uint64_t hi = (base >> 32) | (cum[0] << 8) | (cum[1] << 22) | (cum[2] << 36) | (cum[3] << 50);
+    rec[0] = (uint32_t)base;
+    rec[1] = (uint32_t)hi;
+    rec[2] = (uint32_t)(hi >> 32);
+}
+// Sibling `slot` of a grouped record, in the plain table's 8-byte form (lower | width << 40; KTAB_WIDE = ask the search)
+RSB_HD uint64_t ktab_group_entry(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t slot) {
+    const uint64_t hi = ((uint64_t)d2 << 32) | d1;
+    const uint64_t base = ((hi & 0xFFull) << 32) | d0;
+    const uint32_t c3 = (uint32_t)(hi >> 50) & KTAB_CUM_ESCAPE;
+    const uint32_t chi = (uint32_t)(hi >> (8u + KTAB_CUM_BITS * slot)) & KTAB_CUM_ESCAPE;
+    const uint32_t clo = slot ? (uint32_t)(hi >> (KTAB_CUM_BITS * slot - 6u)) & KTAB_CUM_ESCAPE : 0u;
+    if (c3 == KTAB_CUM_ESCAPE || chi <= clo) return (uint64_t)KTAB_WIDE << COUNT_BITS;
+    return (base + clo) | ((uint64_t)(chi - clo) << COUNT_BITS);
+}
 
 RSB_HD uint64_t window_of(const span_params &sp, uint64_t p) { return p / sp.S; }
 RSB_HD uint64_t line_of_window(uint64_t w) { return w + (w >> GROUP_SHIFT); }

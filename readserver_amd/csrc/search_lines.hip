@@ -40,6 +40,17 @@ __device__ __forceinline__ bool view_uses_ktab(const shard_view &ix, uint32_t k)
     return ix.ktab != nullptr && ix.ktab_depth >= 2u && k >= ix.ktab_depth;
 }
 
+// Entry of T-mer `code` in the plain table's 8-byte form, whatever the table's format (line_format.h)
+__device__ __forceinline__ uint64_t ktab_entry(const uint64_t *__restrict__ ktab, uint32_t fmt, uint32_t T, uint32_t stride, uint64_t code) {
+    if (fmt == KTAB_GROUPED) {
+        const uint32_t gbits = 2u * (T - 1u);
+        const uint64_t g = code & ((1ull << gbits) - 1ull);
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ktab) + g * stride * (uint64_t)KTAB_GROUP_BYTES);
+        return ktab_group_entry(r[0], r[1], r[2], (uint32_t)(code >> gbits) & 3u);
+    }
+    return ktab[code * stride];
+}
+
 __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const uint64_t *pq, uint32_t k) {
     ulonglong2 rec;
     const uint64_t last = pq[(k - 1u) >> 5];
@@ -49,7 +60,7 @@ __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const u
         const uint32_t w0 = off >> 6, sh = off & 63u;
         uint64_t bits = (w0 == ((k - 1u) >> 5) ? last : pq[w0]) >> sh;
         if (sh + 2u * T > 64u) bits |= last << (64u - sh);
-        const uint64_t e = ix.ktab[(bits & ((1ull << (2u * T)) - 1ull)) * ix.ktab_stride];
+        const uint64_t e = ktab_entry(ix.ktab, ix.ktab_fmt, T, ix.ktab_stride, bits & ((1ull << (2u * T)) - 1ull));
         const uint32_t width = (uint32_t)(e >> COUNT_BITS);
         // an entry is an interval of this BWT's rows: one that is not (a damaged table) is not believed --
         // the search then starts from initInterval like an untabulated one and still ends on the right rows

@@ -87,7 +87,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
 
         // FUSED: what start_record() reads of the shard, in scalar registers
         const uint64_t *__restrict__ ktab_p = sv->ktab;
-        const uint32_t ktab_T = sv->ktab_depth, ktab_stride = sv->ktab_stride;
+        const uint32_t ktab_T = sv->ktab_depth, ktab_stride = sv->ktab_stride, ktab_fmt = sv->ktab_fmt;
         const uint64_t ix_n = sv->n;
         const uint64_t sc1 = sv->C[1], sc2 = sv->C[2], sc3 = sv->C[3], sc4 = sv->C[4];
         const uint64_t st1 = sv->total[1], st2 = sv->total[2], st3 = sv->total[3], st4 = sv->total[4];
@@ -258,7 +258,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     const uint32_t alt = d_ < orig ? d_ : d_ + 1u;
                     vword = nword ^ ((uint64_t)(orig ^ alt) << (2u * p_));
                     const uint64_t code = (vword >> (2u * wl_tn)) & ((1ull << (2u * ktab_T)) - 1ull);
-                    entry = ktab_p[code * ktab_stride];
+                    entry = ktab_entry(ktab_p, ktab_fmt, ktab_T, ktab_stride, code);
                 }
             } else if (FUSED) {
                 if (got_n) {
@@ -267,7 +267,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 }
                 if (stage_b) {
                     const uint64_t code = (nword >> (2u * (k - ktab_T))) & ((1ull << (2u * ktab_T)) - 1ull);
-                    entry = ktab_p[code * ktab_stride];
+                    entry = ktab_entry(ktab_p, ktab_fmt, ktab_T, ktab_stride, code);
                 }
             } else if (got_n) {
                 rec = init_s[nq];

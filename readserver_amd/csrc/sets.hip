@@ -299,8 +299,9 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
 
 // The depth rsbwt_set_attach_ktabs(s, 0) would give the shards of device group g: the deepest T whose
 // tables (one per shard of that device without one) fit a third of the device's free HBM, none larger
-// than 5/4 of its shard's lines, with 4^T <= the smallest shard's length; at most 16; 0 = none.
-static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g) {
+// than 5/4 of its shard's lines, with 4^T <= the smallest shard's length; at most 16 (grouped: 17); 0 = none.
+// *fmt: in = the format asked for (KTAB_PLAIN / KTAB_GROUPED), out = the one to build (auto_ktab_depth_for).
+static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt) {
     if (use_device(g->device)) return 0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
@@ -314,38 +315,51 @@ static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g) {
     }
     if (!need) return 0;
     const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, free_b / 3 / need);
-    uint32_t T = 1;
-    while (T < 16u && (8ull << (2u * (T + 1u))) <= budget && (1ull << (2u * (T + 1u))) <= min_n) ++T;
-    return T < 2u ? 0u : T;
+    return auto_ktab_depth_for(budget, min_n, fmt);
 }
 
 uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {
     if (!s) return 0;
     uint32_t T = 16;
-    for (dev_group *g : s->groups) T = std::min(T, auto_ktab_depth(s, g));
+    for (dev_group *g : s->groups) {
+        uint32_t fmt = KTAB_PLAIN;
+        T = std::min(T, auto_ktab_depth(s, g, &fmt));
+    }
     return T;
 }
 
 // Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.  The
 // tables of one device are interleaved in one allocation of the set (line_format.h): the start
-// records of a query for all shards come out of one stretch of 8 x shards bytes.
-static int rsbwt_set_attach_ktabs_body(rsbwt_set_t *s, uint32_t depth) {
+// records of a query for all shards come out of one stretch of 8 x shards (grouped: 12 x shards) bytes.
+// format: RSBWT_KTAB_FORMAT_PLAIN / _GROUPED / _AUTO (grouped where the smallest shard's groups fit their records).
+static int rsbwt_set_attach_ktabs_body(rsbwt_set_t *s, uint32_t depth, uint32_t format) {
     if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (format > RSBWT_KTAB_FORMAT_AUTO) return fail(RSBWT_EINVAL, "k-mer table format %u", format);
     for (dev_group *g : s->groups) {
-        uint32_t T = depth ? depth : auto_ktab_depth(s, g);
-        if (T < 2u || g->d_ktab) continue;
-        if (T > 16u) T = 16;
+        if (g->d_ktab) continue;
         std::vector<size_t> need;
+        uint64_t min_n = ~0ull;
         for (size_t i : g->idx)
-            if (!s->shards[i]->view.ktab && s->shards[i]->view.n) need.push_back(i);
+            if (!s->shards[i]->view.ktab && s->shards[i]->view.n) {
+                need.push_back(i);
+                min_n = std::min(min_n, s->shards[i]->view.n);
+            }
         if (need.empty()) continue;
+        uint32_t fmt = format == RSBWT_KTAB_FORMAT_PLAIN ? KTAB_PLAIN : KTAB_GROUPED;
+        uint32_t T = depth;
+        if (T == 0u) T = auto_ktab_depth(s, g, &fmt);
+        else if (format == RSBWT_KTAB_FORMAT_AUTO && !ktab_grouped_sensible(min_n, T)) fmt = KTAB_PLAIN;
+        if (T < 2u) continue;
+        const uint32_t Tmax = fmt == KTAB_GROUPED ? KTAB_MAX_DEPTH_GROUPED : KTAB_MAX_DEPTH_PLAIN;
+        if (T > Tmax) T = Tmax;
         int rc = use_device(g->device);
         if (rc) return rc;
-        hipError_t e = hipMalloc(&g->d_ktab, (8ull << (2u * T)) * need.size());
+        const uint64_t per = fmt == KTAB_GROUPED ? KTAB_GROUP_BYTES : 8u;  // bytes of one shard's entry / record in a stretch
+        hipError_t e = hipMalloc(&g->d_ktab, ktab_bytes(fmt, T) * need.size());
         if (e != hipSuccess) return fail_hip(e, "allocating the k-mer tables");
         for (size_t j = 0; j < need.size(); ++j) {
             rsbwt_t *h = s->shards[need[j]];
-            rc = attach_ktab_into(h, T, g->d_ktab + j, (uint32_t)need.size());
+            rc = attach_ktab_into(h, T, reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(g->d_ktab) + j * per), (uint32_t)need.size(), fmt);
             if (rc) return rc;
             h->ktab_owned = false;
         }
@@ -353,7 +367,10 @@ static int rsbwt_set_attach_ktabs_body(rsbwt_set_t *s, uint32_t depth) {
     return publish_views(s);
 }
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth) {
-    return guarded("rsbwt_set_attach_ktabs", [&]() -> int { return rsbwt_set_attach_ktabs_body(s, depth); });
+    return guarded("rsbwt_set_attach_ktabs", [&]() -> int { return rsbwt_set_attach_ktabs_body(s, depth, RSBWT_KTAB_FORMAT_PLAIN); });
+}
+int rsbwt_set_attach_ktabs_format(rsbwt_set_t *s, uint32_t depth, uint32_t format) {
+    return guarded("rsbwt_set_attach_ktabs_format", [&]() -> int { return rsbwt_set_attach_ktabs_body(s, depth, format); });
 }
 
 

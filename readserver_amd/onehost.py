@@ -68,9 +68,10 @@ class OneProcessHost:
         n = self.S[g] * self.Q
         return int(self.L.rsbwt_packed_pairs_bytes(n)) if self.wire_packed else 16 * n
 
-    def attach_tables(self, depth):
+    def attach_tables(self, depth, fmt=0):
+        """fmt: RSBWT_KTAB_FORMAT_PLAIN (0) / _GROUPED (1) / _AUTO (2)"""
         for ss in self.subsets:
-            check(self.L.rsbwt_set_attach_ktabs(ss._s, depth))
+            check(self.L.rsbwt_set_attach_ktabs_format(ss._s, depth, fmt))
 
     def auto_table_depth(self):
         return min(int(self.L.rsbwt_set_auto_ktab_depth(ss._s)) for ss in self.subsets)

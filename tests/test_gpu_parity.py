@@ -559,20 +559,33 @@ def test_gpu_window_layout_is_bit_exact(rsb, oracle, style, span):
             assert np.array_equal(lo, elo) and np.array_equal(up, eup)
 
 
+@pytest.mark.parametrize("grouped", [False, True])
 @pytest.mark.parametrize("T", [2, 3, 5, 8, 11])
-def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T):
+def test_gpu_kmer_table_is_bit_exact(rsb, oracle, T, grouped):
     """Searches that start from the k-mer table return exactly what the step-by-step search does
     (early exits inside the tabulated suffix included), for k below, at and above T, and for
-    k-mers whose last T symbols straddle two packed words."""
+    k-mers whose last T symbols straddle two packed words.  grouped: the table's 3-bytes-per-T-mer format
+    (rsbwt_attach_ktab_format) -- T = 2, 3: every group is too wide for its record (all left to the search), T = 11:
+    most T-mers do not occur (left to the search too), in between the records answer."""
     import ctypes as C
     L = rsb.lib()
     runs = np.empty(400000, np.uint8)
     assert L.rsbwt_synth_runs_host(runs.ctypes.data, runs.size, 100 + T) == 0
     oix = oracle.from_runs(runs)
     rng = np.random.default_rng(T)
-    with rsb.GpuBWT(runs=runs, ktab_depth=T) as g, rsb.GpuBWT(runs=runs, ktab_depth=None) as plain:
+    with rsb.GpuBWT(runs=runs, ktab_depth=T, ktab_grouped=grouped) as g, rsb.GpuBWT(runs=runs, ktab_depth=None) as plain:
         assert g.ktab_depth() == T and plain.ktab_depth() == 0
-        assert g.hbm_bytes() == plain.hbm_bytes() + 8 * 4 ** T  # both carry the same lines
+        assert g.hbm_bytes() == plain.hbm_bytes() + (3 if grouped else 8) * 4 ** T  # both carry the same lines
+        fmt, nbytes, left = g.ktab_info()
+        assert (fmt, nbytes) == (1 if grouped else 0, (3 if grouped else 8) * 4 ** T) and plain.ktab_info() == (0, 0, 0)
+        if not grouped:
+            assert left == 0
+        elif T <= 3:
+            assert left == 4 ** T
+        elif T == 8:
+            assert 0 < left < 0.03 * 4 ** T  # (35 rows per 8-mer on average: nearly all occur)
+        elif T == 11:
+            assert left > 0.4 * 4 ** T
         for k in sorted({1, T - 1, T, T + 1, 12, 31, 32, 33, 32 + T // 2, 64, 65, 97}):
             if k < 1:
                 continue
@@ -1022,11 +1035,14 @@ def test_gpu_extraction_equals_the_mirrors_walks(rsb, span, long_runs, R, rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,T,span", [(31, None, 0), (31, 8, 2944), (40, 10, 0), (12, 12, 300)])
-def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k, T, span):
+@pytest.mark.parametrize("k,T,span,grouped", [(31, None, 0, False), (31, 8, 2944, False), (40, 10, 0, False), (12, 12, 300, False),
+                                              (31, 10, 0, True), (31, 12, 0, True), (40, 9, 0, True), (12, 12, 300, True)])
+def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k, T, span, grouped):
     """A single shard and a batch of >= 262,144 k-mers: launch_search takes the one-lane-per-search
     kernel (search_solo.h; smaller batches and shard sets stay on lane pairs).  Intervals, counts and
-    {lower, upper} pairs against the oracle; the work counters of a counting launch add up."""
+    {lower, upper} pairs against the oracle; the work counters of a counting launch add up.  grouped: the k-mer table's
+    12-byte records (the kernel that makes its own start records reads them: FUSED; at T = 12 most 12-mers do not
+    occur and are searched from initInterval)."""
     import ctypes as C
     import torch
     L = rsb.lib()
@@ -1036,7 +1052,8 @@ def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k
     oix = oracle.from_runs(runs)
     rng = np.random.default_rng(k)
     p = lambda t: C.c_void_p(t.data_ptr())
-    with rsb.GpuBWT(runs=runs, ktab_depth=(0 if T is None else T), window_span=span) as g:
+    with rsb.GpuBWT(runs=runs, ktab_depth=(0 if T is None else T), window_span=span, ktab_grouped=grouped) as g:
+        assert g.ktab_info()[0] == (1 if grouped else 0)
         km = _random_kmers(rng, Q, k)
         d_half = torch.empty((Q // 2, k), dtype=torch.uint8, device="cuda:0")
         assert L.rsbwt_sample_present_kmers_dev(g.handle, Q // 2, k, k, 5, p(d_half), None) == 0
@@ -1064,7 +1081,12 @@ def test_gpu_one_lane_per_search_on_a_batch_that_fills_the_launch(rsb, oracle, k
         assert np.array_equal(lo, elo) and np.array_equal(up, eup)
         Td = g.ktab_depth()
         steps = int(np.maximum(st.astype(np.int64) - (max(Td, 1) - 1 if k >= Td else 0), 0).sum())
-        assert w[0] == steps and w[2] <= w[1] <= 2 * w[0]
+        if grouped:  # a T-mer its record leaves to the search takes the steps the table would have saved
+            assert steps <= w[0] <= int(st.astype(np.int64).sum()) and w[2] <= w[1] <= 2 * w[0]
+            if T == 12 and k > T:
+                assert w[0] > steps  # (most 12-mers of 1.4e7 symbols do not occur)
+        else:
+            assert w[0] == steps and w[2] <= w[1] <= 2 * w[0]
         assert w[12] == 1  # one lane per search
         assert L.rsbwt_find_interval_pairs_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_pr), None) == 0
         assert L.rsbwt_count_dev(g.handle, p(d_pk), p(d_ok), Q, k, p(d_lo), None) == 0

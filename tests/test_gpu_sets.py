@@ -490,12 +490,14 @@ def _spelled(km):
     return out
 
 
-@pytest.mark.parametrize("tables", [7, 0])
+@pytest.mark.parametrize("tables", [7, 0, -7, -9])
 def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
     """rsbwt_set_hits_1mm_dev on a one-device set whose shards share a table depth traces the k-mers and resumes their
     variants in ALL shards by one launch each (csrc/sets.hip, set_hits_1mm_fused): every shard's list = the oracle's
     exact search of every spelled-out variant (query.cpp:24-41 per variant), ordered by variant index; a short list
-    buffer keeps the count; the set's own counters show the fused launches ran."""
+    buffer keeps the count; the set's own counters show the fused launches ran.  tables < 0: the set's interleaved
+    tables in their grouped format (rsbwt_set_attach_ktabs_format; at depth 9 most 9-mers of the small shard do not
+    occur and are left to the search)."""
     import torch
     L = rsb.lib()
     dev = torch.device("cuda", 0)
@@ -508,8 +510,14 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
         oixs.append(oracle.from_runs(runs))
         shards.append(rsb.GpuBWT(runs=runs, ktab_depth=None))
     ss = rsb.ShardSet(shards)
-    if tables:
+    if tables > 0:
         assert L.rsbwt_set_attach_ktabs(ss._s, tables) == 0
+    elif tables < 0:
+        assert L.rsbwt_set_attach_ktabs_format(ss._s, -tables, 1) == 0
+        info = [g.ktab_info() for g in shards]
+        assert all(g.ktab_depth() == -tables for g in shards) and all(i[0] == 1 and i[1] == 3 * 4 ** -tables for i in info)
+        if tables == -9:  # the smaller the shard, the more T-mers that do not occur
+            assert info[1][2] > info[0][2] >= info[2][2] and info[1][2] > 0.2 * 4 ** 9
     S = len(sizes)
     rng = np.random.default_rng(61)
     # (31, 1000): 3 x 1000 x 94 = 282,000 variant searches -- the resumed launch then runs on the one-lane-per-search
@@ -556,7 +564,7 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
             w = (C.c_uint64 * 16)()
             assert L.rsbwt_set_last_search_counters(ss._s, w) == 0 and L.rsbwt_set_set_counting(ss._s, 0) == 0
             assert int(w[10]) > 0  # WORK_PASSES of the set's own launch
-            if tables and m * V * S >= 262144:
+            if tables > 0 and m * V * S >= 262144:
                 assert int(w[12]) == 1  # WORK_SOLO: the resumed launch ran on lone lanes
             for s in range(S):
                 idx, elo, eup = want[s]
@@ -617,7 +625,8 @@ def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices):
             g.close()
 
 
-def test_gpu_set_hits_1mm_worklists_keep_the_references_unsigned_carry(rsb):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_gpu_set_hits_1mm_worklists_keep_the_references_unsigned_carry(rsb, grouped):
     """A BWT without '$' whose rows all begin with one symbol: an empty interval at row 0 is (0, 2^64 - 1) and LIVES by
     the reference's unsigned compare (query.cpp:35, rlebwt.cpp:269) -- every variant of every k-mer then 'occurs'.  The
     set's hit lists (worklists: csrc/mm1_worklist.hip) must report exactly what each shard's own list (round 3's
@@ -626,9 +635,9 @@ def test_gpu_set_hits_1mm_worklists_keep_the_references_unsigned_carry(rsb):
     L = rsb.lib()
     k, m = 31, 60
     rng = np.random.default_rng(5)
-    shards = [rsb.GpuBWT(runs=np.full(227, (4 << 5) | 31, np.uint8), ktab_depth=4),            # 7,037 x 'T', no '$'
-              rsb.GpuBWT(runs=((rng.integers(0, 5, 40000).astype(np.uint8) << 5) | rng.integers(1, 32, 40000).astype(np.uint8)), ktab_depth=4),
-              rsb.GpuBWT(runs=np.full(1, (2 << 5) | 31, np.uint8), ktab_depth=4)]               # 31 x 'C'
+    shards = [rsb.GpuBWT(runs=np.full(227, (4 << 5) | 31, np.uint8), ktab_depth=4, ktab_grouped=grouped),            # 7,037 x 'T', no '$'
+              rsb.GpuBWT(runs=((rng.integers(0, 5, 40000).astype(np.uint8) << 5) | rng.integers(1, 32, 40000).astype(np.uint8)), ktab_depth=4, ktab_grouped=grouped),
+              rsb.GpuBWT(runs=np.full(1, (2 << 5) | 31, np.uint8), ktab_depth=4, ktab_grouped=grouped)]               # 31 x 'C'
     ss = rsb.ShardSet(shards)
     assert L.rsbwt_set_hits_1mm_is_fused(ss._s, m, k) == 1
     km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (m, k))].copy()

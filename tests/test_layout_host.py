@@ -125,3 +125,53 @@ def test_select_samples_and_psi_hints_are_exact(rsb, style, R, span, room):
         assert hint_lines >= 0.9 * nwin - 8, (hint_lines, nwin)
         if style == "pop":
             assert by_hint > 0.8 * n, (by_hint, n)
+
+
+def test_grouped_ktab_record_code(rsb):
+    """The 12-byte record of four sibling T-mers (line_format.h, rsbwt_attach_ktab_format): what it gives back is the
+    sibling's interval exactly, or 'left to the search' -- for an empty sibling (the reference's empty interval depends
+    on the step the search died at: query.cpp:33-38), a group of 16383 rows or more, siblings that do not tile."""
+    L = rsb.lib()
+    rng = np.random.default_rng(5)
+    G = 20000
+    WIDE = 0xFFFFFF
+    base = rng.integers(0, (1 << 40) - (1 << 20), G).astype(np.uint64)
+    base[:8] = [0, 1, (1 << 40) - 70000, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 255 << 32, (1 << 40) - 16384]
+    width = rng.integers(0, 6, (G, 4)).astype(np.uint64) * rng.integers(0, 3000, (G, 4)).astype(np.uint64)
+    width[rng.random((G, 4)) < 0.2] = 0
+    width[10] = [16382, 0, 0, 0]     # the widest group a record holds
+    width[11] = [16383, 0, 0, 0]     # one row too many
+    width[12] = [4000, 4000, 4000, 4382]
+    width[13] = [0, 0, 0, 0]
+    width[14] = [0, 0, 0, 1]
+    lower = np.zeros((G, 4), np.uint64)
+    upper = np.zeros((G, 4), np.uint64)
+    at = base.copy()
+    for i in range(4):
+        live = width[:, i] > 0
+        lower[:, i] = np.where(live, at, rng.integers(1, 1 << 40, G).astype(np.uint64))  # an empty interval sits anywhere
+        upper[:, i] = lower[:, i] + width[:, i] - np.uint64(1)
+        at = at + width[:, i]
+    # groups that do not tile (never for a sound BWT): a gap before the last live sibling
+    untiled = np.zeros(G, bool)
+    for g in range(100, 200):
+        live = np.nonzero(width[g] > 0)[0]
+        if len(live) >= 2:
+            lower[g, live[-1]] += np.uint64(1)
+            upper[g, live[-1]] += np.uint64(1)
+            untiled[g] = True
+    # the reference's (0, 2^64 - 1) carry (query.cpp:35) is an empty interval too
+    lower[15, 0], upper[15, 0], width[15, 0] = 0, np.uint64(0xFFFFFFFFFFFFFFFF), 0
+    out = np.zeros((G, 4), np.uint64)
+    assert L.rsbwt_ktab_group_selftest_host(lower.ctypes.data, upper.ctypes.data, G, out.ctypes.data) == 0
+    total = width.sum(axis=1)
+    escaped = (total >= 16383) | untiled
+    got_w = (out >> np.uint64(40)).astype(np.int64)
+    got_lo = out & np.uint64((1 << 40) - 1)
+    for i in range(4):
+        said = ~escaped & (width[:, i] > 0)
+        assert np.array_equal(got_w[said, i], width[said, i].astype(np.int64))
+        assert np.array_equal(got_lo[said, i], lower[said, i])
+        assert np.all(got_w[~said, i] == WIDE)
+    assert not escaped[10] and escaped[11] and not escaped[12] and np.all(got_w[13] == WIDE) and got_w[14, 3] == 1
+    assert (~escaped).sum() > 0.5 * G and escaped.sum() > 1000  # both kinds are well represented
