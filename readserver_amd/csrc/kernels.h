@@ -98,6 +98,11 @@ uint32_t trace_entries(const shard_view &ix, uint32_t k);
 // (the lists' lengths sit WL_COUNT_STRIDE u64 apart: appended to by every wave of the branch kernel, they must not share
 // a cache line -- eight counters in one line serialised the kernel at one atomic at a time: 10 ms instead of 3)
 constexpr uint32_t WL_COUNT_STRIDE = 32;
+// the search kernels' query pools (one counter per shard, drawn from by every wave of the launch) sit POOL_STRIDE u64
+// apart too: eight adjacent counters are one line of one L2 channel, and a small batch -- 4,096 waves probing eight
+// drained pools each -- then waits on that line longer than it searches (0.58 against 0.32 ms for 4e4 31-mers x 8 shards
+// with a quarter of the waves)
+constexpr uint32_t POOL_STRIDE = 32;
 hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t m,
                                 uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,
                                 void *d_counts, void *d_sparse, void *d_hit_bits, int num_cus, hipStream_t stream,

@@ -64,21 +64,49 @@ wl_own_kernel(const ulonglong2 *__restrict__ own, const uint8_t *__restrict__ va
     atomicOr(hit_bits + s * hit_map_words(mv) + (canon >> 6), 1ull << (canon & 63u));
 }
 
-// Occ of the THREE symbols other than `skip` (0..3 = A..T) up to offset o (1-based, within the line's own pieces:
-// o <= span) of a staged line: out[a] for a = 0..3 (out[skip] is left alone).  One look at the quarter's 24 pieces for
-// all of them: the running symbol totals, the dword holding the position and its prefix sums do not depend on the
-// symbol (rank_device.h, char_rank24, taken apart).
-__device__ __forceinline__ void staged_occ3(const staged_line &L, const line_head &h, uint32_t o, uint32_t skip, uint64_t out[4]) {
+// Occ of the THREE bases other than `orig` (0..3 = A..T) up to offset o (1-based, within the line's own pieces:
+// o <= span) of a staged line: out[d] for the d-th base of ACGT without the original one.  One look at the quarter's
+// 24 pieces for all of them (rank_device.h, char_rank24, taken apart): what does not depend on the symbol -- the
+// pieces' lengths and symbols, the dword and the piece holding the position, the lengths that lie BEFORE it (every
+// other length masked to zero: a piece of no length counts for no symbol) -- is computed once; a base then costs
+// four instructions per dword: its match mask with the matching bytes at 0x80, and a v_dot4 against the masked
+// lengths, the sum shifted down by 7 once.  (The first version ran the whole of char_rank24's count per base and
+// position, three times over in the kernel: 2,195 VALU instructions per pass, which bound the launch.)
+__device__ __forceinline__ void staged_occ_alts(const staged_line &L, const line_head &h, uint32_t o, uint32_t orig, uint64_t out[3]) {
     const uint32_t cq = (o > h.s1 ? 1u : 0u) + (o > h.s2 ? 1u : 0u) + (o > h.s3 ? 1u : 0u);
     const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
     const uint32_t rem = o - start;  // >= 1
-    uint32_t r[6], e[6];  // the quarter holding the position; the earlier quarter of its half (added whole when cq is odd)
+    // the earlier quarter of the position's half, added whole when cq is odd -- first, so that its registers are free again
+    uint32_t me[3];
+    {
+        uint32_t e[6], le[6], se[6];
+        load24(L, HDR_DWORDS + 6u * (cq & 2u), e);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            le[i] = e[i] & 0x1F1F1F1Fu;
+            se[i] = (e[i] >> 5) & 0x07070707u;
+        }
+#pragma unroll
+        for (uint32_t d = 0; d < 3u; ++d) {
+            const uint32_t bb = splat_byte((d < orig ? d : d + 1u) + 1u);
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m = __builtin_amdgcn_udot4(le[i], (0x80808080u - (se[i] ^ bb)) & 0x80808080u, m, false);
+            me[d] = (cq & 1u) ? (m >> 7) : 0u;
+        }
+    }
+    uint32_t r[6];  // the quarter holding the position
     load24(L, HDR_DWORDS + 6u * cq, r);
-    load24(L, HDR_DWORDS + 6u * (cq & 2u), e);
+    uint32_t lr[6], sr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        lr[i] = r[i] & 0x1F1F1F1Fu;
+        sr[i] = (r[i] >> 5) & 0x07070707u;
+    }
     uint32_t cum[6];
     cum[0] = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) cum[i + 1] = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, 0x01010101u, cum[i], false);
+    for (int i = 0; i < 5; ++i) cum[i + 1] = __builtin_amdgcn_udot4(lr[i], 0x01010101u, cum[i], false);
     uint32_t x = r[0], base = 0, di = 0;
 #pragma unroll
     for (int i = 1; i < 6; ++i) {
@@ -92,22 +120,18 @@ __device__ __forceinline__ void staged_occ3(const staged_line &L, const line_hea
     const uint32_t jj = (rd > (ps & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 8) & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 16) & 0xFFu) ? 1u : 0u);
     const uint32_t here = (x >> (8u * jj + 5u)) & 7u;
     const uint32_t pj = jj ? __builtin_amdgcn_ubfe(ps, 8u * jj - 8u, 8u) : 0u;
-    const uint32_t xm = x & ((1u << (8u * jj)) - 1u);
     const uint32_t reach = rd <= (ps >> 24) ? rd - pj : (ps >> 24) - pj;
+    // the lengths before the position: whole dwords before dword di, dword di's pieces before piece jj, nothing after
+    const uint32_t inner = (1u << (8u * jj)) - 1u;
 #pragma unroll
-    for (uint32_t a = 0; a < 4u; ++a) {
-        if (a == skip) continue;
-        const uint32_t b = a + 1u, bb = splat_byte(b);
-        uint32_t before = 0, mc = 0, me = 0;
+    for (uint32_t i = 0; i < 6u; ++i) lr[i] = i < di ? lr[i] : (i == di ? lr[i] & inner : 0u);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            mc = dword_matched(r[i], bb, mc);
-            before = (uint32_t)(i + 1) <= di ? mc : before;
-        }
+    for (uint32_t d = 0; d < 3u; ++d) {
+        const uint32_t b = (d < orig ? d : d + 1u) + 1u, bb = splat_byte(b);
+        uint32_t acc = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) me = dword_matched(e[i], bb, me);
-        const uint32_t inner = dword_matched(xm, bb, 0u);
-        out[a] = read_count(L, b) + (cq >= 2u ? read_half(L, b) : 0u) + ((cq & 1u) ? me : 0u) + before + inner + (here == b ? reach : 0u);
+        for (int i = 0; i < 6; ++i) acc = __builtin_amdgcn_udot4(lr[i], (0x80808080u - (sr[i] ^ bb)) & 0x80808080u, acc, false);
+        out[d] = read_count(L, b) + (cq >= 2u ? read_half(L, b) : 0u) + me[d] + (acc >> 7) + (here == b ? reach : 0u);
     }
 }
 
@@ -180,47 +204,36 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
             const bool needL = have && lo != 0ull;
             const bool needU = have && hi != ~0ull;  // (Occ(b, 2^64 - 1) = Occ(b, -1) = 0: rlebwt.cpp:269)
             const uint32_t orig = (uint32_t)((word >> (2u * j)) & 3u);  // (its own step is the traced search's: not taken again)
-            uint64_t occL[4] = {0, 0, 0, 0}, occU[4] = {0, 0, 0, 0};
-            bool gotU = !needU, spill = false;
-            // ---- pass A: the line of lower - 1 (or, at lower = 0, of upper)
-            {
-                const uint32_t wA = needL ? wL : wU;
-                uint32_t line = wA + (wA >> GROUP_SHIFT);
-                if (line >= nlines) line = 0;
-                const bool fetchA = needL || needU;
-                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fetchA));
-                glds_fetch(lines_bytes, fetchA ? line : ~0u, lane, stage_lds);
-                glds_wait();
-                if (fetchA) {
-                    const line_head h = read_head(L);
-                    if (needL) {
-                        if (oL > h.span) spill = true;
-                        else staged_occ3(L, h, oL, orig, occL);
-                    }
-                    if (!spill && needU && (!needL || wU == wL)) {  // upper out of the same staged line
-                        if (oU > h.span) spill = true;
-                        else {
-                            staged_occ3(L, h, oU, orig, occU);
-                            gotU = true;
-                        }
-                    }
-                }
-            }
-            // ---- pass B: the line of upper where it is another one (a wave-uniform skip when nobody needs it)
+            uint64_t occL[3] = {0, 0, 0}, occU[3] = {0, 0, 0};
+            bool spill = false;
+            // ---- two passes over ONE copy of the code: A fetches the line of lower - 1 (at lower = 0: of upper) and
+            // ranks lower - 1 in it; B fetches the line of upper where it is another one (a wave-uniform skip when no
+            // lane needs it; the row of a lane that fetches nothing keeps pass A's line) and ranks upper in the lane's row
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < 2u; ++pass) {
+                const bool isU = pass != 0u;
 #ifdef RSB_BRANCH_NO_PASS_B  // timing experiment (tools/build_variant.sh): such items go to the worklist unstepped instead
-            if (have && !spill && !gotU) spill = true;
+                if (isU && needL && needU && wU != wL) spill = true;
 #endif
-            const bool needB = have && !spill && !gotU;
-            if (__builtin_amdgcn_ballot_w64(needB) != 0ull) {
-                uint32_t line = wU + (wU >> GROUP_SHIFT);
+                const bool fetch = isU ? (needL && needU && wU != wL && !spill) : (needL || needU);
+                const uint32_t wsel = (isU || !needL) ? wU : wL;
+                uint32_t line = wsel + (wsel >> GROUP_SHIFT);
                 if (line >= nlines) line = 0;
-                if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(__builtin_amdgcn_ballot_w64(needB));
-                glds_fetch(lines_bytes, needB ? line : ~0u, lane, stage_lds);
-                glds_wait();
-                if (needB) {
-                    const line_head h = read_head(L);
-                    if (oU > h.span) spill = true;
-                    else staged_occ3(L, h, oU, orig, occU);
+                const uint64_t fmask = __builtin_amdgcn_ballot_w64(fetch);
+                if (fmask != 0ull) {
+                    if (COUNT_WORK_BRANCH(work)) w_lines += __builtin_popcountll(fmask);
+                    glds_fetch(lines_bytes, fetch ? line : ~0u, lane, stage_lds);
+                    glds_wait();
+                }
+                const line_head h = read_head(L);
+                const bool need = isU ? needU : needL;
+                const uint32_t o = isU ? oU : oL;
+                if (need && o > h.span) spill = true;
+                uint64_t t3[3];
+                staged_occ_alts(L, h, need ? o : 1u, orig, t3);  // (every lane: a lane without the lookup drops the result)
+                if (need && !spill) {
+                    if (isU) { occU[0] = t3[0]; occU[1] = t3[1]; occU[2] = t3[2]; }
+                    else { occL[0] = t3[0]; occL[1] = t3[1]; occL[2] = t3[2]; }
                 }
             }
             // ---- the three substitutions of position j: updateInterval (query.cpp:11-15) with the substituted symbol
@@ -231,10 +244,8 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
             for (uint32_t d = 0; d < 3u; ++d) {
                 const uint32_t alt = d < orig ? d : d + 1u;  // the d-th base of ACGT without the original one
                 const uint64_t cb = alt == 0u ? c1 : alt == 1u ? c2 : alt == 2u ? c3 : c4;
-                const uint64_t oL_ = alt == 0u ? occL[0] : alt == 1u ? occL[1] : alt == 2u ? occL[2] : occL[3];
-                const uint64_t oU_ = alt == 0u ? occU[0] : alt == 1u ? occU[1] : alt == 2u ? occU[2] : occU[3];
-                nlo[d] = cb + oL_;
-                nhi[d] = cb + oU_ - 1ull;
+                nlo[d] = cb + occL[d];
+                nhi[d] = cb + occU[d] - 1ull;
                 const bool stepped_live = have && !spill && nlo[d] <= nhi[d];
                 const bool final_hit = stepped_live && j == 0u;
                 enq[d] = (stepped_live && j != 0u) || (have && spill);

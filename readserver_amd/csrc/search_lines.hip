@@ -196,7 +196,10 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
         // its own, and requests are what this kernel is bound by
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
-        unsigned long long *pool = next_query + sid;
+        unsigned long long *pool = next_query + (size_t)sid * POOL_STRIDE;
+        // (a pool other waves have drained already is left with a load: an atomic on a line every wave of the launch
+        // probes at the end is what the tail of a launch, and most of a small one, would wait for)
+        if (visited != 0u && __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)Q) continue;
         // a traced search's record and a hit-list search's map are per shard: [s][Q][trace_n], [s][hit_map_words(Q)]
         ulonglong2 *trace_s = trace ? trace + (size_t)sid * Q * trace_n : nullptr;
         unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
@@ -671,7 +674,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     const bool fused = solo && nshards == 1 && extra && extra->narrow && !extra->d_init && !resumed && !trace && wpq == 1 && !no_fused_start;
     const bool prepared = (extra && extra->d_init) || fused;  // the start records exist already / are not needed: only the counters are scratch
     scratch_cache::lease mem;
-    hipError_t e = scratch.take((prepared ? 0 : nrec * sizeof(ulonglong2)) + nshards * sizeof(unsigned long long), stream, &mem);
+    hipError_t e = scratch.take((prepared ? 0 : nrec * sizeof(ulonglong2)) + nshards * POOL_STRIDE * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
     if (counts_only) {  // counts: only the searches that find something store theirs
         e = hipMemsetAsync(d_lower, 0, nrec * sizeof(uint64_t), stream);
@@ -682,7 +685,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     }
     ulonglong2 *init = fused ? nullptr : prepared ? (ulonglong2 *)extra->d_init : (ulonglong2 *)mem.p;
     unsigned long long *ctr = prepared ? (unsigned long long *)mem.p : (unsigned long long *)(init + nrec);
-    e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
+    e = hipMemsetAsync(ctr, 0, nshards * POOL_STRIDE * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
         scratch.give(mem, stream);
         return e;
@@ -740,10 +743,10 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
     const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
     if (g > cap) g = cap;
     scratch_cache::lease mem;
-    hipError_t e = scratch.take(nshards * sizeof(unsigned long long), stream, &mem);
+    hipError_t e = scratch.take(nshards * POOL_STRIDE * sizeof(unsigned long long), stream, &mem);
     if (e != hipSuccess) return e;
     unsigned long long *ctr = (unsigned long long *)mem.p;
-    e = hipMemsetAsync(ctr, 0, nshards * sizeof(unsigned long long), stream);
+    e = hipMemsetAsync(ctr, 0, nshards * POOL_STRIDE * sizeof(unsigned long long), stream);
     if (e != hipSuccess) {
         scratch.give(mem, stream);
         return e;

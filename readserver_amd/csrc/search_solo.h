@@ -71,7 +71,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint32_t wl_tn = trace_n, wl_per = WL ? 3u * (k - trace_n) : 1u;  // (WL: trace_n carries tn; 3T implicit items per k-mer)
         uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
-        unsigned long long *pool = next_query + sid;
+        unsigned long long *pool = next_query + (size_t)sid * POOL_STRIDE;
+        if (visited != 0u && __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)Qs) continue;  // (search_lines_kernel: drained already)
         // per shard, as in search_lines_kernel: traces [s][Q][trace_n], hit maps [s][hit_map_words(Q)]
         ulonglong2 *trace_s = (trace && !WL) ? trace + (size_t)sid * Q * trace_n : nullptr;
         unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
