@@ -98,6 +98,38 @@ search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
     init[s * Q + q] = rec;
 }
 
+// The same through LDS for 2..256 shards: a block computes V = 256 / S queries x S shards (adjacent lanes = the shards
+// of one query: one stretch of the interleaved tables per query), turns the records round in LDS and writes V
+// consecutive records per shard -- 512 B per shard and block on 8 shards where the plain kernel writes 256 records of
+// 16 B each into 256 different lines (it ran at a request ceiling of its own: 0.66 ms of the 21 ms headline step).
+__global__ void __launch_bounds__(256)
+search_init_tiled_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                         const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t wpq, uint32_t V,
+                         ulonglong2 *__restrict__ init) {
+    __shared__ ulonglong2 tile[256];
+    const size_t q0 = (size_t)blockIdx.x * V;
+    const uint32_t t = threadIdx.x;
+    {
+        const uint32_t v = t / nshards, s = t - v * nshards;
+        if (v < V && q0 + v < Q) {
+            const size_t q = q0 + v;
+            ulonglong2 rec;
+            if (valid[q] == 0) {
+                rec.x = INIT_INVALID;
+                rec.y = 0;
+            } else {
+                rec = start_record(shards[s], packed + q * wpq, k);
+            }
+            tile[v * nshards + s] = rec;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t s = t / V, v = t - s * V;
+        if (s < nshards && q0 + v < Q) init[(size_t)s * Q + q0 + v] = tile[v * nshards + s];
+    }
+}
+
 // Start records of the 3k+1 variants of m k-mers (1-mismatch search, variants_kernel's order).  A
 // variant whose substituted position is left of the k-mer table's reach shares its whole suffix
 // with the k-mer itself: it starts from the interval the k-mer's own (traced) search had when it
@@ -609,13 +641,25 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
                            pk, init, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
 }
 
+static void launch_init(const shard_view *d_shards, uint32_t nshards, const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k,
+                        uint32_t wpq, ulonglong2 *init, hipStream_t stream) {
+    static const bool untiled = getenv("RSBWT_INIT_UNTILED") != nullptr;  // A/B knob (tools/README.md)
+    if (nshards >= 2u && nshards <= 256u && !untiled) {
+        const uint32_t V = 256u / nshards;
+        hipLaunchKernelGGL(search_init_tiled_kernel, dim3((unsigned)((Q + V - 1) / V)), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q,
+                           k, wpq, V, init);
+    } else {
+        const size_t nrec = Q * nshards;
+        hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k,
+                           wpq, init);
+    }
+}
+
 hipError_t launch_search_init(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t Q,
                               uint32_t k, void *d_init, hipStream_t stream) {
     if (Q == 0 || nshards == 0) return hipSuccess;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    const size_t nrec = Q * nshards;
-    hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, d_shards, nshards,
-                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, Q, k, wpq, (ulonglong2 *)d_init);
+    launch_init(d_shards, nshards, (const uint64_t *)d_packed, (const uint8_t *)d_valid, Q, k, wpq, (ulonglong2 *)d_init, stream);
     return hipGetLastError();
 }
 
@@ -697,7 +741,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         hipLaunchKernelGGL(search_init_1mm_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq,
                            extra->variants, (const ulonglong2 *)extra->d_trace_in, trace_n, init);
     else
-        hipLaunchKernelGGL(search_init_kernel, dim3(ig), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k, wpq, init);
+        launch_init(d_shards, nshards, pk, vd, Q, k, wpq, init, stream);
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (extra && extra->table_build && !d_work && !counts_only && wpq == 1) {
         uint32_t qchunk = 1024;
