@@ -137,6 +137,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def mode_source_sha():
+    """Identifies the kernels a PMC traffic figure of --mode 1mm / extract was measured on: every source under csrc/."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "readserver_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic_mode(mode, R, S, units):
+    """HBM bytes per step of the kernels roofline.kernel_ms covers in --mode 1mm / extract, from the committed PMC passes of
+    the same command (profiles/pmc_traffic_modes.json, tools/collect_mode_profile.py) -- only if they were measured on these
+    very sources and sizes; otherwise None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_modes.json")))[mode]
+        if (d["source_sha"] == mode_source_sha() and int(d["run_bytes_per_shard"]) == R and int(d["shards_per_gpu"]) == S
+                and int(d["units_per_batch"]) == units):
+            return d["hbm_bytes_per_step_covered_kernels"]
+    except Exception:
+        pass
+    return None
+
+
 def pick_tables(a, free_b, S, n_sym, T):
     """(depth, format) of the job's k-mer tables: from the auto depth T up while S tables still leave 8 GB of the free HBM
     and the T-mers are still expected to occur; the grouped format (3 B per T-mer) where it gets a level deeper than
@@ -907,23 +930,35 @@ def run_rows(a, c):
                 verified = (all(int(blocks[r].sum(dtype=torch.int64).item()) == int(sums[r][0].item()) for r in range(world))
                             and int(first[-1]) == sum(int(x[1].item()) for x in sums) and rec.shape[0] == int(first[-1]))
         overflowed = bool((tot_local > cap).any().item())  # (a list longer than its buffer keeps its count and drops records)
+        cpu_base = None
         if world == 1 and a.verify_rows > 0:
-            # shard 0's list of the last batch against the oracle's exact search of every variant of the first k-mers
+            # shard 0's list of the last batch against the oracle's exact search of every variant of the first k-mers -- and
+            # that search, timed, is the CPU baseline of this mode (the composition SURVEY 8 f3 defines: 3k + 1 findInterval
+            # calls per 31-mer, query.cpp:24-41, on every core this process may use)
             oix = oracle_of_shard0(a, c, mix)
-            nv = int(min(a.verify_rows, M))
+            nv = int(min(max(a.verify_rows, 20000 if a.cpu_sample > 0 else 0), M))
             acgt = np.frombuffer(b"ACGT", np.uint8)
             kmh = d_km[:nv].cpu().numpy()
             sp_ = np.repeat(kmh[:, None, :], V, axis=1)
+            alt_tab = np.array([[x for x in acgt if x != o][:3] for o in acgt], np.uint8)  # the bases other than A / C / G / T, in order
+            code = np.searchsorted(acgt, kmh)  # 0..3 (the batch holds ACGT only)
             for pos in range(k):
-                for q_ in range(nv):
-                    sp_[q_, 1 + 3 * pos:4 + 3 * pos, pos] = [x for x in acgt if x != kmh[q_, pos]][:3]
-            vlo, vup = oix.find_intervals(sp_.reshape(-1, k), nthreads=usable_cpus())
+                sp_[:, 1 + 3 * pos:4 + 3 * pos, pos] = alt_tab[code[:, pos]]
+            nthreads = a.cpu_threads if a.cpu_threads > 0 else usable_cpus()
+            t_c = time.perf_counter()
+            vlo, vup = oix.find_intervals(sp_.reshape(-1, k), nthreads=nthreads)
+            t_c = time.perf_counter() - t_c
             n0 = int(oix.bwlen())
-            want = [(int(vlo[i]), int(vup[i]), i) for i in range(nv * V) if vup[i] >= vlo[i] and vup[i] < n0]
+            widx = np.nonzero((vup >= vlo) & (vup < np.uint64(n0)))[0]
             h0 = (d_h[last % 2] if d_h is not None else gat_h.acquire(last))[0]
             rec0 = h0[:min(int(tot_local[0].item()), cap)].cpu().numpy().view(np.uint64)
-            got = [(int(r_[0]), int(r_[1]), int(r_[2])) for r_ in rec0 if r_[2] < nv * V]
-            verified = (got == want) and not overflowed
+            rec0 = rec0[rec0[:, 2] < np.uint64(nv * V)]
+            verified = bool(rec0.shape[0] == widx.size and np.array_equal(rec0[:, 2], widx.astype(np.uint64))
+                            and np.array_equal(rec0[:, 0], vlo[widx]) and np.array_equal(rec0[:, 1], vup[widx])) and not overflowed
+            cpu_base = {"value": nv / t_c, "unit": "(31-mer x shard) 1-mismatch searches/s", "cores": nthreads, "kind": "port",
+                        "sample": f"the first {nv} 31-mers of the batch on shard 0's index ({int(a.runs)} run bytes): {V} exact searches each "
+                                  f"(oracle/rlebwt_oracle.c, {nthreads} POSIX threads, {t_c:.1f} s), the same lists the GPU's are held to",
+                        "exact_searches_per_s": nv * V / t_c, "gpu_matches_oracle_on_sample": verified}
             oix.close()
         hits_local = int(torch.minimum(tot_local, torch.full_like(tot_local, cap)).sum().item())  # (what the lists hold)
         alg = w[2] * LINE_BYTES + S * M * V * 24 + hits_local * 48
@@ -951,7 +986,7 @@ def run_rows(a, c):
                            lf_steps_per_variant=w[0] / (S * M * V), hit_lists_verified=verified,
                            travels=(None if world == 1 else f"[{S}][{cap}] 32-byte records + {S} counts per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _pmc_traffic_mode("1mm", int(a.runs), S, M) if fused else None,
                          "frac_of_step": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
                          "kernel": ("search_lines_kernel (the k-mers traced, their variants resumed): all the rank's shards in one launch each"
                                     if fused else
@@ -959,7 +994,7 @@ def run_rows(a, c):
                                     if side_by_side else
                                     "search_lines_kernel (the k-mers traced, their variants resumed), summed over the rank's shards"),
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": w[2]},
-            "cpu_baseline": None,
+            "cpu_baseline": cpu_base,
         }
     else:
         NR, stride, run = int(a.rows), a.stride, max(1, a.row_run)
@@ -1040,23 +1075,32 @@ def run_rows(a, c):
         dt = max_over_ranks(time.perf_counter() - t1)
         k_ms = ev0.elapsed_time(ev1) / a.steps  # the walk kernels of one batch (current stream; the gather runs beside them)
         verified = None
+        cpu_base = None
         if world == 1 and a.verify_rows > 0:
-            # reads of shard 0 of the last batch against the oracle's extractPrefix + extractPostfix of the same rows
+            # reads of shard 0 of the last batch against the oracle's extractPrefix + extractPostfix of the same rows -- and
+            # that walk, timed, is the CPU baseline of this mode (query.cpp:43-85 per row, one thread)
             oix = oracle_of_shard0(a, c, mix)
             lastb = (step_no[0] - 1) % 2
-            pick = np.unique(np.linspace(0, NR - 1, int(min(a.verify_rows, NR))).astype(np.int64))
+            pick = np.unique(np.linspace(0, NR - 1, int(min(max(a.verify_rows, 5000 if a.cpu_sample > 0 else 0), NR))).astype(np.int64))
             pick_t = torch.from_numpy(pick).to(dev)
             o_h = d_full[lastb][0][pick_t].cpu().numpy()
             l_h = d_lenb[lastb][0][pick_t].cpu().numpy().view(np.uint32)
             r_h = rows[0][pick_t].cpu().numpy()
+            t_c = time.perf_counter()
+            cpu_reads = [oix.extract(int(r_), cap=8192) for r_ in r_h]
+            t_c = time.perf_counter() - t_c
             verified = True
-            for i_ in range(pick.size):
-                pre, post = oix.extract(int(r_h[i_]), cap=8192)
+            for i_, (pre, post) in enumerate(cpu_reads):
                 if len(pre) + len(post) <= stride:
                     verified = verified and l_h[i_] == len(pre) + len(post) and o_h[i_, :l_h[i_]].tobytes().decode() == pre + post
                 else:
                     verified = verified and l_h[i_] == 0xFFFFFFFF
             verified = bool(verified)
+            cpu_base = {"value": pick.size / t_c, "unit": "reads/s", "cores": 1, "kind": "port",
+                        "sample": f"{pick.size} evenly spaced rows of the batch on shard 0's index ({int(a.runs)} run bytes): extractPrefix + "
+                                  f"extractPostfix each (oracle/rlebwt_oracle.c through its ctypes binding, one thread, {t_c:.1f} s), the same "
+                                  "reads the GPU's are held to",
+                        "bases_per_s": sum(len(x) + len(y) for x, y in cpu_reads) / t_c, "gpu_matches_oracle_on_sample": verified}
             oix.close()
         if world > 1:
             last = step_no[0] - 1
@@ -1091,10 +1135,10 @@ def run_rows(a, c):
                            window_lines_with_a_psi_hint=int(L.rsbwt_psi_hint_lines(shards[0].handle)) / max(int(shards[0].num_lines()) * 16 // 17, 1),
                            travels=(None if world == 1 else f"[{S}][{NR}][{stride // 4}] bytes of 2-bit bases (rsbwt_pack_reads_dev) + [{S}][{NR}] lengths per rank and batch")),
             "roofline": {"bound": "hbm", "achieved": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": steps_alg * LINE_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _pmc_traffic_mode("extract", int(a.runs), S, NR),
                          "kernel": "extract_prefix_wave_kernel + move_prefix16_kernel + extract_postfix_wave_kernel: one launch each over all the rank's shards",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": steps_alg * LINE_BYTES, "lf_and_psi_steps": steps_alg},
-            "cpu_baseline": None,
+            "cpu_baseline": cpu_base,
         }
     sset.close()
     for g in shards:

@@ -212,9 +212,6 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
 #pragma unroll 1
             for (uint32_t pass = 0; pass < 2u; ++pass) {
                 const bool isU = pass != 0u;
-#ifdef RSB_BRANCH_NO_PASS_B  // timing experiment (tools/build_variant.sh): such items go to the worklist unstepped instead
-                if (isU && needL && needU && wU != wL) spill = true;
-#endif
                 const bool fetch = isU ? (needL && needU && wU != wL && !spill) : (needL || needU);
                 const uint32_t wsel = (isU || !needL) ? wU : wL;
                 uint32_t line = wsel + (wsel >> GROUP_SHIFT);

@@ -58,6 +58,26 @@ def test_gpu_golden_ladder(rsb, gix, golden, fixture_bwt):
         assert np.array_equal(up, golden[f"upper{kk}"]), kk
 
 
+@pytest.mark.parametrize("T", [4, 6, 9])
+def test_gpu_golden_vectors_behind_a_grouped_table(rsb, golden, fixture_bwt, T):
+    """The reference's own answers on the golden popBWT (a VALID BWT of '$'-terminated reads) from searches that start
+    in the grouped k-mer table (rsbwt_attach_ktab_format): the four T-mers that differ in their last symbol tile one
+    stretch of rows there too -- rows that begin with a shorter suffix and '$' sort before them -- so the records
+    answer for the T-mers that occur, and the others are searched from initInterval: same intervals either way."""
+    path, meta = fixture_bwt
+    with rsb.GpuBWT(path, ktab_depth=T, ktab_grouped=True) as g:
+        fmt, nbytes, left = g.ktab_info()
+        assert (fmt, nbytes, g.ktab_depth()) == (1, 3 * 4 ** T, T)
+        n = g.getBWLen()
+        if 64 * 4 ** T <= n and 4 * n <= 16383 * 4 ** T:  # many rows per T-mer, a group's rows fit its record
+            assert left < 0.5 * 4 ** T, (left, n)
+        lo, up = rsb.find_intervals(g, golden["kmers31"])
+        assert np.array_equal(lo, golden["lower31"]) and np.array_equal(up, golden["upper31"])
+        for kk in meta["ladder"]:
+            lo, up = rsb.find_intervals(g, golden[f"kmers{kk}"])
+            assert np.array_equal(lo, golden[f"lower{kk}"]) and np.array_equal(up, golden[f"upper{kk}"]), kk
+
+
 def test_gpu_golden_occ_char_occ_at(gix, golden):
     pos = golden["occ_pos"]
     for c, ch in enumerate("$ACGT"):

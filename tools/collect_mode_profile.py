@@ -2,7 +2,10 @@
 """Condenses gpurun_out/prof_<mode>_<tag>/ (tools/profile_mode.sh) into profiles/<tag>_<mode>_kernel_stats.csv and
 profiles/<tag>_<mode>_pmc.json: per-launch means of every counter for the kernels whose name contains one of the
 substrings given (default: the walk kernels and the search kernel).
-usage: tools/collect_mode_profile.py TAG MODE [kernel substring ...]"""
+Also profiles/pmc_traffic_modes.json[MODE]: HBM bytes per step of the kernels bench.py's roofline.kernel_ms covers in that mode
+(and of every kernel of the step), from the FETCH_SIZE / WRITE_SIZE passes corrected as collect_profiles.py does, keyed by the
+SHA of csrc/ and the sizes of the run -- bench.py reports it as roofline.traffic when they match.
+usage: tools/collect_mode_profile.py TAG MODE [kernel substring ...]   (env STEPS: steps + warmup of the profiled run, default 4)"""
 import collections
 import csv
 import glob
@@ -30,3 +33,32 @@ for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
 json.dump({"command": f"rocprofv3 --kernel-trace --pmc <one counter set per pass> -f csv -- python3 bench.py --mode {mode} --steps 3 --warmup 1 ...",
            "kernels": out}, open(os.path.join(dst, f"{tag}_{mode}_pmc.json"), "w"), indent=1)
 print(json.dumps({s: {k: round(v["mean_per_launch"]) for k, v in cs.items()} for s, cs in out.items()}, indent=1))
+
+# ---- HBM traffic per step for bench.py's roofline.traffic
+sys.path.insert(0, root)
+import bench  # noqa: E402
+steps = int(os.environ.get("STEPS", "4"))
+covered = {"1mm": ["search_lines_kernel<false, false, false, 0>", "search_solo_kernel<false, false, false, false, true>"],
+           "extract": ["extract_prefix_wave_kernel", "move_prefix", "extract_postfix_wave_kernel"]}[mode]
+of_step = {"1mm": covered + ["wl_", "hit_", "pack_dense_kernel", "search_init"],
+           "extract": covered}[mode]
+tot = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
+for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in tot:
+            if any(c in r["Kernel_Name"] for c in covered):
+                tot[r["Counter_Name"]][0] += float(r["Counter_Value"])
+            if any(c in r["Kernel_Name"] for c in of_step):
+                tot[r["Counter_Name"]][1] += float(r["Counter_Value"])
+p_modes = os.path.join(dst, "pmc_traffic_modes.json")
+modes = json.load(open(p_modes)) if os.path.exists(p_modes) else {}
+args = dict(a.split("=", 1) for a in os.environ.get("RUN_ARGS", "").split() if "=" in a)
+modes[mode] = {"source_sha": bench.mode_source_sha(), "run_bytes_per_shard": int(float(args.get("runs", 2e10))),
+               "shards_per_gpu": int(args.get("shards", 8)), "units_per_batch": int(float(args.get("units", 4e5 if mode == "1mm" else 2e6))),
+               "steps_profiled": steps,
+               "hbm_bytes_per_step_covered_kernels": (2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / steps,
+               "hbm_bytes_per_step_all_kernels": (2 * tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][1]) * 1024 / steps,
+               "covered_kernels": covered, "from": f"profiles/{tag}_{mode}_pmc.json",
+               "rule": "(2*FETCH_SIZE + WRITE_SIZE) KB * 1024 summed over the kernels' dispatches / steps; gfx950 FETCH_SIZE counts 128-B read requests at 64 B"}
+json.dump(modes, open(p_modes, "w"), indent=1)
+print("pmc_traffic_modes:", json.dumps(modes[mode], indent=1))
