@@ -137,6 +137,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def total(t):
+    """Sum of a tensor's elements as a Python int, in slices: `t.sum(dtype=int64)` of a byte tensor makes an int64 copy of
+    it first -- 8 x its size, beside shards that fill the HBM."""
+    f = t.reshape(-1)
+    return sum(int(f[i:i + (1 << 27)].sum(dtype=f.dtype if f.dtype.is_floating_point else __import__("torch").int64).item())
+               for i in range(0, max(f.numel(), 1), 1 << 27)) if f.numel() else 0
+
+
 def mode_source_sha():
     """Identifies the kernels a PMC traffic figure of --mode 1mm / extract was measured on: every source under csrc/."""
     h = hashlib.sha256()
@@ -557,7 +565,7 @@ def run_exact(a, c, mix, steps, warmup, headline):
     if world > 1:
         last = step_no[0] - 1
         sent = gat.wire(last) if wire_packed else gat.pair(last)
-        mine_sum = sent.sum(dtype=torch.int64).reshape(1).to(cdev)
+        mine_sum = torch.tensor([total(sent)], dtype=torch.int64, device=cdev)
         exact = torch.ones(1, dtype=torch.int64, device=cdev)
         if wire_packed:  # the 10-byte form carries this rank's pairs exactly
             src = d_res[last % 2] if d_res is not None else gat.pair(last)
@@ -570,7 +578,7 @@ def run_exact(a, c, mix, steps, warmup, headline):
         dist.all_reduce(exact, op=dist.ReduceOp.MIN)
         if rank == 0:
             got = gat.result(last)
-            gather_verified = bool(exact.item()) and all(int(got[r].sum(dtype=torch.int64).item()) == int(sums[r].item()) for r in range(world))
+            gather_verified = bool(exact.item()) and all(total(got[r]) == int(sums[r].item()) for r in range(world))
 
     searches = world * S * Q * steps
     value = searches / dt
@@ -921,13 +929,13 @@ def run_rows(a, c):
         verified = None
         if world > 1:  # rank 0: the lists side by side in global shard order; every rank's checksum must be in it
             sent_h = gat_h.acquire(last)
-            mine = torch.stack([sent_h.sum(dtype=torch.int64), tot_local.to(cdev).sum()]).to(cdev)
+            mine = torch.tensor([total(sent_h), int(tot_local.sum().item())], dtype=torch.int64, device=cdev)
             sums = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(sums, mine)
             if rank == 0:
                 blocks, totals = gat_h.result(last), gat_t.result(last)
                 rec, first = sharded.concat_hit_lists(blocks, [t.cpu() for t in totals])
-                verified = (all(int(blocks[r].sum(dtype=torch.int64).item()) == int(sums[r][0].item()) for r in range(world))
+                verified = (all(total(blocks[r]) == int(sums[r][0].item()) for r in range(world))
                             and int(first[-1]) == sum(int(x[1].item()) for x in sums) and rec.shape[0] == int(first[-1]))
         overflowed = bool((tot_local > cap).any().item())  # (a list longer than its buffer keeps its count and drops records)
         cpu_base = None
@@ -1112,15 +1120,15 @@ def run_rows(a, c):
             masked = torch.where(torch.arange(stride, device=dev)[None, None, :] < lnc[..., None], full, torch.zeros_like(full))
             exact = torch.tensor([int(torch.equal(back, masked))], dtype=torch.int64, device=cdev)
             del back, masked
-            mine = torch.stack([sent.sum(dtype=torch.int64), sent_l.sum(dtype=torch.int64)]).to(cdev)
+            mine = torch.tensor([total(sent), total(sent_l)], dtype=torch.int64, device=cdev)
             sums = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(sums, mine)
             dist.all_reduce(exact, op=dist.ReduceOp.MIN)
             if rank == 0:
                 reads_all, lens_all = sharded.concat_reads(gat_o.result(last), gat_l.result(last))
                 verified = (bool(exact.item()) and reads_all.shape[0] == world * S
-                            and int(reads_all.sum(dtype=torch.int64).item()) == sum(int(x[0].item()) for x in sums)
-                            and int(lens_all.sum(dtype=torch.int64).item()) == sum(int(x[1].item()) for x in sums))
+                            and total(reads_all) == sum(int(x[0].item()) for x in sums)
+                            and total(lens_all) == sum(int(x[1].item()) for x in sums))
         out = {
             "metric": "reads located and extracted per second on popBWT (BASELINE configs[4])",
             "value": world * S * NR / (dt / a.steps), "unit": "reads/s",
@@ -1423,7 +1431,8 @@ def reference_out_of_cache(a, threads, dev):
         assert L.rsbwt_synth_runs_dev(ptr(d_runs), R2, seed, dev.index or 0, None) == 0
         torch.cuda.synchronize()
         tail = (d_runs[-400000:] & 31).cpu().numpy().astype(np.int64)
-        n_all = int((d_runs & 31).sum(dtype=torch.int64).item())
+        # (in slices: the shards and their tables leave ~12 GB of HBM, and a whole-stream int64 temporary would be 15)
+        n_all = sum(total(d_runs[i:i + (1 << 27)] & 31) for i in range(0, R2, 1 << 27))
         # drop trailing runs until D2 holds, then see that D1 does
         drop = 0
         while drop < 1000:

@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
     std::vector<const char *> cpaths;
     for (const std::string &p : paths) cpaths.push_back(p.c_str());
     rsbwt_set_t *set = nullptr;
-    if (rsbwt_set_open(cpaths.data(), cpaths.size(), devs.data(), 0, &set) != RSBWT_OK) {
+    if (rsbwt_set_open(cpaths.data(), cpaths.size(), devs.data(), RSBWT_OPEN_KTAB_GROUPED, &set) != RSBWT_OK) {
         fprintf(stderr, "%s\n", rsbwt_last_error());
         return EXIT_FAILURE;
     }

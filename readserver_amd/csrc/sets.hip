@@ -266,6 +266,7 @@ int rsbwt_set_from_handles(rsbwt_t *const *handles, size_t num_shards, rsbwt_set
 }
 
 
+static int rsbwt_set_attach_ktabs_body(rsbwt_set_t *s, uint32_t depth, uint32_t format);
 static int rsbwt_set_open_body(const char *const *bwt_paths, size_t num_shards, const int *device_map,
                    uint32_t flags, rsbwt_set_t **out) {
     if (!out || (!bwt_paths && num_shards)) return fail(RSBWT_EINVAL, "null argument");
@@ -286,7 +287,9 @@ static int rsbwt_set_open_body(const char *const *bwt_paths, size_t num_shards, 
         s->shards.push_back(h);
     }
     int rc = make_groups(s);
-    if (rc == RSBWT_OK && T_req == 0u) rc = rsbwt_set_attach_ktabs(s, 0);
+    // (RSBWT_OPEN_KTAB_GROUPED: the grouped format where it is a level deeper and nearly every T-mer occurs, else plain)
+    if (rc == RSBWT_OK && T_req == 0u)
+        rc = rsbwt_set_attach_ktabs_body(s, 0, (flags & RSBWT_OPEN_KTAB_GROUPED) ? RSBWT_KTAB_FORMAT_AUTO : RSBWT_KTAB_FORMAT_PLAIN);
     if (rc) { rsbwt_set_close(s); return rc; }
     *out = s;
     return RSBWT_OK;

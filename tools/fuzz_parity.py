@@ -58,11 +58,14 @@ while time.time() < t_end:
     oix = orc.from_runs(runs)
     n = oix.bwlen()
     reads_layout = bool(rng.random() < 0.4)  # RSBWT_OPEN_READS: a psi hint slot in every window line, sparse select samples
-    cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n), "for_reads": reads_layout}
+    grouped = bool(rng.random() < 0.5)       # RSBWT_OPEN_KTAB_GROUPED: the k-mer table's 12-byte records of four siblings (any depth: groups too
+                                             # wide for their record and T-mers that do not occur are left to the search)
+    cfg = {"runs": R, "shape": shape, "span": span, "T": T, "k": k, "n": int(n), "for_reads": reads_layout, "ktab_grouped": grouped}
     try:
-        with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span, for_reads=reads_layout) as g:
+        with rsb.GpuBWT(runs=runs, ktab_depth=T, window_span=span, for_reads=reads_layout, ktab_grouped=grouped) as g:
             Q = 300000 if rng.random() < 0.1 else 20000  # the larger batch takes the one-lane-per-search kernel on a deep table
             cfg["Q"] = Q
+            cfg["ktab"] = (g.ktab_depth(),) + g.ktab_info()  # (depth, format, bytes, T-mers left to the search)
             km = acgt[rng.integers(0, 4, (Q, k))].copy()
             # k-mers that occur: spelled from the BWT's own rows by the oracle's extraction
             rows = rng.integers(0, n, 400, dtype=np.uint64)
@@ -90,7 +93,8 @@ while time.time() < t_end:
                 oix2 = orc.from_runs(runs2)
                 # (a second shard with the first one's table depth: the set then searches both in one traced and one
                 # resumed launch, csrc/sets.hip set_hits_1mm_fused)
-                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))], for_reads=bool(rng.random() < 0.5)) as g2:
+                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))], for_reads=bool(rng.random() < 0.5),
+                                ktab_grouped=bool(rng.random() < 0.5)) as g2:
                     ss = rsb.ShardSet([g, g2])
                     slo, sup = ss.find_intervals(km[:5000])
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
