@@ -664,3 +664,54 @@ def test_gpu_set_hits_1mm_worklists_keep_the_references_unsigned_carry(rsb, grou
     ss.close()
     for g in shards:
         g.close()
+
+
+def test_gpu_set_table_format_auto_and_set_open_flag(rsb, oracle, tmp_path):
+    """rsbwt_set_attach_ktabs_format(AUTO) takes the grouped records where the smallest shard's T-mers still have 64 rows
+    each and four siblings fit a record (csrc/capi_internal.h, ktab_grouped_sensible), the plain entries elsewhere;
+    rsbwt_set_open with RSBWT_OPEN_KTAB_GROUPED sizes the set's tables itself (plain unless grouped is deeper); intervals
+    equal the oracle's whatever came out."""
+    L = rsb.lib()
+    rng = np.random.default_rng(8)
+    paths, oixs = [], []
+    for i, R in enumerate((3000000, 2500000)):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 5100 + i) == 0
+        p = str(tmp_path / f"f{i}.bwt")
+        n = int((runs & 31).astype(np.int64).sum())
+        with open(p, "wb") as f:  # the 30-byte SGA header + the run bytes (rlebwt_reader.cpp:27-48)
+            f.write((0xCACA).to_bytes(2, "little") + (0).to_bytes(8, "little") + n.to_bytes(8, "little") + R.to_bytes(8, "little") + (0).to_bytes(4, "little"))
+            f.write(runs.tobytes())
+        paths.append(p)
+        oixs.append(oracle.from_runs(runs))
+    n_min = min(o.bwlen() for o in oixs)
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (20000, 31))].copy()
+    want = [o.find_intervals(km, nthreads=8) for o in oixs]
+    for T in (8, 11):
+        shards = [rsb.GpuBWT(p, ktab_depth=None) for p in paths]
+        ss = rsb.ShardSet(shards)
+        assert L.rsbwt_set_attach_ktabs_format(ss._s, T, 2) == 0
+        sensible = 64 <= (n_min >> (2 * T)) and (n_min >> (2 * (T - 1))) <= 2048
+        assert (T == 8) == sensible  # (1.4e7 symbols: 220 rows per 8-mer, 3 per 11-mer)
+        for g in shards:
+            assert g.ktab_depth() == T and g.ktab_info()[0] == (1 if sensible else 0)
+        lo, up = ss.find_intervals(km)
+        for s in range(2):
+            assert np.array_equal(lo[s], want[s][0]) and np.array_equal(up[s], want[s][1]), (T, s)
+        ss.close()
+        for g in shards:
+            g.close()
+    # the set opened from files, tables sized by the library
+    arr = (C.c_char_p * 2)(*[p.encode() for p in paths])
+    h = C.c_void_p()
+    assert L.rsbwt_set_open(arr, 2, None, 2, C.byref(h)) == 0  # RSBWT_OPEN_KTAB_GROUPED
+    try:
+        lo = np.empty((2, 20000), np.uint64)
+        up = np.empty((2, 20000), np.uint64)
+        assert L.rsbwt_set_find_intervals(h, km.ctypes.data, 20000, 31, 31, lo.ctypes.data, up.ctypes.data) == 0
+        for s in range(2):
+            assert np.array_equal(lo[s], want[s][0]) and np.array_equal(up[s], want[s][1]), s
+        d0 = L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, 0))
+        assert d0 >= 2 and d0 == L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, 1))
+    finally:
+        L.rsbwt_set_close(h)
