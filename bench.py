@@ -427,7 +427,10 @@ def run_exact(a, c, mix, steps, warmup, headline):
     # bytes): an xGMI link moves ~77 GB/s per direction, so 1.28 GB of 16-byte pairs per peer and batch would
     # take longer than the 12 ms search that produced them
     wire_packed = world > 1 and not a.separate_arrays and not a.gather_unpacked
-    gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev)
+    # (from 4 ranks on rank 0 keeps ONE batch's gathered blocks: at N = 8 that is 6.4 GB of HBM the k-mer tables get --
+    # the grouped 15-mer tables then fit beside the shards on rank 0 too, and the job's one depth is the N = 1 depth)
+    gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev,
+                                   out_depth=(2 if world <= 2 else 1))
     d_res = [torch.empty_like(gat.pair(i), device=dev) for i in range(2)] if cdev != dev else None
     hold = torch.empty(int(a.hold_gb * (1 << 30)), dtype=torch.uint8, device=dev) if a.hold_gb > 0 else None
     # --piped-start: a batch's packing and start records (they depend on the k-mers and the k-mer tables only) are

@@ -90,7 +90,7 @@ def test_world2_gather_and_reduce(rsb, tmp_path):
     assert q.get() == "ok"
 
 
-def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False):
+def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False, out_depth=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -98,7 +98,7 @@ def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False):
     try:
         from readserver_amd import sharded
         S, Q, steps = 2, 1000, 7
-        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2, interleaved=interleaved, packed=packed)
+        g = sharded.IntervalGatherer(S, Q, torch.device("cpu"), depth=2, interleaved=interleaved, packed=packed, out_depth=out_depth)
         lo_of = (lambda t: t[..., 0]) if interleaved else (lambda t: t[0])  # {lower, upper} pairs / two arrays
         up_of = (lambda t: t[..., 1]) if interleaved else (lambda t: t[1])
         seen = {}
@@ -113,8 +113,13 @@ def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False):
                 buf[1, 1] = torch.tensor([0, -1])
                 buf[1, 2] = torch.tensor([(1 << 40) - 1, (1 << 40) - 2])
                 buf[1, 3] = torch.tensor([1, (1 << 40) - 1])
+            if out_depth == 1 and rank == 0 and i >= 1:
+                # one batch's blocks on rank 0: batch i's gather lands where batch i - 1's did, so batch i - 1 is read
+                # before batch i is submitted (submit would wait for it too)
+                g._work[(i - 1) % 2].wait()
+                seen[i - 1] = [t.clone() for t in g.result(i - 1)]
             g.submit(i)
-            if rank == 0 and i >= 1:
+            if out_depth != 1 and rank == 0 and i >= 1:
                 # batch i - 1 is complete once its handle has been waited for; acquire(i + 1) does
                 # that for its buffer, so read it only after an explicit wait here
                 g._work[(i - 1) % 2].wait()
@@ -148,16 +153,16 @@ def _pipeline_worker(rank, world, port, q, interleaved=False, packed=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("interleaved", [False, True, "packed"])
-def test_world2_pipelined_interval_gather(interleaved):
+@pytest.mark.parametrize("interleaved,out_depth", [(False, None), (True, None), ("packed", None), ("packed", 1), (True, 1)])
+def test_world2_pipelined_interval_gather(interleaved, out_depth):
     """bench.py's N > 1 data path: searches write into one of two resident buffers while the other one's
     gather to rank 0 is in flight ({lower, upper} pairs as rsbwt_set_find_interval_pairs_dev writes them,
-    or two arrays)."""
+    or two arrays).  out_depth = 1: rank 0 keeps one batch's gathered blocks (bench.py from 4 ranks on)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + 3 + [False, True, "packed"].index(interleaved)) % 2000
+    port = 29500 + (os.getpid() * 7 + 3 + [False, True, "packed"].index(interleaved) + 5 * (out_depth or 0)) % 2000
     packed = interleaved == "packed"
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, bool(interleaved), packed)) for r in range(2)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, bool(interleaved), packed, out_depth)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -86,6 +86,35 @@ def test_gpu_a_damaged_kmer_table_entry_is_not_believed(rsb):
         assert np.array_equal(lo1[:, 0], elo[:300]) and np.array_equal(up1[:, 0], eup[:300])
 
 
+def test_gpu_a_damaged_grouped_table_record_is_not_believed(rsb):
+    """The same for the grouped table's 12-byte records (rsbwt_attach_ktab_format): a sibling whose rows would run past
+    the BWT's last row is not believed, one the record gives no rows is left to the search anyway -- every search then
+    starts from initInterval and ends on the right rows; the poke stays inside the table's 3 * 4^T bytes."""
+    rng = np.random.default_rng(16)
+    runs = _random_runs(rng, 400000)
+    oix = ob.load().from_runs(runs)
+    n = oix.bwlen()
+    km = _kmers(rng, 20000, 31)
+    elo, eup = oix.find_intervals(km)
+    with rsb.GpuBWT(runs=runs, ktab_depth=8, ktab_grouped=True) as g:
+        L = rsb.lib()
+        assert g.ktab_info()[:2] == (1, 3 * 4 ** 8)
+
+        def record(base, c):  # 96 bits little-endian: base:40, then four 14-bit running widths (csrc/line_format.h)
+            v = base | (c[0] << 40) | (c[1] << 54) | (c[2] << 68) | (c[3] << 82)
+            return [v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF, (v >> 64) & 0xFFFFFFFF]
+        rec = np.empty((4 ** 7, 3), np.uint32)
+        rec[0::3] = record(n - 3, (9, 9, 20, 20))            # siblings 0 and 2 run past the last row, 1 and 3 hold nothing
+        rec[1::3] = record((1 << 40) - 1, (1, 2, 3, 4))      # far outside
+        rec[2::3] = record(n + 1, (0, 0, 0, 5))              # three hold nothing, the fourth lies past n
+        assert L.rsbwt_debug_poke(g.handle, 1, 0, rec.ctypes.data, rec.nbytes) == 0
+        assert L.rsbwt_debug_poke(g.handle, 1, rec.nbytes - 8, rec.ctypes.data, 16) != 0  # outside the table
+        lo, up = rsb.find_intervals(g, km)
+        assert np.array_equal(lo, elo) and np.array_equal(up, eup)
+        lo1, up1 = rsb.find_intervals_1mm(g, km[:300])
+        assert np.array_equal(lo1[:, 0], elo[:300]) and np.array_equal(up1[:, 0], eup[:300])
+
+
 @pytest.mark.parametrize("span", [0, 2944])
 def test_gpu_damaged_lines_are_survived(rsb, span):
     """Window lines overwritten with noise -- wild counts (lower / upper far past n), far links to
