@@ -174,7 +174,8 @@ RSB_HD uint64_t ktab_group_entry(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t
     const uint32_t c3 = (uint32_t)(hi >> 50) & KTAB_CUM_ESCAPE;
     const uint32_t chi = (uint32_t)(hi >> (8u + KTAB_CUM_BITS * slot)) & KTAB_CUM_ESCAPE;
     const uint32_t clo = slot ? (uint32_t)(hi >> (KTAB_CUM_BITS * slot - 6u)) & KTAB_CUM_ESCAPE : 0u;
-    if (c3 == KTAB_CUM_ESCAPE || chi <= clo) return (uint64_t)KTAB_WIDE << COUNT_BITS;
+    // (base + chi past 2^40: never written by the builder -- a damaged record must not wrap into a row number that is believed)
+    if (c3 == KTAB_CUM_ESCAPE || chi <= clo || base + chi > COUNT_MASK + 1ull) return (uint64_t)KTAB_WIDE << COUNT_BITS;
     return (base + clo) | ((uint64_t)(chi - clo) << COUNT_BITS);
 }
 
