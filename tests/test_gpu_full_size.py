@@ -58,7 +58,9 @@ def test_gpu_eight_20gb_shards_exact_1mm_extract_at_full_size(rsb, oracle):
     th = threading.Thread(target=lambda: box.setdefault("oix", oracle.from_runs(host_runs)))  # (~25 s, beside the GPU's work)
     th.start()
     sset = rsb.ShardSet(shards)
-    assert L.rsbwt_set_attach_ktabs(sset._s, 14) == 0
+    # (the bench's tables: grouped 15-mer tables, 3.2 GB per shard in the HBM plain 14-mer tables would take 2.1 of)
+    assert L.rsbwt_set_attach_ktabs_format(sset._s, 15, 1) == 0
+    assert all(g.ktab_depth() == 15 and g.ktab_info()[:2] == (1, 3 * 4 ** 15) and g.ktab_info()[2] < 1e-3 * 4 ** 15 for g in shards)
     n = int(shards[0].getBWLen())
     assert n > (1 << 36) and all(int(g.getBWLen()) == n and g.window_span() == shards[0].window_span() for g in shards)
     Q = 1_000_000
