@@ -771,6 +771,26 @@ int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, 
     return RSBWT_OK;
 }
 
+int search_launch_walk(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
+                       const void *d_valid, size_t nkmers, uint32_t tn, void *d_worklists, void *d_counts, size_t wl_cap, uint32_t k,
+                       void *d_sparse, void *d_hit_bits, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(m.mu);
+    unsigned long long *work = nullptr;
+    if (m.counting) {
+        work = m.d_work;
+        HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), stream));
+    }
+    const int slot = (int)(m.launches % search_meter::RING);
+    hipError_t e = launch_search_walk(m.scratch, d_views, nshards, d_packed, d_valid, nkmers, tn, d_worklists, d_counts, wl_cap, k, d_sparse,
+                                      d_hit_bits, work, num_cus, stream, m.ev_start[slot], m.ev_stop[slot]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_hip(e, "1-mismatch walk kernel launch");
+    }
+    m.launches++;
+    return RSBWT_OK;
+}
+
 int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                            const void *d_valid, size_t nkmers, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
                            uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream) {

@@ -70,6 +70,11 @@ inline bool view_is_narrow(const shard_view &v, uint32_t k) {
 int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                            const void *d_valid, size_t nkmers, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
                            uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream);
+// the walk that makes those worklists (kernels.h, launch_search_walk), metered like search_launch: a counting launch
+// ZEROES the counters first (it is the first launch of the sequence)
+int search_launch_walk(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
+                       const void *d_valid, size_t nkmers, uint32_t tn, void *d_worklists, void *d_counts, size_t wl_cap, uint32_t k,
+                       void *d_sparse, void *d_hit_bits, hipStream_t stream);
 int meter_history_ms(search_meter &m, float *ms, size_t cap, size_t *count);
 // 1-mismatch hit list of one shard from variants expanded once for the whole batch (sets.hip: every shard of a set
 // searches the same variants)

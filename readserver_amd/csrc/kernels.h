@@ -111,6 +111,13 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
                                   const void *d_valid, size_t m, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
                                   uint32_t k, void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus,
                                   hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// launch_search_walk replaces the traced launch and launch_mm1_worklists' branch kernel by ONE walk of the k-mers
+// (search_solo.h, WALK): the k-mers' own intervals to d_sparse / d_hit_bits at their canonical indices, the variants
+// that survive the step of their position appended to d_worklists (d_counts zeroed by the caller), no trace.
+hipError_t launch_search_walk(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                              const void *d_valid, size_t m, uint32_t tn, void *d_worklists, void *d_counts, size_t wl_cap, uint32_t k,
+                              void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus, hipStream_t stream,
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 constexpr int WORK_WORDS = 16;  // counters of a counting launch (search_lines.hip, WORK_*)
 
 // k-mer table: fills d_entries[c * stride], c < 4^T, by searching every T-mer (fmt = KTAB_GROUPED: the 12-byte

@@ -814,6 +814,50 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
     return e;
 }
 
+// The k-mers' own searches and the step of the three substitutions of every position left of the tables' reach, in one
+// walk (search_solo.h, WALK): m k-mers per shard, worklists / counts / sparse results as mm1_worklist.hip lays them out.
+hipError_t launch_search_walk(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
+                              const void *d_valid, size_t m, uint32_t tn, void *d_worklists, void *d_counts, size_t wl_cap, uint32_t k,
+                              void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus, hipStream_t stream,
+                              hipEvent_t ev0, hipEvent_t ev1) {
+    if (nshards == 0 || m == 0) return hipSuccess;
+    if (k > 32u || tn == 0 || tn >= k) return hipErrorInvalidValue;
+    static const int wgs_per_cu = [] {
+        const char *e = getenv("RSBWT_WALK1MM_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 && v <= RSB_WALK1MM_WGS_PER_CU ? v : RSB_WALK1MM_WGS_PER_CU;
+    }();
+    size_t g = (m * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
+    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    if (g > cap) g = cap;
+    scratch_cache::lease mem;
+    hipError_t e = scratch.take(nshards * POOL_STRIDE * sizeof(unsigned long long), stream, &mem);
+    if (e != hipSuccess) return e;
+    unsigned long long *ctr = (unsigned long long *)mem.p;
+    e = hipMemsetAsync(ctr, 0, nshards * POOL_STRIDE * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) {
+        scratch.give(mem, stream);
+        return e;
+    }
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    uint32_t qchunk = 1024;
+    while (qchunk > 64u && (size_t)qchunk * g * WG_WAVES * 4u > m * nshards) qchunk >>= 1;
+    if (d_work)
+        hipLaunchKernelGGL((search_solo_kernel<true, false, false, true, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream,
+                           d_shards, nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, m, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap, (size_t)0);
+    else
+        hipLaunchKernelGGL((search_solo_kernel<false, false, false, true, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream,
+                           d_shards, nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, m, k, 1u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (const unsigned long long *)d_counts, wl_cap, (size_t)0);
+    e = hipGetLastError();
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    scratch.give(mem, stream);
+    return e;
+}
+
 // Entries per k-mer of a traced search = the positions left of the k-mer table's reach (0: the
 // 1-mismatch search has nothing to share: no table, or k within it)
 uint32_t trace_entries(const shard_view &ix, uint32_t k) {

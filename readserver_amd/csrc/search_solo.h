@@ -27,6 +27,15 @@
 // 32 bytes each: {lower | next symbol << 40, upper, result index, packed word}, of a length only the device knows
 // (wl_counts[s], written by the kernel that appended them): one 32-byte read per take-up.  Results go to the
 // variant's canonical index (sparse results + hit map, as `pairs == 2`); a record flagged WL_DEAD is an empty slot.
+//
+// WALK (with FUSED; the 1-mismatch search of a set, sets.hip): the k-mers' own searches AND the step of the three
+// substitutions at every position left of the k-mer table's reach, in one walk -- what a traced launch of the pair
+// kernel and wl_branch_kernel (mm1_worklist.hip) did between them with a trace of 16 bytes per (k-mer, position, shard)
+// written, read back, and every line fetched twice.  A lane walks its k-mer; where a lookup finds its position among
+// the staged line's own pieces the three other bases are ranked off the same line (staged_occ_alts, wave_lines.h), and
+// when the step completes the variants that survive it are appended to the shard's worklist (their interval after the
+// step), the final ones stored as hits; a position that took a continuation line passes its three variants on
+// UNSTEPPED, as the branch kernel did.  The k-mer's own interval is variant 0's hit.
 #ifndef RSBWT_SEARCH_SOLO_H
 #define RSBWT_SEARCH_SOLO_H
 
@@ -34,8 +43,11 @@ namespace rsb {
 
 constexpr uint64_t WL_DEAD = 1ull << 63;  // worklist record: an empty slot (bit 63 of its first word)
 
-template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK, bool FUSED = false, bool WL = false>
-__global__ void __launch_bounds__(64 * WG_WAVES, RSB_MIN_WGS_PER_CU)
+#ifndef RSB_WALK1MM_WGS_PER_CU  // tuning knob (tools/build_variant.sh): the walk keeps three bases' counts across passes
+#define RSB_WALK1MM_WGS_PER_CU 3
+#endif
+template <bool COUNT_WORK, bool COUNTS_ONLY, bool LONGK, bool FUSED = false, bool WL = false, bool WALK = false>
+__global__ void __launch_bounds__(64 * WG_WAVES, WALK ? RSB_WALK1MM_WGS_PER_CU : RSB_MIN_WGS_PER_CU)
 search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
                    const ulonglong2 *__restrict__ init, const uint8_t *__restrict__ valid,
                    unsigned long long *__restrict__ next_query,
@@ -54,6 +66,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
 #define SOLO_MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
 
     unsigned long long w_steps = 0, w_occ = 0, w_lines = 0, w_hops = 0, w_ktab = 0, passes = 0;
+    unsigned long long w_surv = 0, w_unstepped = 0;  // WALK (wave-uniform: popcounts of ballots)
 
     uint32_t sid = blockIdx.x % nshards;
     for (uint32_t visited = 0; visited < nshards; ++visited, sid = (sid + 1u == nshards) ? 0u : sid + 1u) {
@@ -67,15 +80,20 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint32_t w_table = j_table > 0 ? (uint32_t)j_table >> 5 : 0u;
         // WL: `init` is the worklists, [nshards][wl_cap] records of two ulonglong2; wl_counts their lengths
         const ulonglong2 *init_s = WL ? init + (size_t)sid * wl_cap * 2u : init + (size_t)sid * Q;
-        const size_t Qs = WL ? wl_implicit + (size_t)(wl_counts[(size_t)sid * WL_COUNT_STRIDE] < wl_cap ? wl_counts[(size_t)sid * WL_COUNT_STRIDE] : wl_cap) : Q;  // searches of this shard
+        const size_t Qs = WALK ? Q : WL ? wl_implicit + (size_t)(wl_counts[(size_t)sid * WL_COUNT_STRIDE] < wl_cap ? wl_counts[(size_t)sid * WL_COUNT_STRIDE] : wl_cap) : Q;  // searches of this shard
         const uint32_t wl_tn = trace_n, wl_per = WL ? 3u * (k - trace_n) : 1u;  // (WL: trace_n carries tn; 3T implicit items per k-mer)
-        uint64_t *out_lo = out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
+        // WALK: Q k-mers, results at their canonical indices in [nshards][Q * (3k+1)] sparse pairs / hit maps; `init` is
+        // the worklists the surviving variants are appended to, wl_counts their lengths (device-side atomics)
+        const size_t walk_V = 3u * (size_t)k + 1u, walk_mv = Q * walk_V;
+        ulonglong2 *walk_wl = WALK ? const_cast<ulonglong2 *>(init) + (size_t)sid * wl_cap * 2u : nullptr;
+        unsigned long long *walk_count = WALK ? const_cast<unsigned long long *>(wl_counts) + (size_t)sid * WL_COUNT_STRIDE : nullptr;
+        uint64_t *out_lo = WALK ? out_lower + (size_t)sid * walk_mv * 2u : out_lower + (size_t)sid * Q * (pairs ? 2u : 1u);
         uint64_t *out_up = (COUNTS_ONLY || pairs) ? nullptr : out_upper + (size_t)sid * Q;
         unsigned long long *pool = next_query + (size_t)sid * POOL_STRIDE;
         if (visited != 0u && __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)Qs) continue;  // (search_lines_kernel: drained already)
         // per shard, as in search_lines_kernel: traces [s][Q][trace_n], hit maps [s][hit_map_words(Q)]
         ulonglong2 *trace_s = (trace && !WL) ? trace + (size_t)sid * Q * trace_n : nullptr;
-        unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(Q) : nullptr;
+        unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(WALK ? walk_mv : Q) : nullptr;
         // C[1..4] in lanes 0..3, picked with ds_bpermute (scalar loads: see search_lines_kernel)
         uint32_t ctab_lo, ctab_hi;
         {
@@ -111,6 +129,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         uint32_t sub = 0;
         uint64_t occL = 0, cacc = 0;
         uint32_t cont = 0, cblk = 0, cdw = 0, co = 0, tries = 0, w = 0;
+        // WALK: Occ of the three other bases at lower - 1 (kept until the step's upper lookup is in too) and whether
+        // both lookups of the step found their position among a staged line's own pieces
+        uint64_t altL0 = 0, altL1 = 0, altL2 = 0, altU0 = 0, altU1 = 0, altU2 = 0;
+        bool alt_ok = true;
 
         for (;;) {
             // ---- a lane whose query ended in the last pass takes up the one it had prefetched
@@ -289,6 +311,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             bool no_fetch = false;  // Occ(b, -1) = 0 on the upper side too: the step completes without a line
             if (fresh) {
                 if (sub == 0u) {
+                    if (WALK) {  // a step begins: nothing known of the other bases yet (Occ(., -1) = 0 is what lower = 0 leaves)
+                        alt_ok = true;
+                        altL0 = altL1 = altL2 = altU0 = altU1 = altU2 = 0;
+                    }
                     // traced search (1-mismatch): the interval this query has when about to take symbol j
                     if (trace && (uint32_t)j < trace_n) trace_s[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
                     if (lo == 0ull) {  // Occ(b, -1) = 0 (rlebwt.cpp:269)
@@ -412,6 +438,17 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             uint64_t occU = 0;
             bool second = false;
             uint32_t oh = 0;
+            // WALK: this pass's lookup found its position among the staged line's own pieces (the three other bases can be
+            // ranked off the same line: for lower - 1 or for upper), or came out of a continuation line (they cannot)
+            bool ev1 = false, ev1_is_L = false;
+            if (WALK && do_scan && (uint32_t)j < trace_n) {
+                if (own_line) {
+                    ev1 = true;
+                    ev1_is_L = sub == 0u;
+                } else {
+                    alt_ok = false;
+                }
+            }
             if (do_scan) {
                 cont = 0;
                 tries = 0;
@@ -458,6 +495,74 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 occU = 0;
                 step_done = true;
             }
+            if (WALK) {
+                // ---- the three other bases at this pass's position(s): one copy of the rank code, run for the lookup
+                // of the pass and again for upper where it was ranked off the same line (wave-uniform skips)
+                const staged_line Lrow = {mine0, swz};
+                const line_head hh = {s1, s2, s3, span, 0u};
+#pragma unroll 1
+                for (uint32_t ev = 0; ev < 2u; ++ev) {
+                    const bool want = ev == 0u ? ev1 : (second && (uint32_t)j < trace_n);
+                    if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
+                    uint64_t t3[3];
+                    staged_occ_alts(Lrow, hh, want ? (ev == 0u ? oe_here : oh) : 1u, b - 1u, t3);
+                    if (want) {
+                        if (ev == 0u && ev1_is_L) { altL0 = t3[0]; altL1 = t3[1]; altL2 = t3[2]; }
+                        else { altU0 = t3[0]; altU1 = t3[1]; altU2 = t3[2]; }
+                    }
+                }
+                // ---- a step of a position left of the tables' reach completes: updateInterval (query.cpp:11-15) with each
+                // of the three substituted symbols; the variants that survive become searches (mm1_worklist.hip's records)
+                const bool emit = step_done && (uint32_t)j < trace_n;
+                if (__builtin_amdgcn_ballot_w64(emit) != 0ull) {
+                    const uint32_t orig = b - 1u;
+                    uint64_t nlo[3], nhi[3], masks[3];
+                    bool enq[3];
+#pragma unroll
+                    for (uint32_t d = 0; d < 3u; ++d) {
+                        const uint32_t alt = d < orig ? d : d + 1u;  // the d-th base of ACGT without the original one
+                        const uint64_t cb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(alt << 2), (int)ctab_hi) << 32) |
+                                            (uint32_t)__builtin_amdgcn_ds_bpermute((int)(alt << 2), (int)ctab_lo);
+                        nlo[d] = cb + (d == 0u ? altL0 : d == 1u ? altL1 : altL2);
+                        nhi[d] = cb + (d == 0u ? altU0 : d == 1u ? altU1 : altU2) - 1ull;
+                        const bool stepped_live = emit && alt_ok && nlo[d] <= nhi[d];
+                        const bool final_hit = stepped_live && j == 0;
+                        enq[d] = (stepped_live && j != 0) || (emit && !alt_ok);
+                        if (final_hit) {
+                            const size_t canon = q * walk_V + 1u + 3u * (uint32_t)j + d;
+                            reinterpret_cast<ulonglong2 *>(out_lo)[canon] = make_ulonglong2(nlo[d], nhi[d]);
+                            atomicOr(hit_map + (canon >> 6), 1ull << (canon & 63u));
+                        }
+                        masks[d] = __builtin_amdgcn_ballot_w64(enq[d]);
+                        if (COUNT_WORK) {
+                            w_surv += __builtin_popcountll(__builtin_amdgcn_ballot_w64((enq[d] && alt_ok) || final_hit));
+                            w_unstepped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(enq[d] && !alt_ok));
+                        }
+                    }
+                    if (COUNT_WORK && emit) w_steps += 3;
+                    // ONE append per wave and pass for the three rounds together
+                    const uint32_t n0 = (uint32_t)__builtin_popcountll(masks[0]), n1 = (uint32_t)__builtin_popcountll(masks[1]);
+                    const uint32_t total = n0 + n1 + (uint32_t)__builtin_popcountll(masks[2]);
+                    if (total != 0u) {
+                        unsigned long long wbase = 0;
+                        if (lane == 0u) wbase = atomicAdd(walk_count, (unsigned long long)total);
+                        wbase = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wbase >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
+                        const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (uint32_t d = 0; d < 3u; ++d) {
+                            if (!enq[d]) continue;
+                            const size_t slot = (size_t)wbase + (d >= 1u ? n0 : 0u) + (d >= 2u ? n1 : 0u) + (size_t)__builtin_popcountll(masks[d] & lt);
+                            if (slot >= wl_cap) continue;  // (room for every variant: the caller's sizing)
+                            const uint32_t alt = d < orig ? d : d + 1u;
+                            const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * (uint32_t)j));
+                            const uint64_t canon = (uint64_t)q * walk_V + 1ull + 3ull * (uint32_t)j + d;
+                            if (!alt_ok) wl_store(walk_wl, slot, lo, (uint32_t)j, hi, canon, vword);            // the step is the search kernel's
+                            else wl_store(walk_wl, slot, nlo[d], (uint32_t)j - 1u, nhi[d], canon, vword);     // already taken
+                        }
+                    }
+                }
+            }
             // ---- updateInterval (query.cpp:11-15)
             if (step_done) {
                 if (COUNT_WORK) w_steps += 1;
@@ -494,8 +599,9 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     // atomic nobody waits for; a counter handing out list positions would stall the wave for a
                     // round trip per hit and serialise on one address).  compact_hits orders them afterwards.
                     if (lo <= hi) {
-                        reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
-                        atomicOr(hit_map + (q >> 6), 1ull << (q & 63u));
+                        const size_t qi = WALK ? q * walk_V : q;  // (WALK: the k-mer itself is variant 0 of its 3k + 1)
+                        reinterpret_cast<ulonglong2 *>(out_lo)[qi] = make_ulonglong2(lo, hi);
+                        atomicOr(hit_map + (qi >> 6), 1ull << (qi & 63u));
                     }
                 } else if (pairs) {
                     reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
@@ -516,6 +622,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         if (w_lines) atomicAdd(&work[WORK_LINES], w_lines);
         if (w_ktab) atomicAdd(&work[WORK_KTAB], w_ktab);
         if (w_hops) atomicAdd(&work[WORK_HOPS], w_hops);
+        if (WALK && lane == 0u) {
+            atomicAdd(&work[13], w_surv);       // variants alive after the step of their position (mm1_worklist.hip's words)
+            atomicAdd(&work[14], w_unstepped);  // variants passed on unstepped
+        }
     }
 #undef SOLO_MINE
 }

@@ -946,14 +946,22 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
         // the k-mers traced; the step of the three substitutions of every traced position off one fetch, the variants
         // inside the tables' reach from their table entries: worklists of live searches; then ONE launch runs them
         uint8_t *d_wl = d_blocks + L.blocks, *d_counts = d_wl + L.wl;
-        search_extra traced;
-        traced.d_trace_out = d_trace;
-        traced.trace_n = L.tn;
-        traced.pairs = true;
-        if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced)) != RSBWT_OK) return rc;
-        const hipError_t ew = launch_mm1_worklists(g->d_views, S, d_packed, d_valid, m, k, L.tn, d_trace, d_own, d_wl, L.wl_cap, d_counts,
-                                                   d_sparse, d_bits, g->num_cus, st, g->counting ? g->d_work : nullptr);
-        if (ew != hipSuccess) return fail_hip(ew, "worklist kernels");
+        static const bool no_walk = getenv("RSBWT_SET_1MM_NO_WALK") != nullptr;  // A/B knob (tools/README.md): the traced launch + the branch kernel
+        if (!no_walk) {
+            // ONE walk of the k-mers: their own searches, and at every position left of the tables' reach the step of the
+            // three substitutions off the same fetch -- the survivors appended to the worklists (search_solo.h, WALK)
+            HIP_OK(hipMemsetAsync(d_counts, 0, L.counts, st));
+            if ((rc = search_launch_walk(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, L.tn, d_wl, d_counts, L.wl_cap, k, d_sparse, d_bits, st)) != RSBWT_OK) return rc;
+        } else {
+            search_extra traced;
+            traced.d_trace_out = d_trace;
+            traced.trace_n = L.tn;
+            traced.pairs = true;
+            if ((rc = search_launch(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, k, d_own, nullptr, false, st, &traced)) != RSBWT_OK) return rc;
+            const hipError_t ew = launch_mm1_worklists(g->d_views, S, d_packed, d_valid, m, k, L.tn, d_trace, d_own, d_wl, L.wl_cap, d_counts,
+                                                       d_sparse, d_bits, g->num_cus, st, g->counting ? g->d_work : nullptr);
+            if (ew != hipSuccess) return fail_hip(ew, "worklist kernels");
+        }
         rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, L.tn, d_wl, d_counts, L.wl_cap, k, d_sparse, d_bits, st);
     } else {
         rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);

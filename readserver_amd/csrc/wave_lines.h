@@ -129,5 +129,85 @@ __device__ __forceinline__ uint32_t read_chunk_dword(const staged_line &L) {
     return 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
 }
 
+// ---- the 1-mismatch worklists' shared pieces (mm1_worklist.hip, search_solo.h)
+// Worklist record (32 B): x = lower (40 bits) | next symbol j << 40 (16 bits) | WL_DEAD << 63;  y = upper;
+//                         z = canonical search index q * (3k+1) + v;  w = the variant's packed word (k <= 32).
+__device__ __forceinline__ void wl_store(ulonglong2 *wl, size_t slot, uint64_t lo, uint32_t j, uint64_t hi, uint64_t canon, uint64_t word) {
+    wl[2u * slot] = make_ulonglong2((lo & COUNT_MASK) | ((uint64_t)(j & 0xFFFFu) << COUNT_BITS), hi);
+    wl[2u * slot + 1u] = make_ulonglong2(canon, word);
+}
+
+
+// Occ of the THREE bases other than `orig` (0..3 = A..T) up to offset o (1-based, within the line's own pieces:
+// o <= span) of a staged line: out[d] for the d-th base of ACGT without the original one.  One look at the quarter's
+// 24 pieces for all of them (rank_device.h, char_rank24, taken apart): what does not depend on the symbol -- the
+// pieces' lengths and symbols, the dword and the piece holding the position, the lengths that lie BEFORE it (every
+// other length masked to zero: a piece of no length counts for no symbol) -- is computed once; a base then costs
+// four instructions per dword: its match mask with the matching bytes at 0x80, and a v_dot4 against the masked
+// lengths, the sum shifted down by 7 once.  (The first version ran the whole of char_rank24's count per base and
+// position, three times over in the kernel: 2,195 VALU instructions per pass, which bound the launch.)
+__device__ __forceinline__ void staged_occ_alts(const staged_line &L, const line_head &h, uint32_t o, uint32_t orig, uint64_t out[3]) {
+    const uint32_t cq = (o > h.s1 ? 1u : 0u) + (o > h.s2 ? 1u : 0u) + (o > h.s3 ? 1u : 0u);
+    const uint32_t start = cq == 0u ? 0u : cq == 1u ? h.s1 : cq == 2u ? h.s2 : h.s3;
+    const uint32_t rem = o - start;  // >= 1
+    // the earlier quarter of the position's half, added whole when cq is odd -- first, so that its registers are free again
+    uint32_t me[3];
+    {
+        uint32_t e[6], le[6], se[6];
+        load24(L, HDR_DWORDS + 6u * (cq & 2u), e);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            le[i] = e[i] & 0x1F1F1F1Fu;
+            se[i] = (e[i] >> 5) & 0x07070707u;
+        }
+#pragma unroll
+        for (uint32_t d = 0; d < 3u; ++d) {
+            const uint32_t bb = splat_byte((d < orig ? d : d + 1u) + 1u);
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m = __builtin_amdgcn_udot4(le[i], (0x80808080u - (se[i] ^ bb)) & 0x80808080u, m, false);
+            me[d] = (cq & 1u) ? (m >> 7) : 0u;
+        }
+    }
+    uint32_t r[6];  // the quarter holding the position
+    load24(L, HDR_DWORDS + 6u * cq, r);
+    uint32_t lr[6], sr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        lr[i] = r[i] & 0x1F1F1F1Fu;
+        sr[i] = (r[i] >> 5) & 0x07070707u;
+    }
+    uint32_t cum[6];
+    cum[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cum[i + 1] = __builtin_amdgcn_udot4(lr[i], 0x01010101u, cum[i], false);
+    uint32_t x = r[0], base = 0, di = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        const bool past = rem > cum[i];
+        x = past ? r[i] : x;
+        base = past ? cum[i] : base;
+        di = past ? (uint32_t)i : di;
+    }
+    const uint32_t rd = rem - base;
+    const uint32_t ps = (x & 0x1F1F1F1Fu) * 0x01010101u;
+    const uint32_t jj = (rd > (ps & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 8) & 0xFFu) ? 1u : 0u) + (rd > ((ps >> 16) & 0xFFu) ? 1u : 0u);
+    const uint32_t here = (x >> (8u * jj + 5u)) & 7u;
+    const uint32_t pj = jj ? __builtin_amdgcn_ubfe(ps, 8u * jj - 8u, 8u) : 0u;
+    const uint32_t reach = rd <= (ps >> 24) ? rd - pj : (ps >> 24) - pj;
+    // the lengths before the position: whole dwords before dword di, dword di's pieces before piece jj, nothing after
+    const uint32_t inner = (1u << (8u * jj)) - 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < 6u; ++i) lr[i] = i < di ? lr[i] : (i == di ? lr[i] & inner : 0u);
+#pragma unroll
+    for (uint32_t d = 0; d < 3u; ++d) {
+        const uint32_t b = (d < orig ? d : d + 1u) + 1u, bb = splat_byte(b);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc = __builtin_amdgcn_udot4(lr[i], (0x80808080u - (sr[i] ^ bb)) & 0x80808080u, acc, false);
+        out[d] = read_count(L, b) + (cq >= 2u ? read_half(L, b) : 0u) + me[d] + (acc >> 7) + (here == b ? reach : 0u);
+    }
+}
+
 }  // namespace rsb
 #endif
