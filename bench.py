@@ -999,7 +999,10 @@ def run_rows(a, c):
             "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _pmc_traffic_mode("1mm", int(a.runs), S, M) if fused else None,
                          "frac_of_step": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                         "kernel": ("search_lines_kernel (the k-mers traced, their variants resumed): all the rank's shards in one launch each"
+                         "kernel": ("search_solo_kernel<WALK> (the k-mers walked, the three substitutions of every traced position stepped off the same "
+                                    "line) + search_solo_kernel<WL> (the surviving variants and those inside the tables' reach): all the rank's shards "
+                                    "in one launch each" if fused and "RSBWT_SET_1MM_NO_WALK" not in os.environ and "RSBWT_SET_1MM_NO_WORKLIST" not in os.environ else
+                                    "search_lines_kernel (the k-mers traced, their variants resumed): all the rank's shards in one launch each"
                                     if fused else
                                     "search_lines_kernel (the k-mers traced, their variants resumed): the shards side by side, priced on the whole step"
                                     if side_by_side else

@@ -15,7 +15,8 @@ import shutil
 import sys
 
 tag, mode = sys.argv[1], sys.argv[2]
-subs = sys.argv[3:] or ["extract_prefix_wave_kernel", "extract_postfix_wave_kernel", "search_lines_kernel<false, false, false, 0>", "search_solo_kernel"]
+subs = sys.argv[3:] or ["extract_prefix_wave_kernel", "extract_postfix_wave_kernel", "search_solo_kernel<false, false, false, true, false, true>",
+                        "search_solo_kernel<false, false, false, false, true, false>"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{mode}_{tag}")
 dst = os.path.join(root, "profiles")
@@ -41,7 +42,8 @@ steps = int(os.environ.get("STEPS", "4"))
 # launches of the covered kernels in the profiled run: the walk kernels of --mode extract run once more in the bench's counting
 # step under the same names (the 1-mismatch search kernels' counting instantiations have names of their own)
 cov_launches = steps + (1 if mode == "extract" else 0)
-covered = {"1mm": ["search_lines_kernel<false, false, false, 0>", "search_solo_kernel<false, false, false, false, true>"],
+covered = {"1mm": ["search_solo_kernel<false, false, false, true, false, true>",   # the walk of the k-mers (search_solo.h, WALK)
+                   "search_solo_kernel<false, false, false, false, true, false>"],  # the worklist search (WL)
            "extract": ["extract_prefix_wave_kernel", "move_prefix", "extract_postfix_wave_kernel"]}[mode]
 # the step's other kernels: they also run in the bench's one counting step (whose search kernels have names of their own)
 others = {"1mm": ["wl_", "hit_", "pack_dense_kernel", "search_init_tiled_kernel"], "extract": []}[mode]
