@@ -394,8 +394,11 @@ int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, siz
 /* (below 2^26 variant searches per shard the shards work side by side on streams of the set, forked from and joined to `stream`, each with a scratch of its
  * own -- rsbwt_set_hits_1mm_scratch_bytes accounts for that) */
 size_t rsbwt_set_hits_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k);
-/* 1 when a call of this size searches ALL the set's shards by one traced and one resumed launch (one device, k-mer
- * tables of one depth, below the same 2^26 variant searches per shard) instead of shard by shard: the launches are
+/* 1 when a call of this size searches ALL the set's shards by two launches (one device, k-mer tables of one depth,
+ * below the same 2^26 variant searches per shard) instead of shard by shard -- for k <= 32 a walk of the k-mers that
+ * also takes the step of the three substitutions at every position left of the tables' reach, then one search of the
+ * variants that survived it and of those inside the tables' reach (csrc/search_solo.h WALK / WL, csrc/mm1_worklist.hip);
+ * else a traced and a resumed launch: the launches are
  * then metered by the set (rsbwt_set_search_history_ms, rsbwt_set_last_search_counters), not by the shards' handles */
 int rsbwt_set_hits_1mm_is_fused(const rsbwt_set_t *s, size_t m, uint32_t k);
 int rsbwt_set_hits_1mm_dev(rsbwt_set_t *s, const void *d_packed, const void *d_valid, size_t m, uint32_t k, void *d_hits,

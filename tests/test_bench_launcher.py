@@ -93,3 +93,24 @@ def test_cxx_host_is_one_process_and_the_second_leg_of_an_n_gpu_run(monkeypatch)
     for flag, val in (("--host", "cxx"), ("--gpus", "8"), ("--steps", "7"), ("--warmup", "2"), ("--shards-per-gpu", "8"), ("--mix", "population")):
         assert cmd[cmd.index(flag) + 1] == val
     assert float(cmd[cmd.index("--runs") + 1]) == 2e10 and float(cmd[cmd.index("--queries") + 1]) == 1e7
+
+
+def test_bench_picks_the_tables_the_hbm_left_over_allows():
+    """bench.py pick_tables: one depth and format for the job out of the HBM that is free once every buffer exists, less
+    8 GB -- the grouped format (3 B per T-mer) where it is a level deeper than the plain one (8 B) and a T-mer still has
+    64 rows; and bench.total sums byte tensors without an int64 copy of them."""
+    import argparse
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(ktab_format="auto")
+    n = 117219747342  # symbols of a 2e10-run-byte `pop` shard
+    assert bench.pick_tables(a, int(42e9), 8, n, 13) == (15, 1)       # the headline: 8 shards, 42 GB left
+    assert bench.pick_tables(a, int(30e9), 8, n, 13) == (14, 0)       # rank 0 with two batches' gathered blocks: plain 14-mers
+    assert bench.pick_tables(a, int(270e9), 1, n, 13) == (16, 0)      # one shard: a 17-mer has 7 rows -- plain 16-mers
+    assert bench.pick_tables(a, int(200e9), 8, 2_100_000_000, 12) == (15, 0)  # the valid popBWT's shards: too few rows per T-mer
+    assert bench.pick_tables(argparse.Namespace(ktab_format="plain"), int(42e9), 8, n, 13) == (14, 0)
+    assert bench.pick_tables(a, int(42e9), 8, n, 0) == (0, 0)
+    t = torch.arange(300, dtype=torch.int32).to(torch.uint8)
+    assert bench.total(t) == int(t.to(torch.int64).sum()) and bench.total(torch.empty(0, dtype=torch.uint8)) == 0
+    assert bench.total(torch.tensor([-1, 5, -1], dtype=torch.int32)) == 3
