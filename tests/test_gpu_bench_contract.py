@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--runs", "3e8", "--shards-per-gpu", "2", "--steps", "2", "--warmup", "1"]
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, more_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(more_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
                          timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -60,6 +61,19 @@ def test_gpu_bench_rows_modes(mode, extra):
     d = _run(SMALL + ["--mode", mode] + extra)
     _common(d, 1)
     assert ("configs[3]" if mode == "1mm" else "configs[4]") in d["config"]["workload"]
+    # the mode's own CPU baseline: the oracle's composition / walk of the sample the GPU's output is held to
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["gpu_matches_oracle_on_sample"] is True
+    assert d["config"]["hit_lists_verified" if mode == "1mm" else "reads_verified"] is True
+
+
+def test_gpu_bench_1mm_by_the_traced_launch_and_the_branch_kernel():
+    """The A/B path of a set's 1-mismatch hit lists (RSBWT_SET_1MM_NO_WALK: a traced launch of the pair kernel,
+    wl_branch_kernel, wl_own_kernel instead of the one walk of the k-mers) leaves the same lists: shard 0's against the
+    oracle's, as in the default run."""
+    d = _run(SMALL + ["--mode", "1mm", "--kmers", "2e4"], more_env={"RSBWT_SET_1MM_NO_WALK": "1"})
+    assert d["config"]["hit_lists_verified"] is True and d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+    assert "traced" in d["roofline"]["kernel"]
 
 
 def test_gpu_bench_launches_its_own_ranks():
