@@ -59,7 +59,7 @@ extern "C" {
  * bits 5..9: depth T of the k-mer table (4^T entries of 8 B holding findInterval's answer for
  * every T-mer; searches of k >= T symbols start from one lookup).  0 = auto (the deepest table
  * no larger than the index itself nor than a quarter of the free HBM, with 4^T <= n; rsbwt_set_open
- * sizes the tables of one GPU's shards together), 31 = no table, else T = 2..16 (T = 16: 34 GB). */
+ * sizes the tables of one GPU's shards together, out of three quarters of what is free once they are all resident), 31 = no table, else T = 2..16 (T = 16: 34 GB). */
 #define RSBWT_OPEN_READS 1u
 #define RSBWT_OPEN_KTAB_GROUPED 2u
 #define RSBWT_KTAB_SHIFT 5
@@ -325,8 +325,9 @@ void rsbwt_set_close(rsbwt_set_t *s); /* closes the shards it opened itself */
 size_t rsbwt_set_size(const rsbwt_set_t *s);
 size_t rsbwt_set_devices(const rsbwt_set_t *s);
 rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
-/* k-mer tables for the shards that have none; depth 0 = sized per device from its free HBM (the depth
- * that gives, over all devices: rsbwt_set_auto_ktab_depth) */
+/* k-mer tables for the shards that have none; depth 0 = sized per device from its free HBM: the deepest tables that
+ * fit three quarters of what is free with the shards resident, leave 8 GiB, and are no larger than 5/4 of a shard's
+ * lines (the depth that gives, over all devices: rsbwt_set_auto_ktab_depth) */
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth);
 uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s);
 /* the same with the format named (rsbwt_attach_ktab_format; rsbwt_set_attach_ktabs = PLAIN); grouped tables are

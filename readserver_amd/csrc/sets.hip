@@ -301,7 +301,9 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
 
 
 // The depth rsbwt_set_attach_ktabs(s, 0) would give the shards of device group g: the deepest T whose
-// tables (one per shard of that device without one) fit a third of the device's free HBM, none larger
+// tables (one per shard of that device without one) fit three quarters of the device's free HBM and leave 8 GiB of it
+// (the shards are resident when this is asked: what is free is what the tables and the caller's batch buffers share --
+// a third of it, the rule until round 4, left 8 x 20 GB shards at 13-mer tables where 15-mer ones fit), none larger
 // than 5/4 of its shard's lines, with 4^T <= the smallest shard's length; at most 16 (grouped: 17); 0 = none.
 // *fmt: in = the format asked for (KTAB_PLAIN / KTAB_GROUPED), out = the one to build (auto_ktab_depth_for).
 static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt) {
@@ -317,7 +319,8 @@ static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt) {
         min_bytes = std::min(min_bytes, h->hbm_bytes);
     }
     if (!need) return 0;
-    const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, free_b / 3 / need);
+    const uint64_t keep = std::max<uint64_t>(8ull << 30, free_b / 4);
+    const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, (free_b > keep ? free_b - keep : 0) / need);
     return auto_ktab_depth_for(budget, min_n, fmt);
 }
 
