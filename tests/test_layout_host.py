@@ -63,7 +63,9 @@ def test_layout_rejects_symbols_above_four(rsb):
 def test_layout_code_under_address_and_ub_sanitizers(tmp_path):
     """tests/native/fuzz_layout_host.cpp: the layout builder and the scalar readers of line_format.h
     (the code the GPU kernels run) built for the CPU with -fsanitize=address,undefined, on 30 random run
-    streams of six shapes at spans 2..2,944, every position held to naive ranks."""
+    streams of six shapes at spans 2..2,944, every position held to naive ranks; and the grouped k-mer table's record
+    code on 200,000 groups of four siblings, sound ones and arbitrary ones (a sibling that comes back with a width is
+    exactly what went in)."""
     import os
     import shutil
     import subprocess
