@@ -177,3 +177,49 @@ def test_grouped_ktab_record_code(rsb):
         assert np.all(got_w[~said, i] == WIDE)
     assert not escaped[10] and escaped[11] and not escaped[12] and np.all(got_w[13] == WIDE) and got_w[14, 3] == 1
     assert (~escaped).sum() > 0.5 * G and escaped.sum() > 1000  # both kinds are well represented
+
+
+@pytest.mark.parametrize("T", [5, 7, 9])
+def test_grouped_ktab_records_of_a_valid_bwt_are_the_oracles_intervals(rsb, oracle, fixture_bwt, T):
+    """What the grouped k-mer table rests on, held to the oracle on the golden popBWT (a VALID BWT of '$'-terminated reads,
+    the oracle pinned to the compiled reference's vectors): the four T-mers that differ in their LAST symbol tile one
+    stretch of rows -- rows that begin with a shorter suffix and '$' sort before all four -- so EVERY group the record
+    code gives up on is one of 16,383 rows or more, and every T-mer that occurs in a smaller group comes back from its
+    12-byte record as exactly findInterval's answer (query.cpp:24-41).  CPU only: the oracle's intervals through the
+    record code the builder kernel and the lookups share (csrc/line_format.h)."""
+    L = rsb.lib()
+    path, _ = fixture_bwt
+    oix = oracle.load(path)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    G = 4 ** (T - 1)
+    g = np.arange(G, dtype=np.int64)
+    # group g = the first T - 1 symbols (first symbol in the low bits of the code, as the tables index them); sibling = the last
+    first = np.stack([(g >> (2 * j)) & 3 for j in range(T - 1)], axis=1)
+    km = np.empty((G, 4, T), np.uint8)
+    km[:, :, :T - 1] = acgt[first][:, None, :]
+    km[:, :, T - 1] = acgt[None, :]
+    lo, up = oix.find_intervals(km.reshape(-1, T), nthreads=8)
+    lo, up = lo.reshape(G, 4).copy(), up.reshape(G, 4).copy()
+    out = np.zeros((G, 4), np.uint64)
+    assert L.rsbwt_ktab_group_selftest_host(lo.ctypes.data, up.ctypes.data, G, out.ctypes.data) == 0
+    live = up >= lo  # (no interval of this BWT ends at 2^64 - 1: its first row is a '$' row)
+    width = np.where(live, up - lo + np.uint64(1), 0).astype(np.int64)
+    total = width.sum(axis=1)
+    got_w = (out >> np.uint64(40)).astype(np.int64)
+    got_lo = (out & np.uint64((1 << 40) - 1))
+    small = total < 16383
+    escaped = (got_w == 0xFFFFFF).all(axis=1)
+    assert not (escaped & small & (total > 0)).any()            # no group of a valid BWT fails to tile
+    assert (escaped | small).all()                               # a group too wide for its record is given up whole
+    said = live & small[:, None]
+    assert np.array_equal(got_w[said], width[said]) and np.array_equal(got_lo[said], lo[said])
+    assert (got_w[~said] == 0xFFFFFF).all()                      # a T-mer that does not occur is left to the search
+    if T >= 7:  # (555 rows per 7-mer of this BWT: nearly every group fits its record; at T = 5 none does)
+        assert said.sum() > 0.9 * live.sum()
+    else:
+        assert escaped.all()
+    # the siblings of a group are neighbours in row order: each begins where the one before it ended
+    for i in range(1, 4):
+        prev_end = np.where(live[:, i - 1], up[:, i - 1] + np.uint64(1), 0)
+        both = live[:, i] & live[:, i - 1]
+        assert np.array_equal(lo[both, i], prev_end[both])
