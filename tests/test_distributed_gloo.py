@@ -295,3 +295,18 @@ def test_read_packing_round_trips_on_the_host():
     # shapes with leading dimensions ([S][n][stride], as bench.py holds them)
     p3 = sharded.pack_reads(reads.reshape(5, 100, stride), lens.reshape(5, 100))
     assert p3.shape == (5, 100, stride // 4) and torch.equal(p3.reshape(n, -1), packed)
+
+
+def test_world3_pipelined_interval_gather_with_one_batch_of_blocks_on_the_root():
+    """The same pipeline with three ranks and out_depth = 1 (bench.py's choice from 4 ranks on: rank 0 keeps ONE batch's
+    gathered blocks): every rank's packed pairs of every batch arrive, rank by rank, in the blocks the batch before used."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + 1777) % 2000
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 3, port, q, True, True, 1)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == "ok"
