@@ -195,7 +195,7 @@ def test_pack_pairs_check_refuses_what_the_record_cannot_carry():
         sharded.pack_pairs(t)  # unchecked: truncates, as documented
 
 
-def _concat_worker(rank, world, port, q):
+def _concat_worker(rank, world, port, q, depth=2):
     """configs[3] / configs[4] at N > 1: what every rank's shards give is gathered on rank 0 (fixed-size blocks,
     pipelined like the interval gather) and laid side by side in global shard order."""
     import torch
@@ -205,10 +205,10 @@ def _concat_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         S, cap, n, stride = 3, 50, 7, 16
-        gh = sharded.BlockGatherer((S, cap, 4), torch.int64, torch.device("cpu"), depth=2)
-        gt = sharded.BlockGatherer((S,), torch.int64, torch.device("cpu"), depth=2)
-        go = sharded.BlockGatherer((S, n, stride), torch.uint8, torch.device("cpu"), depth=2)
-        gl = sharded.BlockGatherer((S, n), torch.int32, torch.device("cpu"), depth=2)
+        gh = sharded.BlockGatherer((S, cap, 4), torch.int64, torch.device("cpu"), depth=depth)
+        gt = sharded.BlockGatherer((S,), torch.int64, torch.device("cpu"), depth=depth)
+        go = sharded.BlockGatherer((S, n, stride), torch.uint8, torch.device("cpu"), depth=depth)
+        gl = sharded.BlockGatherer((S, n), torch.int32, torch.device("cpu"), depth=depth)
         ok = True
         for i in range(5):  # more batches than buffers: acquire waits for the gather that used the buffer
             hb, tb, ob, lb = gh.acquire(i), gt.acquire(i), go.acquire(i), gl.acquire(i)
@@ -270,6 +270,22 @@ def test_world2_hit_lists_and_reads_are_concatenated_in_shard_order():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_world3_hit_lists_and_reads_with_one_gather_in_flight():
+    """bench.py's rows modes from 3 ranks on: ONE batch's blocks per rank (BlockGatherer depth 1: a batch is written once
+    the gather of the one before it is complete), three ranks, global shard order."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + 911) % 2000
+    procs = [ctx.Process(target=_concat_worker, args=(r, 3, port, q, 1)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True), (2, True)]
 
 
 def test_read_packing_round_trips_on_the_host():
