@@ -33,6 +33,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# when this run began: the launcher parent's start where there is one (it hands its own down), else this process's
+T_START = float(os.environ.get("BENCH_T0", "0") or 0) or time.time()
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LINE_BYTES = 128       # algorithmic bytes per distinct window line read by an Occ lookup
@@ -97,6 +99,10 @@ def parse():
                          "N > 1 run of the default host adds this as a second leg (config.cxx_host) unless --no-cxx-leg")
     ap.add_argument("--no-cxx-leg", action="store_true", help="N > 1: skip the one-process (C++ host) leg after the per-rank one")
     ap.add_argument("--cxx-leg-timeout", type=float, default=420.0, help="seconds the second leg may take before it is given up")
+    ap.add_argument("--total-budget", type=float, default=540.0,
+                    help="seconds the WHOLE run may take (the driver's limit is 600): rank 0 prints the headline line BEFORE the second "
+                         "leg starts, bounds the leg by what is left of this budget, and prints the line again with config.cxx_host "
+                         "after it -- the first line stands whatever happens to the leg")
     ap.add_argument("--layout", choices=["auto", "plain", "reads"], default="auto",
                     help="reads = RSBWT_OPEN_READS: a psi hint in every window line, built with the index (~9 %% more lines): "
                          "what a shard that serves read extraction is opened with; auto = reads for --mode extract, plain otherwise")
@@ -201,7 +207,7 @@ def search_kernel_name(nshards, n=0, ktab_depth=0, span=0):
     otherwise; RSBWT_SEARCH_KERNEL overrides."""
     e = os.environ.get("RSBWT_SEARCH_KERNEL", "auto")
     narrow = ktab_depth >= 2 and ((n >> (2 * ktab_depth)) << 2) <= span
-    solo = e == "solo" or (e not in ("pair", "solo") and nshards == 1 and narrow)
+    solo = e == "solo" or (e not in ("pair", "solo") and narrow)
     return "search_solo_kernel" if solo else "search_lines_kernel"
 
 
@@ -240,6 +246,7 @@ def self_launch(a, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks here
     env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("BENCH_T0", repr(T_START))  # the ranks count the run's budget from here
     cmd = self_launch_cmd(argv, a.gpus, int(os.environ.get("BENCH_MASTER_PORT", "0")) or free_port())
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     p = subprocess.Popen(cmd, env=env)  # stdout/stderr inherited: rank 0's JSON line arrives on our stdout
@@ -415,6 +422,19 @@ def run_exact(a, c, mix, steps, warmup, headline):
     R, Q, k, S = int(a.runs), int(a.queries), a.k, a.shards_per_gpu
     t_build0 = time.time()
     want_cpu = headline and rank == 0 and world == 1 and a.cpu_sample > 0  # the CPU baseline is an N = 1 leg
+    # what this rank will hold, item by item, against what the device has free -- BEFORE the first shard is built: a
+    # job that cannot fit (rank 0 of an N-GPU job also holds every rank's gathered blocks) stops here with the table,
+    # not with an out-of-memory error between two shards or in the first gather (readserver_amd/sharded.py, hbm_plan)
+    wire_packed = world > 1 and not a.separate_arrays and not a.gather_unpacked
+    for_reads = a.layout == "reads" or (a.layout == "auto" and a.mode == "extract")
+    plan_kw = dict(wire_packed=wire_packed, separate=a.separate_arrays, out_depth=(2 if world <= 2 else 1))
+    if not a.rehearse_on_one_gpu:  # (a rehearsal's ranks share one GPU: no plan holds there)
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        est = sharded.hbm_plan(world, rank, S, Q, k, int(R * (1.73 if for_reads else 1.64)), R, **plan_kw)
+        try:
+            sharded.check_hbm_plan(est, free0)
+        except MemoryError as e:
+            raise SystemExit("bench.py: " + str(e))
     shards, sset, host_runs = build_shards(a, c, mix, want_host_runs=want_cpu)
     n_sym = shards[0].getBWLen()
     # the batch's buffers first (rank 0 also holds the gathered intervals of all ranks), then the k-mer
@@ -425,8 +445,7 @@ def run_exact(a, c, mix, steps, warmup, headline):
     d_kmers = torch.empty((Q, k), dtype=torch.uint8, device=dev)
     # N > 1: the pairs travel as 10-byte {lower:40, width:40} records (exact for every interval; 5/8 of the
     # bytes): an xGMI link moves ~77 GB/s per direction, so 1.28 GB of 16-byte pairs per peer and batch would
-    # take longer than the 12 ms search that produced them
-    wire_packed = world > 1 and not a.separate_arrays and not a.gather_unpacked
+    # take longer than the 12 ms search that produced them (wire_packed, above)
     # (from 4 ranks on rank 0 keeps ONE batch's gathered blocks: at N = 8 that is 6.4 GB of HBM the k-mer tables get --
     # the grouped 15-mer tables then fit beside the shards on rank 0 too, and the job's one depth is the N = 1 depth)
     gat = sharded.IntervalGatherer(S, Q, cdev, depth=2, interleaved=not a.separate_arrays, packed=wire_packed, wire_device=cdev,
@@ -456,6 +475,11 @@ def run_exact(a, c, mix, steps, warmup, headline):
         two_ok = [d_valid, torch.empty_like(d_valid)]
     size_tables(a, c, sset, shards, S)
     t_build = time.time() - t_build0
+    # the plan again with what was built (exact line bytes, the tables chosen), and what the device says is left
+    lines_b = max(int(g.hbm_bytes()) - int(g.ktab_info()[1]) for g in shards)
+    plan = sharded.hbm_plan(world, rank, S, Q, k, lines_b, R, ktab_bytes_per_shard=max(int(g.ktab_info()[1]) for g in shards), **plan_kw)
+    plan["free_after_allocation"] = int(torch.cuda.mem_get_info(dev)[0])
+    plan = {kk: (round(v / 1e9, 3) if kk not in ("out_depth", "world", "rank") else v) for kk, v in plan.items()} | {"unit": "GB"}
     make_batch(a, c, shards, mix, Q, k, d_kmers)
     torch.cuda.synchronize()
 
@@ -632,6 +656,7 @@ def run_exact(a, c, mix, steps, warmup, headline):
         "index_hbm_bytes_per_gpu": hbm,
         "index_bytes_per_run_byte": (hbm - sum(g.ktab_info()[1] for g in shards)) / (S * R),
         "index_build_s": round(t_build, 2), "gather_verified": gather_verified, "wire_packed": wire_packed,
+        "hbm_plan": plan,
         "single_shard_check": single,
         "step": ("search kernel on the main stream; the next batch's packing and start records on a second stream beside it "
                  "(rsbwt_set_prepare_dev / rsbwt_set_find_interval_pairs_prepared_dev)" if piped else
@@ -681,6 +706,44 @@ def cxx_leg_cmd(a):
     return [sys.executable, os.path.abspath(__file__), "--host", "cxx", "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
             "--runs", str(a.runs), "--queries", str(a.queries), "--k", str(a.k), "--shards-per-gpu", str(a.shards_per_gpu),
             "--stream", a.stream, "--mix", a.mix, "--seed", str(a.seed), "--ktab-depth", str(a.ktab_depth), "--ktab-format", a.ktab_format, "--window-span", str(a.window_span)]
+
+
+def cxx_leg_budget(a, elapsed):
+    """Seconds the second leg may take: what is left of --total-budget after `elapsed` seconds of the run, less 20 s for
+    the second line and the ranks' teardown, and no more than --cxx-leg-timeout.  None (with the reason) when less than
+    90 s would be left -- the leg builds 8 shards per GPU (25 s) before its first batch: not worth starting."""
+    left = a.total_budget - elapsed - 20.0
+    if left < 90.0:
+        return None, f"{max(left, 0):.0f} s left of the run's {a.total_budget:.0f} s budget after {elapsed:.0f} s: not started"
+    return min(a.cxx_leg_timeout, left), None
+
+
+def second_leg(a, out, rehearsal=False, emit=None, runner=None, clock=time.time):
+    """Rank 0, after every rank has closed its shards: the headline line goes out NOW (config.cxx_host says the leg is
+    still to come), then the one-process leg runs as a child within the budget, then the line goes out again with the
+    leg's record.  A reader that takes the last JSON line of stdout gets the most complete one that was reached."""
+    import subprocess
+    emit = emit or (lambda line: print(line, flush=True))
+    runner = runner or (lambda cmd, timeout: subprocess.run(cmd, capture_output=True, text=True, timeout=timeout))
+    out["config"]["cxx_host"] = {"pending": "this line was printed before the one-process (--host cxx) leg started; a later line of the same run carries its record"}
+    emit(json.dumps(out))
+    limit, why_not = cxx_leg_budget(a, clock() - T_START)
+    if limit is None:
+        out["config"]["cxx_host"] = {"skipped": why_not}
+    else:
+        try:
+            cmd = cxx_leg_cmd(a)
+            if rehearsal:  # (one device: the leg's control flow, not its gather)
+                cmd[cmd.index("--gpus") + 1] = "1"
+            t0 = clock()
+            r = runner(cmd, limit)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            rec = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-800:]}
+            rec["leg_seconds"], rec["leg_limit_seconds"] = round(clock() - t0, 1), round(limit, 1)
+            out["config"]["cxx_host"] = rec
+        except Exception as e:  # noqa: BLE001  (a time-out included: subprocess.TimeoutExpired)
+            out["config"]["cxx_host"] = {"error": repr(e), "leg_limit_seconds": round(limit, 1)}
+    emit(json.dumps(out))
 
 
 def main():
@@ -765,6 +828,7 @@ def main():
                 "spilled_position_fraction": head["spilled_position_fraction"],
                 "index_hbm_bytes_per_gpu": head["index_hbm_bytes_per_gpu"], "index_bytes_per_run_byte": head["index_bytes_per_run_byte"],
                 "index_build_s": head["index_build_s"],
+                "hbm_plan": head["hbm_plan"],
                 "gather_verified": head["gather_verified"],
                 "gathered_as": (None if world == 1 else "10-byte {lower:40, width:40} records (rsbwt_pack_interval_pairs_dev), exact"
                                 if head["wire_packed"] else "16-byte pairs"),
@@ -781,23 +845,16 @@ def main():
             out["config"]["shards_matching_oracle"] = head["shards_matching_oracle"]
         if world > 1 and not a.no_cxx_leg:
             # second leg: the same workload driven by ONE process over all the GPUs (the C++ host's shape).  Every rank has
-            # closed its shards; rank 0 starts the leg as a child with a time limit and the others wait -- whatever happens
-            # to it, the line above stands.
+            # closed its shards; rank 0 PRINTS THE HEADLINE LINE FIRST, then starts the leg as a child bounded by what is
+            # left of the run's budget, and prints the line again with the leg's record: the first line stands whatever
+            # happens to the leg -- a time-out of the leg, or the driver's own clock running out on it.
             c.torch.cuda.synchronize()
             c.dist.barrier(group=getattr(c, "cpu_group", None))
             if c.rank == 0:
-                import subprocess
-                try:
-                    cmd = cxx_leg_cmd(a)
-                    if a.rehearse_on_one_gpu:  # (one device: the leg's control flow, not its gather)
-                        cmd[cmd.index("--gpus") + 1] = "1"
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.cxx_leg_timeout)
-                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    out["config"]["cxx_host"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-800:]}
-                except Exception as e:  # noqa: BLE001
-                    out["config"]["cxx_host"] = {"error": repr(e)}
+                second_leg(a, out, rehearsal=a.rehearse_on_one_gpu)
+                out = None  # (both lines are out)
             c.dist.barrier(group=getattr(c, "cpu_group", None))
-    if c.rank == 0:
+    if c.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if c.world > 1:
         c.dist.destroy_process_group()

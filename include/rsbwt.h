@@ -139,7 +139,15 @@ int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 int rsbwt_attach_ktab_format(rsbwt_t *h, uint32_t T, uint32_t format);
 /* format (RSBWT_KTAB_FORMAT_PLAIN / _GROUPED), bytes in HBM and -- grouped -- the T-mers left to the search; any may be NULL */
 int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_t *untabulated);
-int rsbwt_device(const rsbwt_t *h);
+int rsbwt_device(const rsbwt_t *h);          /* the GPU the shard is resident on */
+/* The device number the shard was opened with.  Equal to rsbwt_device() except under the TEST HOOK
+ * RSBWT_TEST_DEVICE_ALIASES=N (honoured only while RSBWT_ENABLE_TEST_HOOKS is set; read at every rsbwt_open*):
+ * device numbers 0..N-1 then name N logical devices dealt round-robin over the physical ones, and a shard set groups
+ * its shards by LOGICAL device -- so the several-device host code of a set (a thread, a context pool and a fused
+ * launch per device group; the merge of the groups' counts, lists and reads) runs on a box with one GPU.  RCCL is
+ * not used between groups that share a GPU (it refuses two ranks on one device): such a set takes the paths of a
+ * box without librccl. */
+int rsbwt_logical_device(const rsbwt_t *h);
 
 /* query.h mirrors, batched (include/bwt/query.h:18-32) ---------------------------------
  * rsbwt_find_intervals replaces  BWTInterval findInterval(const BWT*, const std::string& w)

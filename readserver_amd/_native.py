@@ -71,6 +71,7 @@ SIGNATURES = {
     "rsbwt_attach_ktab_format": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rsbwt_ktab_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), _u64p, _u64p]),
     "rsbwt_device": (C.c_int, [_vp]),
+    "rsbwt_logical_device": (C.c_int, [_vp]),
     "rsbwt_find_intervals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),
     "rsbwt_count": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp]),
     "rsbwt_find_intervals_1mm": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp]),

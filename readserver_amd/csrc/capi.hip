@@ -48,6 +48,25 @@ int use_device(int device) {
     return RSBWT_OK;
 }
 
+// The device number an rsbwt_open* caller gives is a LOGICAL device.  In a deployment logical = physical.  Test hook
+// (honoured only while RSBWT_ENABLE_TEST_HOOKS is set, read at every open): RSBWT_TEST_DEVICE_ALIASES=N makes the
+// numbers 0..N-1 name N logical devices dealt round-robin over the physical ones -- on a one-GPU box all N are
+// GPU 0.  A shard set groups its shards by LOGICAL device (sets.hip, make_groups), so the host code of a set that
+// spans several devices -- one thread, one context pool, one fused launch per group; the merge of the groups'
+// counts, lists and reads -- runs where only one GPU exists.  RCCL refuses two ranks on one physical device: such a
+// set takes the paths a box without librccl takes (host-side sums, peer copies for the gather).
+int resolve_device(int logical, int *physical) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RSBWT_ENODEV, "no HIP device is visible: the popBWT engine has no CPU fallback");
+    const char *hooks = getenv("RSBWT_ENABLE_TEST_HOOKS"), *al = getenv("RSBWT_TEST_DEVICE_ALIASES");
+    const int aliases = (hooks && al) ? atoi(al) : 0;
+    const int limit = aliases > 0 ? aliases : n;
+    if (logical < 0 || logical >= limit) return fail(RSBWT_ENODEV, "device %d out of range (0..%d)", logical, limit - 1);
+    *physical = aliases > 0 ? logical % n : logical;
+    return RSBWT_OK;
+}
+
 // ---- per-call contexts: a stream pair + staging buffer, so that concurrent host callers of one
 // handle (the reference shares one BWT* across its pool threads, service.cpp:1513,1532-1569) run
 // side by side instead of queueing on one lock.  At most MAX_CTX per handle; further callers wait.
@@ -262,11 +281,12 @@ int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_
 
 static int ensure_select_samples(rsbwt_t *h, hipStream_t stream);
 
-static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device,
+static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device, int logical,
                        uint32_t flags, rsbwt_t **out) {
     rsbwt_t *h = new (std::nothrow) rsbwt();
     if (!h) return fail(RSBWT_ENOMEM, "host allocation failed");
     h->device = device;
+    h->logical_device = logical;
     h->num_strings = num_strings;
     memset(&h->view, 0, sizeof h->view);
     hipDeviceProp_t prop;
@@ -349,23 +369,27 @@ int rsbwt_open_device_runs(const void *d_runs, uint64_t num_runs, uint64_t num_s
                            uint32_t flags, rsbwt_t **out) {
     if (!out || (!d_runs && num_runs)) return fail(RSBWT_EINVAL, "null argument");
     *out = nullptr;
-    int rc = use_device(device);
+    const int logical = device;
+    int rc = resolve_device(logical, &device);
+    if (rc == RSBWT_OK) rc = use_device(device);
     if (rc) return rc;
-    return finish_open(d_runs, num_runs, num_strings, device, flags, out);
+    return finish_open(d_runs, num_runs, num_strings, device, logical, flags, out);
 }
 
 int rsbwt_open_runs(const uint8_t *runs, uint64_t num_runs, uint64_t num_strings, int device,
                     uint32_t flags, rsbwt_t **out) {
     if (!out || (!runs && num_runs)) return fail(RSBWT_EINVAL, "null argument");
     *out = nullptr;
-    int rc = use_device(device);
+    const int logical = device;
+    int rc = resolve_device(logical, &device);
+    if (rc == RSBWT_OK) rc = use_device(device);
     if (rc) return rc;
     void *d_runs = nullptr;
     hipError_t e = hipMalloc(&d_runs, num_runs ? num_runs : 16);
     if (e != hipSuccess) return fail(RSBWT_ENOMEM, "hipMalloc(%llu) for run bytes: %s", (unsigned long long)num_runs, hipGetErrorString(e));
     e = hipMemcpy(d_runs, runs, num_runs, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d_runs); return fail_hip(e, "hipMemcpy(runs)"); }
-    rc = finish_open(d_runs, num_runs, num_strings, device, flags, out);
+    rc = finish_open(d_runs, num_runs, num_strings, device, logical, flags, out);
     (void)hipFree(d_runs);
     return rc;
 }
@@ -378,7 +402,9 @@ int rsbwt_open(const char *bwt_path, int device, uint32_t flags, rsbwt_t **out) 
     int rc = bwt_open_read(bwt_path, &f, &hdr);
     if (rc == RSBWT_EIO) return fail(rc, "cannot open %s", bwt_path);
     if (rc) return fail(rc, "%s is not an SGA run-length BWT (magic 0xCACA) or is truncated", bwt_path);
-    rc = use_device(device);
+    const int logical = device;
+    rc = resolve_device(logical, &device);
+    if (rc == RSBWT_OK) rc = use_device(device);
     if (rc) { fclose(f); return rc; }
     // stream the file through two pinned buffers into HBM
     const size_t CH = 64u << 20;
@@ -405,7 +431,7 @@ int rsbwt_open(const char *bwt_path, int device, uint32_t flags, rsbwt_t **out) 
     if (st) (void)hipStreamSynchronize(st);
     fclose(f);
     if (rc == RSBWT_OK) {
-        rc = finish_open(d_runs, hdr.num_runs, hdr.num_strings, device, flags, out);
+        rc = finish_open(d_runs, hdr.num_runs, hdr.num_strings, device, logical, flags, out);
         if (rc == RSBWT_OK && (*out)->view.n != hdr.num_symbols) {
             rsbwt_close(*out);
             *out = nullptr;
@@ -460,6 +486,7 @@ uint64_t rsbwt_hbm_bytes(const rsbwt_t *h) { return h->hbm_bytes; }
 uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h) { return h->psi_hint_lines; }
 int rsbwt_opened_for_reads(const rsbwt_t *h) { return h->view.hint_room ? 1 : 0; }
 int rsbwt_device(const rsbwt_t *h) { return h->device; }
+int rsbwt_logical_device(const rsbwt_t *h) { return h->logical_device; }
 
 // Test hook: w[i] = p[i] / S, r[i] = p[i] % S as the KERNELS compute them (fast_window); host buffers.
 int rsbwt_debug_fast_window(const uint64_t *p, size_t n, uint32_t S, uint32_t *w, uint32_t *r, int device) {
@@ -827,8 +854,10 @@ static int search_dev(rsbwt_t *h, const void *d_packed, const void *d_valid, siz
 namespace rsb {
 int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
                       const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
-                      bool counts_only) {
+                      bool counts_only, bool narrow) {
     const uint32_t wpq = words_per_kmer(k);
+    search_extra ex;
+    ex.narrow = narrow;
     ctx_guard g(pool);
     if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
     const size_t SLICE = std::max<size_t>(1u << 16, (2u << 20) / nshards);
@@ -854,7 +883,7 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
             HIP_OK(hipMemcpyAsync(d_ascii, hp, ascii_bytes, hipMemcpyHostToDevice, st));
             hipError_t e = launch_pack(d_ascii, Q, k, stride, d_packed, d_valid, st);
             if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
-            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, Q, k, d_lo, d_lo + a_res, counts_only, st, nullptr);
+            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, Q, k, d_lo, d_lo + a_res, counts_only, st, &ex);
             if (rc) return rc;
             HIP_OK(hipMemcpyAsync(hp + h_res, d_lo, (counts_only ? 1 : 2) * res_bytes, hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
@@ -902,7 +931,7 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
         }
         {
             RSB_TIMED(search_launch);
-            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st, nullptr);
+            rc = search_launch(m, d_views, nshards, num_cus, d_packed, d_valid, cur.m, k, cur.d_lo, cur.d_up, counts_only, cur.st, &ex);
         }
         if (rc) return rc;
         if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
@@ -929,7 +958,7 @@ static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size
         return RSBWT_OK;
     }
     if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
-    return search_host_views(*h, h->pool, h->d_view, 1, h->num_cus, kmers, Q, k, stride, lower, upper, counts_only);
+    return search_host_views(*h, h->pool, h->d_view, 1, h->num_cus, kmers, Q, k, stride, lower, upper, counts_only, view_is_narrow(h->view, k));
 }
 
 extern "C" {

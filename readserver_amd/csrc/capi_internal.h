@@ -21,6 +21,7 @@ namespace rsb {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail_hip(hipError_t e, const char *what);
 int use_device(int device);
+int resolve_device(int logical, int *physical);  // the device number of an rsbwt_open* call -> the GPU it names (capi.hip)
 
 // A stream pair and a staging buffer for the duration of one host-buffer call.
 struct call_ctx {
@@ -59,8 +60,8 @@ int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, 
                   hipStream_t stream, const search_extra *extra);
 int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
                       const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
-                      bool counts_only);
-// search_extra::narrow for a launch on this shard alone: a T-mer's interval is ~ n / 4^T rows wide;
+                      bool counts_only, bool narrow = false);
+// search_extra::narrow for a launch on this shard: a T-mer's interval is ~ n / 4^T rows wide;
 // a quarter of a window or less = the steps after the table find both positions in one line
 inline bool view_is_narrow(const shard_view &v, uint32_t k) {
     return v.ktab && v.ktab_depth >= 2u && k >= v.ktab_depth && ((v.n >> (2u * v.ktab_depth)) << 2) <= v.sp.S;
@@ -85,7 +86,8 @@ int meter_work(search_meter &m, uint64_t *words, size_t nwords);
 }  // namespace rsb
 
 struct rsbwt : rsb::search_meter {
-    int device = 0;
+    int device = 0;          // the GPU (hipSetDevice)
+    int logical_device = 0;  // the number the caller opened it with: what a shard set groups by (= device outside tests)
     int num_cus = 256;
     rsb::shard_view view;              // host copy
     rsb::shard_view *d_view = nullptr; // the same in HBM, for kernels that take views from memory

@@ -676,12 +676,15 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     ulonglong2 *trace = extra ? (ulonglong2 *)extra->d_trace_out : nullptr;
     const uint32_t trace_n = extra ? extra->trace_n : 0u;
     const uint32_t wpq = (k + 31u) / 32u ? (k + 31u) / 32u : 1u;
-    // one lane per search (search_solo.h) where intervals are narrow for most of a search: a single
-    // shard whose k-mer table is deep (extra->narrow: what is left of a hit are steps inside one
-    // window); several shards per launch run at the request ceiling on lane pairs already, and behind
+    // one lane per search (search_solo.h) where intervals are narrow for most of a search: shards whose
+    // k-mer tables are deep (extra->narrow: what is left of a hit are steps inside one window); behind
     // a shallow table the first steps are wide, where pairs take one pass and a lone lane two
     // (and only when the batch fills every lane of the launch: below that nothing is saturated and the
-    // pairs answer sooner -- a lone request of the service loop takes half the passes)
+    // pairs answer sooner -- a lone request of the service loop takes half the passes).
+    // Until round 5 several shards per launch stayed on lane pairs ("at the request ceiling already"): the
+    // launch is bound by the instructions a SIMD issues, not by requests (+ 12.6 % VALU = + 5.7 %
+    // time, the same build), a pair spends a whole lane on `upper` where 97 % of the steps find it in the line
+    // `lower - 1` staged, and the lone lanes run the headline's 8 x 20 GB shards in 19.05 ms against 20.04
     const bool table_build = extra && extra->table_build;
     const int choice = search_kernel_choice();
     size_t g = 0;
@@ -700,7 +703,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
     // pass where pairs take 32 -- any number of shards: 25.0 -> 23.5 ms per batch of 4e5 31-mers x 8 shards)
     const bool resumed = extra && extra->d_trace_in;
     const bool solo = !table_build && (choice == 1 || (choice == 2 && Q * nshards >= cap * WG_WAVES * 64u &&
-                                                       (resumed || (nshards == 1 && extra && extra->narrow))));
+                                                       (resumed || (extra && extra->narrow))));
     // 32 (pairs) or 64 (solo) searches per wave, 4 waves per workgroup
     const size_t per_wg = (solo ? 64u : 32u) * WG_WAVES;
     g = (Q * nshards + per_wg - 1) / per_wg;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -86,13 +87,17 @@ sum_rows_kernel(const uint64_t *__restrict__ rows, uint32_t S, size_t m, uint64_
 
 // the shards of one device
 struct dev_group : search_meter {
-    int device = 0;
+    int device = 0;   // the GPU
+    int logical = 0;  // the device number its shards were opened with: what groups them (= device outside tests, capi.hip resolve_device)
     int num_cus = 256;
     std::vector<size_t> idx;         // positions in the set, ascending
     shard_view *d_views = nullptr;   // [idx.size()] in HBM
     uint64_t *d_ktab = nullptr;      // the interleaved k-mer tables of the shards this set gave one
     ctx_pool pool;
     ncclComm_t comm = nullptr;
+    // the gather without RCCL (peer copies issued on the root's stream): "the block is ready" on this group's stream,
+    // "the block has been read" back onto it
+    hipEvent_t peer_ready = nullptr, peer_done = nullptr;
     // side streams for calls that let the group's shards work side by side (small 1-mismatch batches: one shard's
     // launch does not fill the GPU), forked from and joined to the caller's stream with events; made on first use
     static constexpr int FORK = 8;
@@ -148,11 +153,12 @@ int make_groups(rsbwt_set_t *s) {
         if (!h) return fail(RSBWT_EINVAL, "null shard handle");
         dev_group *g = nullptr;
         for (dev_group *x : s->groups)
-            if (x->device == h->device) g = x;
+            if (x->logical == h->logical_device) g = x;
         if (!g) {
             g = new (std::nothrow) dev_group();
             if (!g) return fail(RSBWT_ENOMEM, "host allocation failed");
             g->device = h->device;
+            g->logical = h->logical_device;
             g->num_cus = h->num_cus;
             s->groups.push_back(g);
         }
@@ -178,12 +184,26 @@ bool ensure_comms(rsbwt_set_t *s) {
     s->comms_tried = true;
     if (s->groups.size() < 2 || !rccl().ok) return false;
     std::vector<int> devs;
-    for (dev_group *g : s->groups) devs.push_back(g->device);
+    for (dev_group *g : s->groups) {
+        // two groups on one GPU (logical devices of the test hook, capi.hip resolve_device): RCCL refuses two ranks
+        // on one device, and the set goes the way a box without librccl goes
+        if (std::find(devs.begin(), devs.end(), g->device) != devs.end()) return false;
+        devs.push_back(g->device);
+    }
     std::vector<ncclComm_t> comms(devs.size());
     if (rccl().CommInitAll(comms.data(), (int)devs.size(), devs.data()) != ncclSuccess) return false;
     for (size_t i = 0; i < devs.size(); ++i) s->groups[i]->comm = comms[i];
     s->comms_ok = true;
     return true;
+}
+
+// search_extra::narrow for a fused launch over a group's shards: every one of them behind a k-mer table deep enough
+// that what is left of a search are steps inside one window (capi_internal.h, view_is_narrow) -- the launch then runs
+// one lane per search (search_solo.h)
+bool group_is_narrow(const rsbwt_set_t *s, const dev_group *g, uint32_t k) {
+    for (size_t i : g->idx)
+        if (!view_is_narrow(s->shards[i]->view, k)) return false;
+    return !g->idx.empty();
 }
 
 // runs fn(group index) for every device group, concurrently when there are several
@@ -228,6 +248,8 @@ void rsbwt_set_close(rsbwt_set_t *s) {
             if (g->join_ev[i]) (void)hipEventDestroy(g->join_ev[i]);
         }
         if (g->fork_ev) (void)hipEventDestroy(g->fork_ev);
+        if (g->peer_ready) (void)hipEventDestroy(g->peer_ready);
+        if (g->peer_done) (void)hipEventDestroy(g->peer_done);
         if (g->d_views) (void)hipFree(g->d_views);
         if (g->d_work) (void)hipFree(g->d_work);
         g->scratch.destroy();
@@ -408,9 +430,10 @@ static int rsbwt_set_find_intervals_body(rsbwt_set_t *s, const char *kmers, size
         const bool contiguous = g->idx.back() - g->idx.front() + 1 == Sg;
         if (contiguous)
             return search_host_views(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, kmers, Q, k, stride,
-                                     lower + g->idx.front() * Q, upper + g->idx.front() * Q, false);
+                                     lower + g->idx.front() * Q, upper + g->idx.front() * Q, false, group_is_narrow(s, g, k));
         std::vector<uint64_t> lo(Sg * Q), up(Sg * Q);
-        rc = search_host_views(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, kmers, Q, k, stride, lo.data(), up.data(), false);
+        rc = search_host_views(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, kmers, Q, k, stride, lo.data(), up.data(), false,
+                               group_is_narrow(s, g, k));
         if (rc) return rc;
         for (size_t j = 0; j < Sg; ++j) {
             memcpy(lower + g->idx[j] * Q, lo.data() + j * Q, Q * 8);
@@ -468,7 +491,9 @@ static int rsbwt_set_count_body(rsbwt_set_t *s, const char *kmers, size_t Q, uin
             HIP_OK(hipMemcpyAsync(d_ascii, kmers + q0 * stride, ascii_bytes, hipMemcpyHostToDevice, st));
             hipError_t e = launch_pack(d_ascii, m, k, stride, d_pk, d_ok, st);
             if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
-            r = search_launch(*g, g->d_views, (uint32_t)Sg, g->num_cus, d_pk, d_ok, m, k, d_cnt, nullptr, true, st, nullptr);
+            search_extra ex;
+            ex.narrow = group_is_narrow(s, g, k);
+            r = search_launch(*g, g->d_views, (uint32_t)Sg, g->num_cus, d_pk, d_ok, m, k, d_cnt, nullptr, true, st, &ex);
             if (r) return r;
             hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_cnt, (uint32_t)Sg, m, d_sum[gi]);
             HIP_OK(hipGetLastError());
@@ -531,7 +556,7 @@ int rsbwt_set_find_intervals_dev(rsbwt_set_t *s, const void *d_packed, const voi
     int rc = use_device(g->device);
     if (rc) return rc;
     search_extra ex;
-    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
+    ex.narrow = group_is_narrow(s, g, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_lower, d_upper,
                          false, (hipStream_t)stream, &ex);
 }
@@ -545,7 +570,7 @@ int rsbwt_set_find_interval_pairs_dev(rsbwt_set_t *s, const void *d_packed, cons
     if (rc) return rc;
     search_extra ex;
     ex.pairs = true;
-    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
+    ex.narrow = group_is_narrow(s, g, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_pairs, nullptr,
                          false, (hipStream_t)stream, &ex);
 }
@@ -581,7 +606,7 @@ int rsbwt_set_find_interval_pairs_prepared_dev(rsbwt_set_t *s, const void *d_pac
     search_extra ex;
     ex.pairs = true;
     ex.d_init = d_records;
-    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
+    ex.narrow = group_is_narrow(s, g, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_pairs, nullptr,
                          false, (hipStream_t)stream, &ex);
 }
@@ -594,7 +619,7 @@ int rsbwt_set_count_dev(rsbwt_set_t *s, const void *d_packed, const void *d_vali
     int rc = use_device(g->device);
     if (rc) return rc;
     search_extra ex;
-    ex.narrow = g->idx.size() == 1 && view_is_narrow(s->shards[g->idx[0]]->view, k);
+    ex.narrow = group_is_narrow(s, g, k);
     return search_launch(*g, g->d_views, (uint32_t)g->idx.size(), g->num_cus, d_packed, d_valid, Q, k, d_counts, nullptr,
                          true, (hipStream_t)stream, &ex);
 }
@@ -734,9 +759,35 @@ static int rsbwt_set_gather_intervals_dev_body(rsbwt_set_t *s, const void *const
     (void)hipSetDevice(s->groups[0]->device);
     HIP_OK(hipMemcpyAsync(d_root, d_blocks[0], bytes[0], hipMemcpyDeviceToDevice, (hipStream_t)streams[0]));
     if (G == 1) return RSBWT_OK;
-    if (!ensure_comms(s)) return fail(RSBWT_ENODEV, "RCCL is not available: cannot gather across devices");
     size_t off = bytes[0];
     std::lock_guard<std::mutex> comm_lock(s->comm_mu);
+    if (!ensure_comms(s)) {
+        // No RCCL (no librccl on the box, or groups that share a GPU): the root PULLS every block with a peer copy
+        // on its own stream, behind an event the block's stream records ("ready"), and tells that stream when the
+        // block has been read ("done") -- the stream order ncclSend / ncclRecv would have given.  xGMI peer copies
+        // by the copy engines; slower to start than one grouped RCCL call, the same bytes over the same links.
+        static const bool quiet = getenv("RSBWT_QUIET") != nullptr;
+        static bool said = false;
+        if (!said && !quiet) {
+            said = true;
+            fprintf(stderr, "rsbwt: interval gather over peer copies (%s)\n", rccl().ok ? "device groups share a GPU" : "librccl not found");
+        }
+        for (size_t g = 1; g < G; ++g) {
+            dev_group *grp = s->groups[g];
+            (void)hipSetDevice(grp->device);
+            if (!grp->peer_ready) HIP_OK(hipEventCreateWithFlags(&grp->peer_ready, hipEventDisableTiming));
+            if (!grp->peer_done) HIP_OK(hipEventCreateWithFlags(&grp->peer_done, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(grp->peer_ready, (hipStream_t)streams[g]));
+            (void)hipSetDevice(s->groups[0]->device);
+            HIP_OK(hipStreamWaitEvent((hipStream_t)streams[0], grp->peer_ready, 0));
+            HIP_OK(hipMemcpyPeerAsync((uint8_t *)d_root + off, s->groups[0]->device, d_blocks[g], grp->device, bytes[g], (hipStream_t)streams[0]));
+            HIP_OK(hipEventRecord(grp->peer_done, (hipStream_t)streams[0]));
+            (void)hipSetDevice(grp->device);
+            HIP_OK(hipStreamWaitEvent((hipStream_t)streams[g], grp->peer_done, 0));
+            off += bytes[g];
+        }
+        return RSBWT_OK;
+    }
     ncclResult_t nr = rccl().GroupStart();
     for (size_t g = 1; g < G && nr == ncclSuccess; ++g) {
         (void)hipSetDevice(s->groups[g]->device);

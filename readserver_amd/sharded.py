@@ -54,6 +54,62 @@ def broadcast_queries(kmers, src=0, group=None):
     return kmers
 
 
+def hbm_plan(world, rank, s_local, q, k, lines_bytes, run_bytes, *, wire_packed=True, depth=2, out_depth=None, separate=False,
+             ktab_bytes_per_shard=0, reserve=8 << 30, dst=0):
+    """What one rank of bench.py's exact search holds in HBM, item by item, BEFORE anything is allocated -- so that a
+    job that cannot fit says so at start-up, with the table, instead of running out of memory between two shards or
+    in the middle of the first gather (VERDICT r04 next #1c).  Pure arithmetic: no torch, no GPU.
+
+    world / rank: the job's size and this rank (rank `dst` also holds the gathered blocks of every rank);
+    s_local: shards per GPU; q: k-mers per batch; lines_bytes: bytes of ONE shard's window lines (estimate before the
+    build: ~1.64 x run bytes for the plain layout, ~1.73 for RSBWT_OPEN_READS; exact afterwards: rsbwt_hbm_bytes);
+    run_bytes: run bytes of one shard (the builder holds them, and ~9 % of them in prefix arrays, next to the lines it
+    writes); ktab_bytes_per_shard: 0 = not chosen yet.  Returns a dict of byte counts:
+      shards, build_peak (the last shard's build: S - 1 shards resident + its run bytes + prefix arrays + its lines),
+      batch (ASCII k-mers, packed words, validity bytes, `depth` result buffers), wire (`depth` 10-byte-record
+      buffers, N > 1), gathered (rank dst: out_depth x world blocks), scratch (the start records and pools of the launch
+      in flight), tables, reserve (left free: verification transients after the timed region, the runtime's own),
+      steady = everything but build_peak, need = max(steady, build_peak + batch ... ) -- see below."""
+    wpq = (k + 31) // 32
+    n_pairs = s_local * q
+    if out_depth is None:
+        out_depth = 2 if world <= 2 else 1  # (bench.py: from 4 ranks on rank 0 keeps ONE batch's gathered blocks)
+    packed = bool(wire_packed) and world > 1 and not separate
+    pair_bytes = n_pairs * 16
+    block = packed_pairs_bytes(n_pairs) if packed else pair_bytes
+    plan = {
+        "shards": s_local * int(lines_bytes),
+        "build_peak": (s_local - 1) * int(lines_bytes) + int(run_bytes) + int(run_bytes * 0.09) + int(lines_bytes),
+        "batch": q * k + q * 8 * wpq + q + depth * pair_bytes,
+        "wire": depth * block if packed else 0,
+        "gathered": out_depth * world * block if (world > 1 and rank == dst) else 0,
+        "scratch": pair_bytes + 256 * 8 * s_local,
+        "tables": s_local * int(ktab_bytes_per_shard),
+        "reserve": int(reserve),
+    }
+    plan["steady"] = sum(plan[x] for x in ("shards", "batch", "wire", "gathered", "scratch", "tables", "reserve"))
+    # the build happens before the batch buffers exist (bench.py builds the shards first), the tables after them
+    plan["need"] = max(plan["steady"], plan["build_peak"] + plan["reserve"])
+    plan["out_depth"], plan["world"], plan["rank"] = out_depth, world, rank
+    return plan
+
+
+def hbm_plan_text(plan):
+    gb = lambda b: f"{b / 1e9:8.2f} GB"
+    rows = [(x, plan[x]) for x in ("shards", "batch", "wire", "gathered", "scratch", "tables", "reserve")]
+    return ("\n".join(f"  {n:9s}{gb(b)}" for n, b in rows) + f"\n  {'steady':9s}{gb(plan['steady'])}   (last shard's build peaks at {plan['build_peak'] / 1e9:.2f} GB)")
+
+
+def check_hbm_plan(plan, free_bytes, what="HBM free on this device"):
+    """Raises MemoryError with the plan when `need` exceeds free_bytes (torch.cuda.mem_get_info()[0] at start-up,
+    before this rank has allocated anything)."""
+    if plan["need"] > free_bytes:
+        raise MemoryError(f"rank {plan['rank']} of {plan['world']}: the job needs {plan['need'] / 1e9:.2f} GB of HBM, {what}: "
+                          f"{free_bytes / 1e9:.2f} GB\n" + hbm_plan_text(plan) +
+                          "\n  (fewer or smaller shards per GPU, fewer queries per batch, or shallower k-mer tables)")
+    return plan
+
+
 _M40 = (1 << 40) - 1
 
 

@@ -114,3 +114,83 @@ def test_bench_picks_the_tables_the_hbm_left_over_allows():
     t = torch.arange(300, dtype=torch.int32).to(torch.uint8)
     assert bench.total(t) == int(t.to(torch.int64).sum()) and bench.total(torch.empty(0, dtype=torch.uint8)) == 0
     assert bench.total(torch.tensor([-1, 5, -1], dtype=torch.int32)) == 3
+
+
+def test_the_headline_line_is_out_before_the_second_leg_and_the_leg_lives_on_what_is_left(monkeypatch):
+    """VERDICT r04 next #1a.  Rank 0 of an N > 1 run prints its line BEFORE it starts the one-process leg and again with
+    the leg's record after it; the leg gets what is left of --total-budget (<= 540 s: the driver allows 600), never its
+    fixed 420 s; a leg that times out, fails, or is not worth starting leaves both lines valid."""
+    import json
+    import subprocess
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    a = b.parse()
+    assert a.total_budget <= 540.0
+    # the budget rule
+    assert b.cxx_leg_budget(a, 100.0) == (420.0, None)             # early: the leg's own cap
+    lim, why = b.cxx_leg_budget(a, 300.0)
+    assert lim == 540.0 - 300.0 - 20.0 and why is None            # a per-rank leg of 300 s leaves 220 s, not 420
+    lim, why = b.cxx_leg_budget(a, 460.0)
+    assert lim is None and "not started" in why                    # < 90 s: the shards alone take 25 s per GPU
+    head = {"metric": "m", "value": 1.0, "config": {"workload": "w"}}
+
+    def run(elapsed, runner):
+        printed, calls = [], []
+        monkeypatch.setattr(b, "T_START", 1000.0)
+        def wrapped(cmd, timeout):
+            calls.append((cmd, timeout, len(printed)))
+            return runner(cmd, timeout)
+        b.second_leg(a, json.loads(json.dumps(head)), emit=printed.append, runner=wrapped, clock=lambda: 1000.0 + elapsed)
+        return [json.loads(x) for x in printed], calls
+
+    class R:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+    # a leg that answers
+    lines, calls = run(120.0, lambda cmd, t: R(0, 'noise\n{"value": 7.0, "n_gpus": 8}\n'))
+    assert len(lines) == 2 and calls[0][2] == 1                     # one line was out when the child started
+    assert "pending" in lines[0]["config"]["cxx_host"] and lines[0]["value"] == 1.0
+    assert lines[1]["config"]["cxx_host"]["value"] == 7.0 and lines[1]["value"] == 1.0
+    assert calls[0][1] == 400.0 and calls[0][0][calls[0][0].index("--host") + 1] == "cxx"
+    # a leg that runs out of time: the exception is the record, both lines parse
+    def slow(cmd, t):
+        raise subprocess.TimeoutExpired(cmd, t)
+    lines, calls = run(330.0, slow)
+    assert len(lines) == 2 and "TimeoutExpired" in lines[1]["config"]["cxx_host"]["error"] and calls[0][1] == 190.0
+    # a leg that fails
+    lines, _ = run(50.0, lambda cmd, t: R(1, "", "hipErrorOutOfMemory"))
+    assert "hipErrorOutOfMemory" in lines[1]["config"]["cxx_host"]["error"]
+    # no time left: not started, said so
+    lines, calls = run(500.0, lambda cmd, t: R(0, "{}"))
+    assert not calls and "not started" in lines[1]["config"]["cxx_host"]["skipped"]
+
+
+def test_rank0_hbm_plan_at_2_4_8_gpus():
+    """VERDICT r04 next #1c: what a rank holds, item by item, as plain arithmetic (readserver_amd/sharded.py, hbm_plan) --
+    bench.py checks it against torch.cuda.mem_get_info before the first shard is built.  configs[2]'s load: 8 shards of
+    2e10 run bytes (32.7 GB of lines each), 1e7 31-mers per batch, grouped 15-mer tables (3.2 GB per shard)."""
+    from readserver_amd import sharded
+    lines, runs, q, tab = int(1.633 * 2e10), int(2e10), 10**7, 3 * 4**15
+    hbm = 309_220_868_096  # what an MI355X reports as total (288 GiB)
+    plans = {w: sharded.hbm_plan(w, 0, 8, q, 31, lines, runs, ktab_bytes_per_shard=tab) for w in (1, 2, 4, 8)}
+    for w, p in plans.items():
+        assert p["shards"] == 8 * lines and p["tables"] == 8 * tab
+        assert p["steady"] == sum(p[x] for x in ("shards", "batch", "wire", "gathered", "scratch", "tables", "reserve"))
+        assert p["batch"] == q * 31 + q * 8 + q + 2 * 8 * q * 16
+        sharded.check_hbm_plan(p, hbm - (1 << 30))  # fits, with the 8 GiB reserve inside the plan
+    assert plans[1]["wire"] == 0 and plans[1]["gathered"] == 0
+    blk = sharded.packed_pairs_bytes(8 * q)                         # a rank's batch as 10-byte records: 0.8 GB
+    assert plans[2]["gathered"] == 2 * 2 * blk and plans[4]["gathered"] == 4 * blk and plans[8]["gathered"] == 8 * blk
+    assert plans[8]["out_depth"] == 1 and plans[2]["out_depth"] == 2
+    # the other ranks gather nothing
+    assert sharded.hbm_plan(8, 3, 8, q, 31, lines, runs, ktab_bytes_per_shard=tab)["gathered"] == 0
+    # what does NOT fit says so, with the table: two batches' blocks on rank 0 of 8 (round 4's first layout), unpacked pairs
+    big = sharded.hbm_plan(8, 0, 8, q, 31, lines, runs, ktab_bytes_per_shard=tab, out_depth=2, wire_packed=False)
+    with pytest.raises(MemoryError) as e:
+        sharded.check_hbm_plan(big, hbm - (1 << 30))
+    msg = str(e.value)
+    assert "rank 0 of 8" in msg and "gathered" in msg and "tables" in msg and "GB" in msg
+    # ... and the same job with plain 14-mer tables does (what pick_tables falls back to)
+    sharded.check_hbm_plan(sharded.hbm_plan(8, 0, 8, q, 31, lines, runs, ktab_bytes_per_shard=8 * 4**14, out_depth=2), hbm - (1 << 30))
+    # the last shard's build (its run bytes and prefix arrays beside the lines it writes) is the peak before the tables exist
+    assert plans[1]["build_peak"] == 7 * lines + runs + int(runs * 0.09) + lines

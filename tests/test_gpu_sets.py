@@ -234,16 +234,32 @@ def test_gpu_select_across_stretches_without_the_symbol(rsb, oracle):
             assert checked > 500
 
 
-def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path):
+@pytest.fixture
+def two_devices(rsb, monkeypatch):
+    """Two device numbers a set will treat as two devices: GPUs 0 and 1 where the box has them, else the library's
+    test hook (include/rsbwt.h, rsbwt_logical_device: RSBWT_TEST_DEVICE_ALIASES=2 makes 0 and 1 two LOGICAL devices on
+    GPU 0), so that the several-device host code of csrc/sets.hip -- a thread, a context pool and a fused launch per
+    device group, the merge of the groups' results, the gather onto the first group's device -- runs under -m gpu on
+    the one-GPU boxes this repo is tested on.  What the alias cannot reach is RCCL itself (two ranks on one GPU are
+    refused): the set then sums on the host and gathers with peer copies, as it does on a box without librccl."""
+    L = rsb.lib()
+    aliased = L.rsbwt_device_count() < 2
+    if aliased:
+        monkeypatch.setenv("RSBWT_ENABLE_TEST_HOOKS", "1")
+        monkeypatch.setenv("RSBWT_TEST_DEVICE_ALIASES", "2")
+    return aliased
+
+
+def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path, two_devices):
     """The cross-device paths of csrc/sets.hip: the same four shards as a set on ONE device and as a
     set split over devices 0 and 1 must give the same intervals, the same summed counts (ncclReduce over the
-    per-device communicators), the same gathered blocks (ncclSend / ncclRecv onto the first device), hit lists,
-    reads and query lists.  Needs two GPUs: skipped on the one-GPU boxes this repo has been developed on -- no
-    RCCL collective of this library has run anywhere yet, and this is the test that will say when one has."""
+    per-device communicators where there are two GPUs and librccl; the host-side sum otherwise), the same gathered
+    blocks (ncclSend / ncclRecv onto the first device; peer copies otherwise), hit lists, reads and query lists.  On a
+    one-GPU box the two devices are two logical devices on GPU 0 (`two_devices`): every line of the several-group host
+    code runs, RCCL does not."""
     import torch
     L = rsb.lib()
-    if L.rsbwt_device_count() < 2:
-        pytest.skip("one GPU: the cross-device paths need two")
+    aliased = two_devices
     kw = dict(seed=41, genome_len=20000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=3.0)
     paths = []
     for s in range(4):
@@ -257,44 +273,80 @@ def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path)
     kmers = _kmers_from(reads, rng, 3000, 31, mutate=0.3)
     one = [rsb.GpuBWT(p_, device=0) for p_ in paths]
     two = [rsb.GpuBWT(p_, device=(0 if s < 2 else 1)) for s, p_ in enumerate(paths)]
+    assert [L.rsbwt_logical_device(g.handle) for g in two] == [0, 0, 1, 1]
+    assert [L.rsbwt_device(g.handle) for g in two] == ([0, 0, 0, 0] if aliased else [0, 0, 1, 1])
     s1, s2 = rsb.ShardSet(one), rsb.ShardSet(two)
     assert L.rsbwt_set_devices(s1._s) == 1 and L.rsbwt_set_devices(s2._s) == 2
+    # a set whose groups interleave in shard order (0, 1, 0, 1): the per-group blocks are scattered back by shard
+    mixed = [rsb.GpuBWT(p_, device=s % 2) for s, p_ in enumerate(paths)]
+    s3 = rsb.ShardSet(mixed)
+    assert L.rsbwt_set_devices(s3._s) == 2
     lo1, up1 = s1.find_intervals(kmers)
     lo2, up2 = s2.find_intervals(kmers)
     assert np.array_equal(lo1, lo2) and np.array_equal(up1, up2)
-    assert np.array_equal(s1.count(kmers), s2.count(kmers))  # the RCCL reduce when librccl is there
+    lo3, up3 = s3.find_intervals(kmers)
+    assert np.array_equal(lo1, lo3) and np.array_equal(up1, up3)
+    # shard 0 against the oracle, so that "equal" is not "equally wrong"
+    elo, eup = oracle.load(paths[0]).find_intervals(np.frombuffer("".join(kmers).encode(), np.uint8).reshape(len(kmers), 31))
+    assert np.array_equal(lo2[0], elo) and np.array_equal(up2[0], eup)
+    c1 = s1.count(kmers)
+    assert np.array_equal(c1, s2.count(kmers))  # the RCCL reduce where there are two GPUs and librccl, else the host's sum
+    assert np.array_equal(c1, s3.count(kmers))
+    assert np.array_equal(c1, np.where(up1 >= lo1, up1 - lo1 + 1, 0).sum(axis=0).astype(np.uint64))
     h1, f1 = s1.hits_1mm(kmers[:300])
-    h2, f2 = s2.hits_1mm(kmers[:300])
-    assert np.array_equal(h1, h2) and np.array_equal(f1, f2)
-    assert s1.query(kmers[:200], read_stride=96) == s2.query(kmers[:200], read_stride=96)
+    for sx in (s2, s3):
+        h2, f2 = sx.hits_1mm(kmers[:300])
+        assert np.array_equal(h1, h2) and np.array_equal(f1, f2)
+    q1 = s1.query(kmers[:200], read_stride=96)
+    assert q1 == s2.query(kmers[:200], read_stride=96) and q1 == s3.query(kmers[:200], read_stride=96)
     sh = rng.integers(0, 4, 2000).astype(np.uint32)
     rows = np.array([rng.integers(0, one[s].getBWLen()) for s in sh], dtype=np.uint64)
-    assert s1.extract(sh, rows, stride=96)[0] == s2.extract(sh, rows, stride=96)[0]
-    if L.rsbwt_rccl_available():
+    e1 = s1.extract(sh, rows, stride=96)[0]
+    assert e1 == s2.extract(sh, rows, stride=96)[0] and e1 == s3.extract(sh, rows, stride=96)[0]
+    # concurrent callers of the spanning set: its per-group threads and context pools under load
+    import threading
+    errs = []
+    def caller(i):
+        try:
+            for _ in range(3):
+                lo_, up_ = s2.find_intervals(kmers[i::4])
+                assert np.array_equal(lo_, lo1[:, i::4]) and np.array_equal(up_, up1[:, i::4])
+                assert np.array_equal(s3.count(kmers[i::4]), c1[i::4])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+    th = [threading.Thread(target=caller, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    if aliased or L.rsbwt_rccl_available():
         # per-device interval blocks gathered onto device 0: [2][Q] x {lower, upper} from each device
         Q = len(kmers)
         blocks, streams, nbytes = [], [], []
         a = np.frombuffer("".join(kmers).encode(), np.uint8).reshape(Q, 31)
-        for dv, ss in ((0, [0, 1]), (1, [2, 3])):
+        for dv, ss in ((0, [0, 1]), (0 if aliased else 1, [2, 3])):
             torch.cuda.set_device(dv)
             pr = torch.empty((2, Q, 2), dtype=torch.int64, device=f"cuda:{dv}")
             pr[..., 0] = torch.from_numpy(lo2[ss].astype(np.int64)).to(pr.device)
             pr[..., 1] = torch.from_numpy(up2[ss].astype(np.int64)).to(pr.device)
             blocks.append(pr)
             nbytes.append(pr.numel() * 8)
-            streams.append(torch.cuda.current_stream(dv).cuda_stream)
+            streams.append(torch.cuda.Stream(device=dv))
         torch.cuda.set_device(0)
         root = torch.zeros((4, Q, 2), dtype=torch.int64, device="cuda:0")
+        streams_keep = streams  # (streams of their own: what was filled on the devices' current streams is waited for)
+        for st_, b_ in zip(streams, blocks):
+            st_.wait_stream(torch.cuda.current_stream(b_.device))
+        streams = [st_.cuda_stream for st_ in streams_keep]
         bp = (C.c_void_p * 2)(*[b.data_ptr() for b in blocks])
         nb = (C.c_size_t * 2)(*nbytes)
         st = (C.c_void_p * 2)(*streams)
         assert L.rsbwt_set_gather_intervals_dev(s2._s, bp, nb, C.c_void_p(root.data_ptr()), st) == 0, L.rsbwt_last_error()
-        for dv in (0, 1):
+        for dv in ((0,) if aliased else (0, 1)):
             torch.cuda.synchronize(dv)
         got = root.cpu().numpy().view(np.uint64)
         assert np.array_equal(got[..., 0], lo2) and np.array_equal(got[..., 1], up2)
-    s1.close(); s2.close()
-    for g in one + two:
+    s1.close(); s2.close(); s3.close()
+    for g in one + two + mixed:
         g.close()
 
 
@@ -581,17 +633,19 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
 
 
 @pytest.mark.parametrize("devices", [1, 2])
-def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices):
+def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices, monkeypatch):
     """readserver_amd/onehost.py -- the C++ host's shape, what `bench.py --host cxx` times: per device pack + ONE fused
     launch over its shards + 10-byte records on a stream of its own, the records gathered onto the first device by
     rsbwt_set_gather_intervals_dev (ncclSend / ncclRecv) on a second stream, double-buffered.  Every device's pairs
-    against the oracle; with two devices the root's blocks against what the devices searched (skipped on a one-GPU box:
-    RCCL needs distinct devices)."""
+    against the oracle; with two devices the root's blocks against what the devices searched.  On a one-GPU box the two
+    devices are two LOGICAL devices on GPU 0 (include/rsbwt.h, rsbwt_logical_device): the host's whole sequence runs --
+    two groups, two stream pairs, double-buffered records -- and the gather goes over peer copies instead of RCCL."""
     import torch
     from readserver_amd import onehost
-    if torch.cuda.device_count() < devices:
-        pytest.skip(f"{devices} GPUs needed")
     L = rsb.lib()
+    if torch.cuda.device_count() < devices:
+        monkeypatch.setenv("RSBWT_ENABLE_TEST_HOOKS", "1")
+        monkeypatch.setenv("RSBWT_TEST_DEVICE_ALIASES", str(devices))
     rng = np.random.default_rng(11)
     Q, k = 30000, 31
     by_dev, oixs = [], []
@@ -608,7 +662,7 @@ def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices):
     host.attach_tables(6)
     km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (Q, k))].copy()
     km[::3, :20] = km[0, :20]  # (some shared prefixes)
-    d_km = [torch.from_numpy(km).to(torch.device("cuda", d)) for d in range(devices)]
+    d_km = [torch.from_numpy(km).to(torch.device("cuda", host.devices[d])) for d in range(devices)]
     for _ in range(5):  # (past the double buffers)
         host.step(d_km)
     host.synchronize()
