@@ -437,6 +437,12 @@ int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t reque
 int rsbwt_proto_decode_request(const uint8_t *msg, size_t len, int *t, int *rt, const char **q, size_t *qlen);
 size_t rsbwt_proto_encode_count_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen,
                                       int revcomp, int32_t c);
+/* Reply{rt = request_type, t = ReplyReads, q, r = ReplyReads{forward_matches | revcomp_matches = ResultReads{r}}*}
+ * (src/service/readserver.proto:35-37,39-49,61-64): what QueryTask::run sends for a Request whose return type is
+ * Reads (src/service/service.cpp:1260-1291).  `r` is present even with no read (mutable_r(), :1278).  Returns the
+ * bytes needed (written when out != NULL and they fit cap); 0 = bad arguments. */
+size_t rsbwt_proto_encode_reads_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen, int revcomp,
+                                      const char *const *reads, const size_t *read_len, size_t nreads);
 
 /* The service's configuration file: the libconfig subset the reference's service.cfg uses
  * (`key = "value";`, `key = [ "a", ... ];`, comments; demo/TEMPLATE.service.cfg).  Loading fails with
@@ -477,12 +483,34 @@ void rsbwt_transport_close(rsbwt_transport_t *t); /* the loop ends once what was
  * arrival order, forward strand then reverse complement, CountReads on push_count and ExactMatch on
  * push.  per_partition = 1: two replies per request PER SHARD, each what a reference service holding
  * that partition sends (front-end `workers` = 2 x shards); 0: two replies with the counts summed
- * (`workers` = 2).  Requests of other types go to the handler (may be NULL). */
+ * (`workers` = 2).  ExactMatch requests that ask for Reads are answered too (rsbwt_service_set_reads).  Requests of
+ * other types go to the handler (may be NULL), which is called on the loop's SENDER thread, not on the thread that
+ * called rsbwt_service_run; an exception it throws is caught there and becomes the run's error. */
 typedef struct rsbwt_service rsbwt_service_t;
 typedef void (*rsbwt_service_other_fn)(void *arg, const uint8_t *request, size_t len);
 int rsbwt_service_create(rsbwt_set_t *set, rsbwt_transport_t *t, int64_t window_us, size_t max_batch,
                          int per_partition, rsbwt_service_t **out);
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg);
+/* ExactMatch requests whose return type is Reads (`GET /get?output=reads`: the front-end's count pre-flight is
+ * followed by this request, and it waits for `workers` replies without a timeout, src/service/server.cpp:469,565-601).
+ * The loop answers them itself (default on): find_reads (src/service/service.cpp:714-797) batched over the set --
+ * a query shorter than min_read_length: the reads of every row of its interval (in find_reads' order: the tail of an
+ * interval wider than 4,097 rows first, then its 2,048-row chunks, :724-751); up to max_read_length: the
+ * min_read_length-long tiles of the query that are themselves reads (query_exactmatch, src/bwt/query.cpp:102-120), then
+ * every read that contains it (query, :87-100); longer: its max_read_length-long tiles that are reads, then the
+ * min_read_length-long ones -- and sends, per partition (or once, summed mode) and strand,
+ * Reply{rt = ExactMatch, t = ReplyReads, q, r} on `push` (QueryTask::run, service.cpp:1260-1291), forward strand
+ * first.  min / max_read_length: service.cfg's keys (service.cpp:1417-1420; 0 = keep: 73 / 100, :56-57).
+ * Tiles are visited in the order of the reference's container (std::unordered_set<std::string>, filled the same
+ * way): the same order on the same C++ standard library.  A query holding a symbol outside ACGT matches nothing
+ * (find_reads' short-query branch would search it as it stands; count_reads, the pre-flight, answers 0 for it).
+ * The return type All needs the RocksDB shards: still the `other` handler's.  enable = 0: Reads requests go to the
+ * `other` handler too, as before round 5. */
+void rsbwt_service_set_reads(rsbwt_service_t *s, int enable, uint32_t min_read_length, uint32_t max_read_length);
+/* service.cfg's `suffix` of every shard of the set (demo/TEMPLATE.service.cfg:16-17), n = rsbwt_set_size (0: none):
+ * a tile is looked up only in the partitions whose suffix it ends with (is_suffix_of, service.cpp:228-230,759). */
+int rsbwt_service_set_suffixes(rsbwt_service_t *s, const char *const *suffix, size_t n);
+uint64_t rsbwt_service_read_requests(const rsbwt_service_t *s); /* Reads requests answered so far */
 /* The loop is a pipeline: the thread that runs it receives and cuts the windows, `workers` threads answer a whole
  * window each (decode, one batched search per query length, Reply bytes -- the set's entry points are re-entrant),
  * a sender thread sends the windows' Replies in window order, so replies still leave in arrival order.  Default 8,

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "query.h"
@@ -89,6 +90,27 @@ size_t ref_query(void *h, const char *w, size_t len, char *out, size_t cap, size
         need += s.size() + 1;
     }
     if (count) *count = seqs.size();
+    return need;
+}
+
+// The order in which a std::unordered_set<std::string> filled with the kmer-long substrings of w, position by position
+// (what get_tiles does, src/service/service.cpp:232-246 with skip = 0), is ITERATED on this C++ standard library: the
+// order find_reads visits its tiles in (service.cpp:758-764).  No reference code: the container is the library's.
+// Tiles '\n'-terminated into out; returns the bytes needed, *count = number of distinct tiles.
+size_t ref_tiles_order(const char *w, size_t len, size_t kmer, char *out, size_t cap, size_t *count) {
+    std::unordered_set<std::string> vs;
+    const std::string s(w, len);
+    if (kmer != 0 && len >= kmer)
+        for (size_t i = 0; i <= len - kmer; ++i) vs.insert(s.substr(i, kmer));
+    size_t need = 0;
+    for (const std::string &t : vs) {
+        if (need + t.size() + 1 <= cap) {
+            memcpy(out + need, t.data(), t.size());
+            out[need + t.size()] = '\n';
+        }
+        need += t.size() + 1;
+    }
+    if (count) *count = vs.size();
     return need;
 }
 

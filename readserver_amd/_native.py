@@ -130,6 +130,9 @@ SIGNATURES = {
     "rsbwt_transport_push_requests": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "rsbwt_transport_pop_replies": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int64]),
     "rsbwt_service_set_other_handler": (None, [_vp, _vp, _vp]),
+    "rsbwt_service_set_reads": (None, [_vp, C.c_int, C.c_uint32, C.c_uint32]),
+    "rsbwt_service_set_suffixes": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.c_size_t]),
+    "rsbwt_service_read_requests": (C.c_uint64, [_vp]),
     "rsbwt_service_run": (C.c_int, [_vp]),
     "rsbwt_service_start": (C.c_int, [_vp]),
     "rsbwt_service_stop": (C.c_int, [_vp]),
@@ -138,6 +141,8 @@ SIGNATURES = {
     "rsbwt_proto_decode_request": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                              C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
     "rsbwt_proto_encode_count_reply": (C.c_size_t, [_vp, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int32]),
+    "rsbwt_proto_encode_reads_reply": (C.c_size_t, [_vp, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
+                                                    C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]),
     "rsbwt_set_open": (C.c_int, [C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
     "rsbwt_set_from_handles": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.POINTER(_vp)]),
     "rsbwt_set_close": (None, [_vp]),

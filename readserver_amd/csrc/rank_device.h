@@ -54,6 +54,59 @@ __device__ __forceinline__ uint32_t runs_scan(const uint32_t *r, uint32_t b, uin
     return acc;
 }
 
+// ---- the search kernels' rank since round 5: dword by dword, not run by run.
+// The search launches are bound by the instructions a SIMD issues (a wave of the headline launch
+// issued ~600 instructions per pass, 400 of them VALU, at 4 waves per SIMD; + 12.6 % VALU cost + 5.7 % time), and the
+// run-by-run scan above was 120 of them per lookup.  Here the 24 pieces' dword totals -- all symbols, and symbol b's --
+// come from two v_dot4 each; the 0/1 match mask of a dword is ONE v_perm_b32: the pieces' symbols (0..4, three bits)
+// are the byte selectors into an 8-byte table that holds 1 at byte b, so no compare, subtract or shift of a mask is
+// needed (3 instructions per dword where dword_matched's mask takes 5); the dword holding the position is picked by
+// five compare-and-selects on the running totals, and only ITS four pieces are scanned run by run: 76 VALU
+// instructions per lookup, 30 for the whole-quarter sum an odd quarter needs.
+
+// v_perm_b32 table of symbol b (1..4): byte s of {hi, lo} is 1 where s == b, 0 elsewhere (s = 0..7 selects it)
+struct sym_tab {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ sym_tab make_sym_tab(uint32_t b) {
+    const uint64_t t = 1ull << (8u * b);
+    sym_tab o;
+    o.lo = (uint32_t)t;
+    o.hi = (uint32_t)(t >> 32);
+    return o;
+}
+// 0/1 per piece of the dword: its symbol is the table's
+__device__ __forceinline__ uint32_t match01(uint32_t x, const sym_tab &t) {
+    return __builtin_amdgcn_perm(t.hi, t.lo, (x >> 5) & 0x07070707u);
+}
+// what 24 pieces hold of the table's symbol
+__device__ __forceinline__ uint32_t matched24_tab(const uint32_t e[6], const sym_tab &t) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m = __builtin_amdgcn_udot4(e[i] & 0x1F1F1F1Fu, match01(e[i], t), m, false);
+    return m;
+}
+// RLEBWT::getOcc's bucket scan (src/bwt/rlebwt.cpp:281-298) over 24 pieces: how many of their first `rem` symbols are
+// b (t = make_sym_tab(b)); rem = 0 gives 0, rem beyond what the pieces hold gives all they hold of b
+__device__ __forceinline__ uint32_t rank24(const uint32_t r[6], const sym_tab &t, uint32_t b, uint32_t rem) {
+    uint32_t cum = 0, mat = 0, x = r[0], base = 0, mb = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (i) {  // the position lies past dwords 0..i-1: dword i is the candidate
+            const bool past = rem > cum;
+            x = past ? r[i] : x;
+            base = past ? cum : base;
+            mb = past ? mat : mb;
+        }
+        if (i < 5) {
+            const uint32_t l = r[i] & 0x1F1F1F1Fu;
+            cum = __builtin_amdgcn_udot4(l, 0x01010101u, cum, false);
+            mat = __builtin_amdgcn_udot4(l, match01(r[i], t), mat, false);
+        }
+    }
+    return mb + runs_scan<1>(&x, b, rem - base);
+}
+
 // ---- whole-dword forms for the walk kernels (extract_lines.hip), where a lane has to find out WHICH
 // symbol sits at a position before it can rank it.  24 pieces = 6 dwords: dword totals come from
 // v_dot4, the dword holding the position from five compares, and only that dword's four pieces are

@@ -405,6 +405,7 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
             const lds_u32 *mine0 = shared_row ? own_row - 4 * 32 : own_row;  // row of lane - 32
 
             // ---- Occ(b, p) out of this lane's staged line.  RLEBWT::getOcc, src/bwt/rlebwt.cpp:268-301.
+            const sym_tab stab = make_sym_tab(b);  // v_perm_b32 table of the symbol (rank_device.h)
             bool do_scan = false;
             uint64_t base = 0;
             uint32_t dw = HDR_DWORDS, rem = 0;
@@ -431,13 +432,10 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                         const uint2 x0 = *reinterpret_cast<const lds_u2 *>(MINE(qd));
                         const uint2 x1 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 2u));
                         const uint2 x2 = *reinterpret_cast<const lds_u2 *>(MINE(qd + 4u));
-                        const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte (v_perm_b32: byte 0 four times)
-                        uint32_t m = dword_matched(x0.x, bb, 0u);
-                        m = dword_matched(x0.y, bb, m);
-                        m = dword_matched(x1.x, bb, m);
-                        m = dword_matched(x1.y, bb, m);
-                        m = dword_matched(x2.x, bb, m);
-                        m = dword_matched(x2.y, bb, m);
+                        const uint32_t e6[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+                        const uint32_t m = matched24_tab(e6, stab);
+                        const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // (the timing experiment below)
+                        (void)bb;
 #ifdef RSB_EXPERIMENT_EXTRA_DOT4  // timing experiment (answers unchanged): the quarter sum done twice
                         {
                             uint32_t m2 = dword_matched(x0.x ^ 1u, bb, 1u);
@@ -484,14 +482,14 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                 // every wave drains
                 if (!do_scan && ++tries > 72u) do_scan = true;
             }
-            // the scan of the (at most) 24 pieces at dword dw, run by run (rlebwt.cpp:281-298);
-            // lanes with nothing to scan take part with rem = 0
+            // the rank within the (at most) 24 pieces at dword dw (rlebwt.cpp:281-298; rank_device.h, rank24: dword totals
+            // by v_dot4, the dword holding the position run by run); lanes with nothing to scan take part with rem = 0
             {
                 const uint2 y0 = *reinterpret_cast<const lds_u2 *>(MINE(dw & 31u));
                 const uint2 y1 = *reinterpret_cast<const lds_u2 *>(MINE((dw + 2u) & 31u));
                 const uint2 y2 = *reinterpret_cast<const lds_u2 *>(MINE((dw + 4u) & 31u));
                 const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
-                const uint32_t sc = runs_scan<6>(r6, b, rem);
+                const uint32_t sc = rank24(r6, stab, b, rem);
 #ifdef RSB_EXPERIMENT_EXTRA_SCAN2  // timing experiment (answers unchanged): 8 more pieces scanned
                 {
                     const uint32_t sc2 = runs_scan<2>(r6 + 2, b, rem + 1u);

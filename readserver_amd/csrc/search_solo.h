@@ -355,7 +355,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
             uint64_t base = 0, cnt_b = 0;
             uint32_t dw = HDR_DWORDS, rem = 0, oe_here = 0;
             uint32_t s1 = 0, s2 = 0, s3 = 0, span = 0, hb = 0;
-            const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte
+            const sym_tab stab = make_sym_tab(b);  // v_perm_b32 table of the symbol (rank_device.h)
             if (looking) {
                 if (cont != KIND_CHUNK) {
                     const uint32_t oe = cont ? co : o;
@@ -377,12 +377,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         const uint2 x0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd));
                         const uint2 x1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 2u));
                         const uint2 x2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 4u));
-                        uint32_t m = dword_matched(x0.x, bb, 0u);
-                        m = dword_matched(x0.y, bb, m);
-                        m = dword_matched(x1.x, bb, m);
-                        m = dword_matched(x1.y, bb, m);
-                        m = dword_matched(x2.x, bb, m);
-                        m = dword_matched(x2.y, bb, m);
+                        const uint32_t e6[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+                        const uint32_t m = matched24_tab(e6, stab);
                         base = cnt + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
                         dw = HDR_DWORDS + 6u * cq;
                         rem = oe - start;
@@ -426,7 +422,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 const uint2 y1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE((dw + 2u) & 31u));
                 const uint2 y2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE((dw + 4u) & 31u));
                 const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
-                occ = base + runs_scan<6>(r6, b, rem);
+                occ = base + rank24(r6, stab, b, rem);
 #ifdef RSB_FAULT_INJECT_WILD_OCC  // fault-injection build (search_lines.hip): wild counts, answers WRONG by design
                 if ((((uint32_t)q + (uint32_t)j) * 2654435761u >> 28) == 0u)
                     occ = (occ + (((uint64_t)q * 0x9E3779B97F4A7C15ull) >> (23u + (((uint32_t)q + (uint32_t)j) & 31u)))) & ((1ull << 41) - 1ull);
@@ -473,18 +469,14 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 const uint2 x0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd));
                 const uint2 x1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 2u));
                 const uint2 x2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(qd + 4u));
-                uint32_t m = dword_matched(x0.x, bb, 0u);
-                m = dword_matched(x0.y, bb, m);
-                m = dword_matched(x1.x, bb, m);
-                m = dword_matched(x1.y, bb, m);
-                m = dword_matched(x2.x, bb, m);
-                m = dword_matched(x2.y, bb, m);
+                const uint32_t e6[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+                const uint32_t m = matched24_tab(e6, stab);
                 const uint32_t dw2 = HDR_DWORDS + 6u * cq;
                 const uint2 y0 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2));
                 const uint2 y1 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2 + 2u));
                 const uint2 y2 = *reinterpret_cast<const lds_u2 *>(SOLO_MINE(dw2 + 4u));
                 const uint32_t r6[6] = {y0.x, y0.y, y1.x, y1.y, y2.x, y2.y};
-                const uint32_t sc = runs_scan<6>(r6, b, second ? oh - start : 0u);
+                const uint32_t sc = rank24(r6, stab, b, second ? oh - start : 0u);
                 if (second) {
                     occU = cnt_b + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u) + sc;
                     step_done = true;

@@ -35,6 +35,20 @@ struct reply_arena {
 int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition,
                         reply_arena *replies, std::vector<char> *handled);
 
+// find_reads (src/service/service.cpp:714-797) for the ExactMatch requests of a batch whose return type is Reads
+// (QueryTask::run, :1260-1291): per request, partition and strand one Reply{rt = ExactMatch, t = ReplyReads, q, r =
+// ReplyReads{forward_matches | revcomp_matches}} carrying the reads that partition holds for the query.
+struct reads_config {
+    size_t min_read_length = 73, max_read_length = 100;  // service.cpp:56-57; service.cfg min_read_length / max_read_length (:1417-1420)
+    std::vector<std::string> suffix;                      // service.cfg `suffix` of each shard of the set ("" where absent): a tile is looked
+                                                          // up only in the partitions whose suffix it ends with (is_suffix_of, :228-230)
+};
+int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition, const reads_config &cfg,
+                        reply_arena *replies, std::vector<char> *handled);
+// the same requests answered with EMPTY read lists (a failed batch: the front-end has no timeout, server.cpp:469)
+void service_reads_empty(const std::vector<service_request> &rq, size_t rows, reply_arena *replies, std::vector<char> *handled);
+inline bool service_is_reads_request(const service_request &r) { return r.t == 2 && r.rt == 2; }  // ExactMatch + Reads
+
 // What the loop needs of ZeroMQ: the SUB socket it receives Requests on (service.cpp:1495-1497) and
 // the two PUSH sockets it answers on (push for ExactMatch, push_count for CountReads: :1499-1502,1568).
 class transport {

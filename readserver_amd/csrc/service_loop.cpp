@@ -419,6 +419,11 @@ struct rsbwt_service {
     int workers = 8;  // service.cpp:88
     rsbwt_service_other_fn other = nullptr;
     void *other_arg = nullptr;
+    // ExactMatch requests that ask for Reads (QueryTask, service.cpp:1556-1561 -> find_reads :714-797): answered here
+    // (BWT only); off = left to `other`, as until round 5
+    bool serve_reads = true;
+    reads_config reads_cfg;
+    std::atomic<uint64_t> read_requests{0};
     std::atomic<bool> stop{false};
     std::thread worker;
     // statistics
@@ -460,40 +465,71 @@ struct rsbwt_service {
         const size_t n = job.msgs.size();
         job.rq.resize(n);
         job.parsed.assign(n, 0);
+        bool any_reads = false;
         for (size_t i = 0; i < n; ++i) {
             job.parsed[i] = service_decode(job.msgs[i].data(), job.msgs[i].size(), &job.rq[i]) ? 1 : 0;
             if (!job.parsed[i]) { job.rq[i].t = 0; malformed++; }
-        }
-        const int rc = service_count_batch(set, job.rq, per_partition, &job.rep, &job.handled);
-        if (rc == RSBWT_OK) return;
-        // The front-end has no timeout (server.cpp:403,469,480): a request must not go unanswered.
-        // A failed batch is answered with zero counts and the error kept for the operator.
-        {
-            std::lock_guard<std::mutex> lock(err_mu);
-            last_rc = rc;
-            last_err = rsbwt_last_error();
-            fprintf(stderr, "rsbwt service: batch of %zu requests failed: %s\n", n, last_err.c_str());
+            else if (serve_reads && service_is_reads_request(job.rq[i])) any_reads = true;
         }
         const size_t rows = per_partition ? rsbwt_set_size(set) : 1;
-        job.handled.assign(n, 0);
-        job.rep.bytes.clear();
-        job.rep.off.assign(1, 0);
-        job.rep.first.assign(n + 1, 0);
-        for (size_t i = 0; i < n; ++i) {
-            job.rep.first[i] = job.rep.off.size() - 1;
-            const bool is_count = job.rq[i].t == 1 || (job.rq[i].t == 2 && job.rq[i].rt == 1);
-            if (!is_count) continue;
-            job.handled[i] = 1;
-            for (size_t r = 0; r < rows; ++r)
-                for (int strand = 0; strand < 2; ++strand) {
-                    const size_t len = rsbwt_proto_encode_count_reply(nullptr, 0, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
-                    const size_t at = job.rep.bytes.size();
-                    job.rep.bytes.resize(at + len);
-                    rsbwt_proto_encode_count_reply(job.rep.bytes.data() + at, len, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
-                    job.rep.off.push_back(job.rep.bytes.size());
-                }
+        int rc = service_count_batch(set, job.rq, per_partition, &job.rep, &job.handled);
+        if (rc != RSBWT_OK) {
+            // The front-end has no timeout (server.cpp:403,469,480): a request must not go unanswered.
+            // A failed batch is answered with zero counts and the error kept for the operator.
+            note_failure(rc, n, "count");
+            job.handled.assign(n, 0);
+            job.rep.bytes.clear();
+            job.rep.off.assign(1, 0);
+            job.rep.first.assign(n + 1, 0);
+            for (size_t i = 0; i < n; ++i) {
+                job.rep.first[i] = job.rep.off.size() - 1;
+                const bool is_count = job.rq[i].t == 1 || (job.rq[i].t == 2 && job.rq[i].rt == 1);
+                if (!is_count) continue;
+                job.handled[i] = 1;
+                for (size_t r = 0; r < rows; ++r)
+                    for (int strand = 0; strand < 2; ++strand) {
+                        const size_t len = rsbwt_proto_encode_count_reply(nullptr, 0, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                        const size_t at = job.rep.bytes.size();
+                        job.rep.bytes.resize(at + len);
+                        rsbwt_proto_encode_count_reply(job.rep.bytes.data() + at, len, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                        job.rep.off.push_back(job.rep.bytes.size());
+                    }
+            }
+            job.rep.first[n] = job.rep.off.size() - 1;
         }
-        job.rep.first[n] = job.rep.off.size() - 1;
+        if (!any_reads) return;
+        // the window's ExactMatch-Reads requests (find_reads, service.cpp:714-797): their Replies are woven into the
+        // window's in arrival order.  A failed batch is answered with empty read lists, for the same reason as above.
+        reply_arena rr;
+        std::vector<char> handled_r;
+        rc = service_reads_batch(set, job.rq, per_partition, reads_cfg, &rr, &handled_r);
+        if (rc != RSBWT_OK) {
+            note_failure(rc, n, "read");
+            service_reads_empty(job.rq, rows, &rr, &handled_r);
+        }
+        reply_arena all;
+        all.off.assign(1, 0);
+        all.first.assign(n + 1, 0);
+        all.bytes.reserve(job.rep.bytes.size() + rr.bytes.size());
+        for (size_t i = 0; i < n; ++i) {
+            all.first[i] = all.off.size() - 1;
+            const reply_arena *src = job.handled[i] ? &job.rep : handled_r[i] ? &rr : nullptr;
+            if (!src) continue;
+            for (size_t j = src->first[i]; j < src->first[i + 1]; ++j) {
+                all.bytes.insert(all.bytes.end(), src->bytes.begin() + src->off[j], src->bytes.begin() + src->off[j + 1]);
+                all.off.push_back(all.bytes.size());
+            }
+            if (handled_r[i]) { job.handled[i] = 2; read_requests++; }
+        }
+        all.first[n] = all.off.size() - 1;
+        job.rep = std::move(all);
+    }
+
+    void note_failure(int rc, size_t n, const char *what) {
+        std::lock_guard<std::mutex> lock(err_mu);
+        last_rc = rc;
+        last_err = rsbwt_last_error();
+        fprintf(stderr, "rsbwt service: the %s requests of a window of %zu failed: %s\n", what, n, last_err.c_str());
     }
 
     // sender: in arrival order; consecutive messages for the same socket go out in one call.
@@ -510,14 +546,14 @@ struct rsbwt_service {
         };
         for (size_t i = 0; i < n; ++i) {
             if (job.handled[i]) {
-                count_requests++;
+                if (job.handled[i] == 1) count_requests++;
                 const transport::channel ch = job.rq[i].t == 1 ? transport::PUSH_COUNT : transport::PUSH;
                 if (ch != run_ch) { flush(); run_ch = ch; }
                 run0 = run1 > run0 ? run0 : rep.first[i];
                 run1 = rep.first[i + 1];
             } else if (job.parsed[i] && other) {
                 flush();
-                other(other_arg, job.msgs[i].data(), job.msgs[i].size());  // KmerMatch, SiteMatch, ExactMatch with reads: the caller's
+                other(other_arg, job.msgs[i].data(), job.msgs[i].size());  // KmerMatch, SiteMatch, ExactMatch with All / Samples: the caller's
             }
         }
         flush();
@@ -537,12 +573,74 @@ struct rsbwt_service {
                 job = todo.front();
                 todo.pop_front();
             }
-            answer(*job);
+            // (an exception must not leave this thread -- std::terminate -- nor the window unanswered: the front-end
+            // has no timeout.  What answer() could not finish is answered with zero counts / empty lists.)
+            try {
+                answer(*job);
+            } catch (...) {
+                fail_window(*job, "answering");
+            }
             {
                 std::lock_guard<std::mutex> lock(mu);
                 job->done = true;
             }
             cv_done.notify_all();
+        }
+    }
+
+    // A window whose answer threw (std::bad_alloc in the reply arena, ...): every count / read request of it gets its
+    // zero / empty Replies (built from the decoded requests alone; if even that fails the window is dropped and the
+    // loss logged), the error is kept for rsbwt_service_run's return code.
+    void fail_window(window_job &job, const char *doing) noexcept {
+        try {
+            {
+                std::lock_guard<std::mutex> lock(err_mu);
+                last_rc = RSBWT_ENOMEM;
+                last_err = std::string("exception while ") + doing + " a window";
+                fprintf(stderr, "rsbwt service: %s (%zu requests): answered with empty results\n", last_err.c_str(), job.msgs.size());
+            }
+            const size_t n = job.msgs.size(), rows = per_partition ? rsbwt_set_size(set) : 1;
+            if (job.rq.size() != n) {
+                job.rq.assign(n, service_request());
+                job.parsed.assign(n, 0);
+                for (size_t i = 0; i < n; ++i) job.parsed[i] = service_decode(job.msgs[i].data(), job.msgs[i].size(), &job.rq[i]) ? 1 : 0;
+            }
+            reply_arena all, rr;
+            std::vector<char> handled_r;
+            service_reads_empty(job.rq, rows, &rr, &handled_r);
+            all.off.assign(1, 0);
+            all.first.assign(n + 1, 0);
+            job.handled.assign(n, 0);
+            for (size_t i = 0; i < n; ++i) {
+                all.first[i] = all.off.size() - 1;
+                const bool is_count = job.parsed[i] && (job.rq[i].t == 1 || (job.rq[i].t == 2 && job.rq[i].rt == 1));
+                if (is_count) {
+                    job.handled[i] = 1;
+                    for (size_t r = 0; r < rows; ++r)
+                        for (int strand = 0; strand < 2; ++strand) {
+                            const size_t len = rsbwt_proto_encode_count_reply(nullptr, 0, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                            const size_t at = all.bytes.size();
+                            all.bytes.resize(at + len);
+                            rsbwt_proto_encode_count_reply(all.bytes.data() + at, len, job.rq[i].t, job.rq[i].q.data(), job.rq[i].q.size(), strand, 0);
+                            all.off.push_back(all.bytes.size());
+                        }
+                } else if (serve_reads && job.parsed[i] && handled_r[i]) {
+                    job.handled[i] = 2;
+                    for (size_t j = rr.first[i]; j < rr.first[i + 1]; ++j) {
+                        all.bytes.insert(all.bytes.end(), rr.bytes.begin() + rr.off[j], rr.bytes.begin() + rr.off[j + 1]);
+                        all.off.push_back(all.bytes.size());
+                    }
+                }
+            }
+            all.first[n] = all.off.size() - 1;
+            job.rep = std::move(all);
+        } catch (...) {
+            fprintf(stderr, "rsbwt service: a window of %zu requests could not be answered at all\n", job.msgs.size());
+            job.handled.assign(job.msgs.size(), 0);
+            job.parsed.assign(job.msgs.size(), 0);
+            job.rep.bytes.clear();
+            job.rep.off.assign(1, 0);
+            job.rep.first.assign(job.msgs.size() + 1, 0);
         }
     }
 
@@ -557,7 +655,14 @@ struct rsbwt_service {
                 inflight.pop_front();
             }
             cv_room.notify_all();
-            emit(*job);
+            try {
+                emit(*job);  // (calls the embedder's `other` handler: on THIS thread, the sender's)
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(err_mu);
+                last_rc = RSBWT_ESYS;
+                last_err = "exception while sending a window's replies (the `other` handler threw?)";
+                fprintf(stderr, "rsbwt service: %s\n", last_err.c_str());
+            }
             delete job;
         }
     }
@@ -569,8 +674,26 @@ struct rsbwt_service {
             no_more = false;
         }
         std::vector<std::thread> pool;
-        for (int i = 0; i < nw; ++i) pool.emplace_back([this] { worker_loop(); });
-        std::thread sender([this] { sender_loop(); });
+        std::thread sender;
+        // (a thread that cannot be started -- std::system_error -- must not unwind past the joinable ones already
+        // running: they are told there is no more work and joined, and the error is the run's)
+        try {
+            for (int i = 0; i < nw; ++i) pool.emplace_back([this] { worker_loop(); });
+            sender = std::thread([this] { sender_loop(); });
+        } catch (...) {
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                no_more = true;
+            }
+            cv_work.notify_all();
+            cv_done.notify_all();
+            for (std::thread &t : pool) t.join();
+            if (sender.joinable()) sender.join();
+            std::lock_guard<std::mutex> lock(err_mu);
+            last_rc = RSBWT_ESYS;
+            last_err = "cannot start the service's threads";
+            return;
+        }
         uint64_t seq = 0;
         while (!stop.load()) {
             window_job *job = new (std::nothrow) window_job();
@@ -775,6 +898,23 @@ void rsbwt_service_set_workers(rsbwt_service_t *s, int workers) {
     if (s && workers >= 1) s->workers = workers > 64 ? 64 : workers;
 }
 
+void rsbwt_service_set_reads(rsbwt_service_t *s, int enable, uint32_t min_read_length, uint32_t max_read_length) {
+    if (!s) return;
+    s->serve_reads = enable != 0;
+    if (min_read_length) s->reads_cfg.min_read_length = min_read_length;
+    if (max_read_length) s->reads_cfg.max_read_length = max_read_length;
+}
+
+int rsbwt_service_set_suffixes(rsbwt_service_t *s, const char *const *suffix, size_t n) {
+    return guarded("rsbwt_service_set_suffixes", [&]() -> int {
+        if (!s || (!suffix && n)) return fail(RSBWT_EINVAL, "null argument");
+        if (n != 0 && n != rsbwt_set_size(s->set)) return fail(RSBWT_EINVAL, "%zu suffixes for a set of %zu shards", n, rsbwt_set_size(s->set));
+        s->reads_cfg.suffix.clear();
+        for (size_t i = 0; i < n; ++i) s->reads_cfg.suffix.emplace_back(suffix[i] ? suffix[i] : "");
+        return RSBWT_OK;
+    });
+}
+
 void rsbwt_service_set_other_handler(rsbwt_service_t *s, rsbwt_service_other_fn fn, void *arg) {
     if (!s) return;
     s->other = fn;
@@ -830,5 +970,7 @@ void rsbwt_service_stats(const rsbwt_service_t *s, uint64_t *stats6) {
     stats6[4] = s->malformed.load();
     stats6[5] = s->max_batch_seen.load();
 }
+
+uint64_t rsbwt_service_read_requests(const rsbwt_service_t *s) { return s ? s->read_requests.load() : 0; }
 
 }  // extern "C"

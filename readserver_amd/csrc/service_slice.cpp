@@ -1,6 +1,9 @@
 // service_slice.cpp -- the CountReads / ExactMatch-Count slice of ReadServer's query service
 // (SURVEY 8 f1), host side: proto2 wire codec for the two messages involved and the batched
-// count_reads (src/service/service.cpp:279-315) over a shard set.
+// count_reads (src/service/service.cpp:279-315) over a shard set; and, since round 5, the ExactMatch requests
+// whose return type is Reads: find_reads (service.cpp:714-797) batched over the set, the replies of
+// QueryTask::run (:1260-1291) -- what `GET /get?output=reads` waits for after its count pre-flight
+// (server.cpp:565-601); BWT only (the `all` return type needs the RocksDB shards and stays with the caller).
 //
 // Wire schema followed: src/service/readserver.proto:3-14 (Request), :31-33 (ResultCount),
 // :39-49 (Reply), :56-59 (ReplyCount).  protobuf is not in this image, so the codec is written
@@ -11,9 +14,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/rsbwt.h"
@@ -218,6 +223,266 @@ int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
     return RSBWT_OK;
 }
 
+// ---- ExactMatch + Reads: find_reads (service.cpp:714-797), batched ---------------------------------------------
+namespace {
+
+// Reply{rt, t = ReplyReads (2), q, r = ReplyReads{forward_matches | revcomp_matches = ResultReads{r}}*}
+// (readserver.proto:35-37,39-49,61-64); `r` is present even when no read matched (QueryTask::run calls
+// r.mutable_r() before the loop, service.cpp:1278: an empty sub-message, 2 bytes on the wire)
+size_t reads_body_len(const std::vector<const std::string *> &reads) {
+    size_t body = 0;
+    for (const std::string *s : reads) {
+        const size_t rr = 1 + varint_len(s->size()) + s->size();  // ResultReads{r}
+        body += 1 + varint_len(rr) + rr;
+    }
+    return body;
+}
+size_t reads_reply_len(int request_type, size_t qlen, size_t body) {
+    return 1 + varint_len((uint64_t)request_type) + 2 + 1 + varint_len(qlen) + qlen + 1 + varint_len(body) + body;
+}
+uint8_t *encode_reads_reply(uint8_t *p, int request_type, const std::string &q, bool revcomp, const std::vector<const std::string *> &reads, size_t body) {
+    *p++ = 0x08; p = put_varint(p, (uint64_t)request_type);  // rt
+    *p++ = 0x10; *p++ = 2;                                    // t = ReplyReads
+    *p++ = 0x1A; p = put_varint(p, q.size());
+    if (!q.empty()) memcpy(p, q.data(), q.size());
+    p += q.size();
+    *p++ = 0x2A; p = put_varint(p, body);                     // r
+    for (const std::string *s : reads) {
+        const size_t rr = 1 + varint_len(s->size()) + s->size();
+        *p++ = revcomp ? 0x12 : 0x0A; p = put_varint(p, rr);
+        *p++ = 0x0A; p = put_varint(p, s->size());
+        if (!s->empty()) memcpy(p, s->data(), s->size());
+        p += s->size();
+    }
+    return p;
+}
+
+// if w ends with s (service.cpp:228-230)
+inline bool is_suffix_of(const std::string &s, const std::string &w) {
+    return s.empty() || (w.size() >= s.size() && memcmp(s.data(), w.data() + (w.size() - s.size()), s.size()) == 0);
+}
+
+// get_tiles(w, kmer) (service.cpp:232-250, skip = 0): every kmer-long substring once -- into the SAME container the
+// reference uses, filled in the same order, so that iterating it visits the tiles in the order the reference's
+// loop does on the same standard library (the order of an unordered_set is the library's, not the standard's)
+std::unordered_set<std::string> get_tiles(const std::string &w, size_t kmer) {
+    std::unordered_set<std::string> vs;
+    if (kmer == 0 || w.size() < kmer) return vs;
+    for (size_t i = 0; i <= w.size() - kmer; ++i) vs.insert(w.substr(i, kmer));
+    return vs;
+}
+
+// The order find_reads leaves the rows of a wide interval in (service.cpp:724-751): while more than 2 x 2,048 rows
+// are left a chunk of 2,048 goes to the extraction pool; the rows that remain are extracted on the spot and come
+// FIRST, the chunks' reads are appended after them in chunk order.  Returns the number of leading rows that move
+// behind the tail (0 for intervals of up to 4,097 rows).
+inline size_t chunked_head(size_t n) {
+    const size_t large = 2048;  // service.cpp:86
+    size_t start = 0;
+    while (n != 0 && (n - 1) - start > 2 * large) start += large;
+    return start;
+}
+
+}  // namespace
+
+void service_reads_empty(const std::vector<service_request> &rq, size_t rows, reply_arena *replies, std::vector<char> *handled) {
+    const size_t n = rq.size();
+    handled->assign(n, 0);
+    replies->bytes.clear();
+    replies->off.assign(1, 0);
+    replies->first.assign(n + 1, 0);
+    const std::vector<const std::string *> none;
+    for (size_t i = 0; i < n; ++i) {
+        replies->first[i] = replies->off.size() - 1;
+        if (!service_is_reads_request(rq[i])) continue;
+        (*handled)[i] = 1;
+        for (size_t r = 0; r < rows; ++r)
+            for (int strand = 0; strand < 2; ++strand) {
+                const size_t at = replies->bytes.size(), len = reads_reply_len(rq[i].t, rq[i].q.size(), 0);
+                replies->bytes.resize(at + len);
+                encode_reads_reply(replies->bytes.data() + at, rq[i].t, rq[i].q, strand == 1, none, 0);
+                replies->off.push_back(replies->bytes.size());
+            }
+    }
+    replies->first[n] = replies->off.size() - 1;
+}
+
+int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition, const reads_config &cfg,
+                        reply_arena *replies, std::vector<char> *handled) {
+    const size_t n = rq.size(), S = rsbwt_set_size(set);
+    const size_t MINL = cfg.min_read_length, MAXL = cfg.max_read_length;
+    handled->assign(n, 0);
+    replies->bytes.clear();
+    replies->off.assign(1, 0);
+    replies->first.assign(n + 1, 0);
+    auto suffix_of = [&](size_t p) -> const std::string & {
+        static const std::string none;
+        return p < cfg.suffix.size() ? cfg.suffix[p] : none;
+    };
+    // a (request, strand) = one call of find_reads per partition; its result per partition: the tile matches, then the
+    // reads of query() / of the interval
+    struct job_t {
+        size_t req;
+        int strand;
+        std::string w;
+        std::vector<std::vector<std::string>> tiles;  // [shard]: tiles that are reads of that partition, in find_reads' order
+        std::vector<std::vector<std::string>> reads;  // [shard]: query(w) / the interval's rows
+    };
+    std::vector<job_t> jobs;
+    for (size_t i = 0; i < n; ++i) {
+        if (!service_is_reads_request(rq[i])) continue;
+        (*handled)[i] = 1;
+        for (int strand = 0; strand < 2; ++strand) {
+            job_t j;
+            j.req = i;
+            j.strand = strand;
+            j.w = strand ? rev_comp(rq[i].q.data(), rq[i].q.size()) : rq[i].q;  // QueryTask::run, service.cpp:1268-1272
+            j.tiles.resize(S);
+            j.reads.resize(S);
+            jobs.push_back(std::move(j));
+        }
+    }
+    if (jobs.empty()) {
+        replies->first.assign(n + 1, 0);
+        return RSBWT_OK;
+    }
+    // ---- the tiles (service.cpp:755-764,773-794): MAX-long ones of a query of MAX or more, then MIN-long ones (of any
+    // query longer than MIN; not again when MIN == MAX).  A tile is looked up in the partitions whose suffix it ends
+    // with; query_exactmatch (query.cpp:102-120) says whether it is a read there.  One batched call per (partition, length).
+    struct cand_t {
+        size_t job, seq;  // seq: the tile's place in find_reads' order within the job
+        std::string tile;
+    };
+    std::map<std::pair<size_t, size_t>, std::vector<cand_t>> by_shard_len;  // (shard, tile length) -> candidates
+    std::vector<size_t> nseq(jobs.size(), 0);
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        const std::string &w = jobs[ji].w;
+        const size_t sz = w.size();
+        std::vector<size_t> lens;
+        if (sz >= MAXL) {
+            lens.push_back(MAXL);
+            if (MINL != MAXL) lens.push_back(MINL);
+        } else if (sz >= MINL && sz != MINL) {
+            lens.push_back(MINL);
+        }
+        for (size_t T : lens) {
+            const std::unordered_set<std::string> vs = get_tiles(w, T);
+            for (const std::string &tile : vs) {
+                const size_t seq = nseq[ji]++;
+                for (size_t p = 0; p < S; ++p)
+                    if (is_suffix_of(suffix_of(p), tile)) by_shard_len[{p, T}].push_back(cand_t{ji, seq, tile});
+            }
+        }
+    }
+    std::vector<std::vector<std::pair<size_t, std::pair<size_t, std::string>>>> hits(jobs.size());  // job -> (seq, (shard, tile))
+    for (auto &g : by_shard_len) {
+        const size_t p = g.first.first, T = g.first.second, m = g.second.size();
+        if (T == 0 || m == 0) continue;
+        std::string flat(m * T, 'N');
+        for (size_t j = 0; j < m; ++j) memcpy(&flat[j * T], g.second[j].tile.data(), T);
+        std::vector<uint8_t> found(m, 0);
+        const int rc = rsbwt_query_exactmatch(rsbwt_set_shard(set, p), flat.data(), m, (uint32_t)T, T, found.data());
+        if (rc != RSBWT_OK) return rc;
+        for (size_t j = 0; j < m; ++j)
+            if (found[j]) hits[g.second[j].job].push_back({g.second[j].seq, {p, g.second[j].tile}});
+    }
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        std::sort(hits[ji].begin(), hits[ji].end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (auto &h : hits[ji]) jobs[ji].tiles[h.second.first].push_back(std::move(h.second.second));
+    }
+    // ---- the reads that CONTAIN w: query() for MIN <= |w| < MAX (service.cpp:767; query.cpp:87-100), the interval's
+    // rows for |w| < MIN (service.cpp:718-753).  One batched call per query length over all partitions.
+    std::map<size_t, std::vector<size_t>> by_len;
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        const size_t sz = jobs[ji].w.size();
+        if (sz != 0 && sz < MAXL) by_len[sz].push_back(ji);
+    }
+    for (auto &g : by_len) {
+        const size_t k = g.first, m = g.second.size();
+        std::string flat(m * k, 'N');
+        for (size_t j = 0; j < m; ++j) memcpy(&flat[j * k], jobs[g.second[j]].w.data(), k);
+        std::vector<uint64_t> first(m + 1, 0);
+        size_t nreads = 0;
+        uint32_t stride = (uint32_t)std::max<size_t>(256, (2 * MAXL + 63) & ~(size_t)15);
+        std::vector<char> reads;
+        std::vector<uint32_t> rlen, rshard;
+        for (int attempt = 0;; ++attempt) {
+            int rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), nullptr, nullptr, stride, nullptr, 0, &nreads);
+            if (rc != RSBWT_OK && rc != RSBWT_ERANGE) return rc;
+            if (nreads == 0) break;
+            reads.assign(nreads * (size_t)stride, 0);
+            rlen.assign(nreads, 0);
+            rshard.assign(nreads, 0);
+            rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), rshard.data(), reads.data(), stride, rlen.data(), nreads, &nreads);
+            if (rc != RSBWT_OK) return rc;
+            bool over = false;
+            for (size_t r = 0; r < nreads && !over; ++r) over = rlen[r] == 0xFFFFFFFFu;
+            if (!over || attempt == 2) break;
+            stride = attempt == 0 ? 4096u : 65536u;  // a read longer than the buffer (none in a collection built for these lengths): once more, wider
+        }
+        for (size_t j = 0; j < m && nreads; ++j) {
+            job_t &jb = jobs[g.second[j]];
+            // this query's reads arrive shard by shard (shard 0's first), each shard's in SA-row order
+            std::vector<size_t> begin_of(S + 1, 0);
+            for (uint64_t r = first[j]; r < first[j + 1]; ++r) begin_of[rshard[r] + 1]++;
+            for (size_t p = 0; p < S; ++p) begin_of[p + 1] += begin_of[p];
+            for (size_t p = 0; p < S; ++p) {
+                const size_t cnt = begin_of[p + 1] - begin_of[p], base = (size_t)first[j] + begin_of[p];
+                const size_t head = k < MINL ? chunked_head(cnt) : 0;  // (find_reads' own extraction reorders wide intervals; query() does not)
+                std::vector<std::string> &out = jb.reads[p];
+                out.reserve(cnt);
+                for (size_t t = 0; t < cnt; ++t) {
+                    const size_t r = base + (t + head < cnt ? t + head : t + head - cnt);
+                    if (rlen[r] == 0xFFFFFFFFu) continue;  // (longer than 64 KB: not a read of this service)
+                    out.emplace_back(reads.data() + r * (size_t)stride, rlen[r]);
+                }
+            }
+        }
+    }
+    // ---- Reply bytes: request by request, partition by partition (or all partitions' lists joined, shard 0's first),
+    // forward then reverse complement
+    const size_t rows = per_partition ? S : 1;
+    std::vector<std::vector<const std::string *>> lists(jobs.size() * rows);
+    for (size_t ji = 0; ji < jobs.size(); ++ji)
+        for (size_t p = 0; p < S; ++p) {
+            std::vector<const std::string *> &l = lists[ji * rows + (per_partition ? p : 0)];
+            // (a partition's list: its tile matches first, then the reads that contain w: service.cpp:757-769)
+            for (const std::string &t : jobs[ji].tiles[p]) l.push_back(&t);
+            for (const std::string &t : jobs[ji].reads[p]) l.push_back(&t);
+        }
+    if (!per_partition) {
+        // joined lists keep find_reads' order WITHIN a partition; across partitions the front-end concatenates in
+        // arrival order (server.cpp:199-261): here shard order, tiles and reads of shard 0 first
+    }
+    std::vector<size_t> body(lists.size());
+    size_t total = 0, messages = 0;
+    for (size_t ji = 0; ji < jobs.size(); ++ji)
+        for (size_t r = 0; r < rows; ++r) {
+            body[ji * rows + r] = reads_body_len(lists[ji * rows + r]);
+            total += reads_reply_len(rq[jobs[ji].req].t, rq[jobs[ji].req].q.size(), body[ji * rows + r]);
+            ++messages;
+        }
+    replies->bytes.resize(total);
+    replies->off.reserve(messages + 1);
+    uint8_t *p = replies->bytes.data();
+    size_t ji = 0;
+    for (size_t i = 0; i < n; ++i) {
+        replies->first[i] = replies->off.size() - 1;
+        if (!(*handled)[i]) continue;
+        // jobs[ji] = forward, jobs[ji + 1] = reverse complement of request i; per partition: forward, then reverse
+        // complement (the count path's order)
+        for (size_t r = 0; r < rows; ++r)
+            for (int strand = 0; strand < 2; ++strand) {
+                const size_t li = (ji + strand) * rows + r;
+                p = encode_reads_reply(p, rq[i].t, rq[i].q, strand == 1, lists[li], body[li]);
+                replies->off.push_back((size_t)(p - replies->bytes.data()));
+            }
+        ji += 2;
+    }
+    replies->first[n] = replies->off.size() - 1;
+    return RSBWT_OK;
+}
+
 bool service_decode(const uint8_t *msg, size_t len, service_request *out) {
     request_view r;
     if (!decode_request(msg, len, r)) return false;
@@ -265,6 +530,26 @@ static int rsbwt_service_counts_body(rsbwt_set_t *set, const uint8_t *requests, 
 int rsbwt_service_counts(rsbwt_set_t *set, const uint8_t *requests, size_t requests_len, const uint64_t *req_off,
                          size_t n, uint8_t *replies, size_t cap, uint64_t *rep_off, size_t *needed) {
     return rsb::guarded("rsbwt_service_counts", [&]() -> int { return rsbwt_service_counts_body(set, requests, requests_len, req_off, n, replies, cap, rep_off, needed); });
+}
+
+
+size_t rsbwt_proto_encode_reads_reply(uint8_t *out, size_t cap, int request_type, const char *q, size_t qlen, int revcomp,
+                                      const char *const *reads, const size_t *read_len, size_t nreads) {
+    if ((!q && qlen) || ((!reads || !read_len) && nreads)) return 0;
+    try {
+        std::vector<std::string> own(nreads);
+        std::vector<const std::string *> l(nreads);
+        for (size_t i = 0; i < nreads; ++i) {
+            own[i].assign(reads[i] ? reads[i] : "", read_len[i]);
+            l[i] = &own[i];
+        }
+        const std::string qs(q ? q : "", qlen);
+        const size_t body = rsb::reads_body_len(l), len = rsb::reads_reply_len(request_type, qlen, body);
+        if (out && len <= cap) rsb::encode_reads_reply(out, request_type, qs, revcomp != 0, l, body);
+        return len;
+    } catch (const std::bad_alloc &) {
+        return 0;
+    }
 }
 
 

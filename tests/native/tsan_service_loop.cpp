@@ -1,8 +1,9 @@
 // tsan_service_loop.cpp -- ThreadSanitizer run of the service loop (csrc/service_loop.cpp) and the
 // in-process transport: a producer thread pushes Requests, the loop thread batches and answers them, a
 // consumer thread pops Replies, a fourth thread polls the statistics; then the transport closes and the
-// loop drains.  The GPU engine behind the loop is stubbed (every count 0): what is checked is the
-// loop's own locking, and that exactly 2 x partitions Replies leave per count Request.  CPU only.
+// loop drains.  The GPU engine behind the loop is stubbed (every count 0, two made-up reads per k-mer and partition):
+// what is checked is the loop's own locking, and that exactly 2 x partitions Replies leave per count or Reads
+// Request.  CPU only.
 // Built and run by tests/test_service_slice.py.
 #include <stdarg.h>
 #include <stdint.h>
@@ -33,6 +34,25 @@ int rsbwt_set_count(rsbwt_set_t *, const char *, size_t Q, uint32_t, size_t, uin
     return RSBWT_OK;
 }
 const char *rsbwt_last_error(void) { return ""; }
+rsbwt_t *rsbwt_set_shard(rsbwt_set_t *, size_t i) { return (rsbwt_t *)(uintptr_t)(i + 1); }
+int rsbwt_query_exactmatch(rsbwt_t *, const char *, size_t Q, uint32_t, size_t, uint8_t *found) {
+    for (size_t q = 0; q < Q; ++q) found[q] = 0;
+    return RSBWT_OK;
+}
+// two 6-base reads per k-mer and partition
+int rsbwt_set_query(rsbwt_set_t *, const char *, size_t Q, uint32_t, size_t, uint64_t *first, uint32_t *read_shard, char *reads,
+                    uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
+    const size_t total = Q * PARTS * 2;
+    for (size_t q = 0; q <= Q; ++q) first[q] = q * PARTS * 2;
+    *nreads = total;
+    if (cap_reads < total) return RSBWT_ERANGE;
+    for (size_t r = 0; r < total; ++r) {
+        memcpy(reads + r * (size_t)read_stride, "ACGTAC", 6);
+        read_len[r] = 6;
+        if (read_shard) read_shard[r] = (uint32_t)((r / 2) % PARTS);
+    }
+    return RSBWT_OK;
+}
 }
 
 int main(int argc, char **argv) {
@@ -45,6 +65,7 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < N; ++i) {
             std::string m("\x08\x01\x10\x01\x1A\x05", 6);
             if (i % 7 == 3) m[1] = 0x02;  // ExactMatch + Count: answered on the other socket
+            if (i % 11 == 5) { m[1] = 0x02; m[3] = 0x02; }  // ExactMatch + Reads: find_reads' host side on a worker thread, woven into the window
             m += "ACGTA";
             m[6 + i % 5] = "ACGT"[i % 4];
             rsbwt_transport_push_request(tr, (const uint8_t *)m.data(), m.size());

@@ -1,5 +1,5 @@
 """Message classes for the part of ReadServer's wire schema the service slice touches
-(src/service/readserver.proto:3-14,31-33,39-49,56-59), re-typed here as a FileDescriptorProto so
+(src/service/readserver.proto:3-14,31-37,39-49,56-64), re-typed here as a FileDescriptorProto so
 the Python protobuf runtime can serialise golden bytes without protoc.  TEST INFRASTRUCTURE."""
 from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
 
@@ -44,6 +44,14 @@ def build():
     _field(rcount, "forward_matches", 1, _F.TYPE_MESSAGE, _F.LABEL_OPTIONAL, ".ResultCount")
     _field(rcount, "revcomp_matches", 2, _F.TYPE_MESSAGE, _F.LABEL_OPTIONAL, ".ResultCount")
 
+    rr = fd.message_type.add()
+    rr.name = "ResultReads"  # readserver.proto:35-37
+    _field(rr, "r", 1, _F.TYPE_STRING, _F.LABEL_REQUIRED)
+    rreads = fd.message_type.add()
+    rreads.name = "ReplyReads"  # readserver.proto:61-64
+    _field(rreads, "forward_matches", 1, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".ResultReads")
+    _field(rreads, "revcomp_matches", 2, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".ResultReads")
+
     rep = fd.message_type.add()
     rep.name = "Reply"
     e = rep.enum_type.add()
@@ -58,6 +66,7 @@ def build():
     _field(rep, "t", 2, _F.TYPE_ENUM, _F.LABEL_REQUIRED, ".Reply.ReplyType")
     _field(rep, "q", 3, _F.TYPE_STRING, _F.LABEL_REQUIRED)
     _field(rep, "c", 4, _F.TYPE_MESSAGE, _F.LABEL_OPTIONAL, ".ReplyCount")
+    _field(rep, "r", 5, _F.TYPE_MESSAGE, _F.LABEL_OPTIONAL, ".ReplyReads")
 
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)

@@ -45,6 +45,24 @@ def test_codec_matches_protobuf_runtime(rsb, pb):
                 out = (C.c_uint8 * (len(exp) + 16))()
                 n = L.rsbwt_proto_encode_count_reply(out, len(out), r.t, r.q.encode(), len(r.q), revcomp, c)
                 assert bytes(out[:n]) == exp
+    # ReplyReads (readserver.proto:35-37,61-64): none, one, many reads, either strand; `r` present even when empty
+    for nreads in (0, 1, 2, 300):
+        reads = ["".join("ACGT"[x] for x in rng.integers(0, 4, int(rng.integers(0, 200)))) for _ in range(nreads)]
+        for revcomp in (0, 1):
+            q = "ACGTTGCA" * int(rng.integers(0, 20))
+            rep = Reply()
+            rep.rt, rep.t, rep.q = 2, 2, q
+            rep.r.SetInParent()
+            for x in reads:
+                (rep.r.revcomp_matches if revcomp else rep.r.forward_matches).add().r = x
+            exp = rep.SerializeToString()
+            arr = (C.c_char_p * max(nreads, 1))(*[x.encode() for x in reads])
+            lens = (C.c_size_t * max(nreads, 1))(*[len(x) for x in reads])
+            need = L.rsbwt_proto_encode_reads_reply(None, 0, 2, q.encode(), len(q), revcomp, arr, lens, nreads)
+            assert need == len(exp)
+            out = (C.c_uint8 * need)()
+            assert L.rsbwt_proto_encode_reads_reply(out, need, 2, q.encode(), len(q), revcomp, arr, lens, nreads) == need
+            assert bytes(out) == exp
     # a message missing a required field, and a truncated one, are rejected
     bad = Request(); bad.t = 1; bad.rt = 1
     wire = bad.SerializePartialToString()
@@ -250,7 +268,8 @@ def test_gpu_service_loop_golden_replies(rsb, fixture_bwt, golden_dir, window_us
     partition = the golden fixture: the replies must be, byte for byte and in order, what a reference
     service process sends (tests/golden/service_v1.json: bytes from the protobuf runtime, counts from
     the compiled reference); CountReads on push_count, ExactMatch-Count on push; other request types
-    go to the handler; a malformed message is dropped and counted."""
+    go to the handler (here the ExactMatch-Reads requests too: rsbwt_service_set_reads(0), the loop as it was until
+    round 5 -- test_gpu_service_loop_reads_golden_replies has them answered); a malformed message is dropped and counted."""
     import json
     import os
     import threading
@@ -262,6 +281,7 @@ def test_gpu_service_loop_golden_replies(rsb, fixture_bwt, golden_dir, window_us
     tr, svc = C.c_void_p(), C.c_void_p()
     assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
     assert L.rsbwt_service_create(ss._s, tr, window_us, max_batch, 1, C.byref(svc)) == 0
+    L.rsbwt_service_set_reads(svc, 0, 0, 0)
     others = []
     CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
     cb = CB(lambda arg, p, n: others.append(bytes(p[:n])))
@@ -373,11 +393,13 @@ def test_gpu_service_loop_many_partitions(rsb, oracle, pb, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, fixture_bwt, golden_dir):
+def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, pb, fixture_bwt, golden_dir):
     """The drop-in claim on real sockets (src/service/service.cpp:1493-1502,1521-1577): this test plays the
     front-end -- binds a PUB socket (server.cpp:124) and two PULL sockets (server.cpp:118-120) -- the service
     connects SUB / PUSH / PUSH to them through libzmq bound at run time, and the golden Request bytes must come
-    back as the golden Reply bytes, in order per socket.  Skipped only where no libzmq exists."""
+    back as the golden Reply bytes, in order per socket: the counts (service_v1.json) and, since round 5, the read
+    lists of the ExactMatch-Reads requests (service_reads_v1.json), some of them hundreds of kilobytes long.
+    Skipped only where no libzmq exists."""
     import json
     import time
     z = _libzmq()
@@ -400,14 +422,19 @@ def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, fixture_bwt, g
         eps.append(ep.value)
     pub, pull, pull_count = socks
     gold = json.load(open(os.path.join(golden_dir, "service_v1.json")))["items"]
+    gr = json.load(open(os.path.join(golden_dir, "service_reads_v1.json")))
+    by_req = {x["request"]: x for x in gr["items"]}
+    gold = gold + gr["items"][::3]  # (a third of the read requests: the rest run through the in-process transport)
     path, _ = fixture_bwt
-    g = rsb.GpuBWT(path)
+    g = rsb.GpuBWT(path, for_reads=True)
     ss = rsb.ShardSet([g])
     tr, svc = C.c_void_p(), C.c_void_p()
     assert L.rsbwt_transport_zmq(eps[0], eps[1], eps[2], C.byref(tr)) == 0, L.rsbwt_last_error()
     assert L.rsbwt_service_create(ss._s, tr, 2000, 512, 1, C.byref(svc)) == 0
+    L.rsbwt_service_set_reads(svc, 1, gr["min_read_length"], gr["max_read_length"])
     assert L.rsbwt_service_start(svc) == 0
-    buf = C.create_string_buffer(65536)
+    BUF = 4 << 20
+    buf = C.create_string_buffer(BUF)
     # PUB/SUB drops what is published before the subscription has arrived: wait for a probe to be answered
     probe = bytes.fromhex(next(x for x in gold if x["replies"] and x["channel"] == 1)["request"])
     t0 = time.time()
@@ -416,13 +443,13 @@ def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, fixture_bwt, g
         z.zmq_send(pub, probe, len(probe), 0)
         tmo = C.c_int(200)
         z.zmq_setsockopt(pull_count, ZMQ_RCVTIMEO, C.byref(tmo), 4)
-        up = z.zmq_recv(pull_count, buf, 65536, 0) >= 0
+        up = z.zmq_recv(pull_count, buf, BUF, 0) >= 0
     assert up, "the service never subscribed"
     time.sleep(0.3)
     tmo = C.c_int(300)
     for so in (pull, pull_count):  # whatever other probes produced
         z.zmq_setsockopt(so, ZMQ_RCVTIMEO, C.byref(tmo), 4)
-        while z.zmq_recv(so, buf, 65536, 0) >= 0:
+        while z.zmq_recv(so, buf, BUF, 0) >= 0:
             pass
     tmo = C.c_int(20000)
     for so in (pull, pull_count):
@@ -431,18 +458,19 @@ def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, fixture_bwt, g
     for x in gold:
         w = bytes.fromhex(x["request"])
         assert z.zmq_send(pub, w, len(w), 0) == len(w)
-        if x["replies"]:
+        if x["t"] == 2 and x["rt"] == 2:
+            want[0] += by_req[x["request"]]["replies"] if x["request"] in by_req else _empty_reads_replies(pb, x["q"])
+        elif x["replies"]:
             want[x["channel"]] += [bytes.fromhex(r) for r in x["replies"]]
-    got = {0: [], 1: []}
     for ch, so in ((1, pull_count), (0, pull)):
-        for _ in want[ch]:
-            n = z.zmq_recv(so, buf, 65536, 0)
-            assert n >= 0, "a reply is missing"
-            got[ch].append(buf.raw[:n])
-    assert got[1] == want[1] and got[0] == want[0]
+        for j, w in enumerate(want[ch]):
+            n = z.zmq_recv(so, buf, BUF, 0)
+            assert 0 <= n <= BUF, "a reply is missing"
+            assert _same(buf.raw[:n], w), (ch, j, n)
+    assert any(isinstance(w, dict) and w["len"] > 100000 for w in want[0])  # (a read list of hundreds of kilobytes went over the socket)
     tmo = C.c_int(300)
     z.zmq_setsockopt(pull, ZMQ_RCVTIMEO, C.byref(tmo), 4)
-    assert z.zmq_recv(pull, buf, 65536, 0) < 0  # exactly two per request, no more
+    assert z.zmq_recv(pull, buf, BUF, 0) < 0  # exactly two per request, no more
     L.rsbwt_transport_close(tr)
     assert L.rsbwt_service_stop(svc) == 0
     L.rsbwt_service_free(svc)
@@ -452,6 +480,200 @@ def test_gpu_service_over_real_zeromq_sockets_golden_replies(rsb, fixture_bwt, g
     z.zmq_ctx_term(ctx)
     ss.close()
     g.close()
+
+
+def _empty_reads_replies(pb, q):
+    """What this service sends for a Reads request it answers with no read: both strands, `r` present and empty."""
+    _, Reply = pb
+    out = []
+    for _strand in (0, 1):
+        rep = Reply()
+        rep.rt, rep.t, rep.q = 2, 2, q
+        rep.r.SetInParent()
+        out.append(rep.SerializeToString())
+    return out
+
+
+def _same(got, want):
+    """a reply against its golden form: the bytes, or (long replies) their length and SHA-256"""
+    import hashlib
+    if isinstance(want, dict):
+        return len(got) == want["len"] and hashlib.sha256(got).hexdigest() == want["sha256"]
+    return got == (bytes.fromhex(want) if isinstance(want, str) else want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window_us,max_batch,for_reads", [(5000, 4096, True), (0, 1, False), (300, 7, True)])
+def test_gpu_service_loop_reads_golden_replies(rsb, pb, fixture_bwt, golden_dir, window_us, max_batch, for_reads):
+    """J1: ExactMatch Requests whose return type is Reads, answered by the loop itself.  The stream is
+    service_v1.json's (counts, other types, malformed) with service_reads_v1.json's woven in; one partition = the golden
+    fixture, min / max read length 50 / 70 as in the golden file.  Every Reads request must come back on `push` as the
+    two Reply messages a reference service sends (QueryTask::run + find_reads, service.cpp:714-797,1260-1291; the reads
+    out of the compiled reference, tests/golden/make_service_reads_golden.py) -- byte for byte, in arrival order,
+    between the count replies of the same socket; intervals of more than 4,097 rows in find_reads' chunked order; the
+    tiles in the reference's container order.  A Reads request with a symbol outside ACGT or an empty query gets two
+    replies with an empty list (this service's rule: include/rsbwt.h).  Shards opened for reads or not: same bytes."""
+    import json
+    import threading
+    L = rsb.lib()
+    v1 = json.load(open(os.path.join(golden_dir, "service_v1.json")))["items"]
+    gr = json.load(open(os.path.join(golden_dir, "service_reads_v1.json")))
+    by_req = {x["request"]: x for x in gr["items"]}
+    stream = []
+    extra = [x for x in gr["items"]]
+    for i, x in enumerate(v1):
+        stream.append(x)
+        if i % 2 == 0 and extra:
+            stream.append(extra.pop(0))
+    stream += extra
+    path, _ = fixture_bwt
+    g = rsb.GpuBWT(path, for_reads=for_reads)
+    ss = rsb.ShardSet([g])
+    tr, svc = C.c_void_p(), C.c_void_p()
+    assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
+    assert L.rsbwt_service_create(ss._s, tr, window_us, max_batch, 1, C.byref(svc)) == 0
+    L.rsbwt_service_set_reads(svc, 1, gr["min_read_length"], gr["max_read_length"])
+    suf = (C.c_char_p * 1)(gr["suffix"].encode())
+    assert L.rsbwt_service_set_suffixes(svc, suf, 1) == 0
+    assert L.rsbwt_service_set_suffixes(svc, suf, 2) == -1  # (one suffix per shard)
+    others = []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+    cb = CB(lambda arg, p, n: others.append(bytes(p[:n])))
+    L.rsbwt_service_set_other_handler(svc, C.cast(cb, C.c_void_p), None)
+    assert L.rsbwt_service_start(svc) == 0
+    want = {0: [], 1: []}
+    n_reads_req = 0
+    for x in stream:
+        if x["t"] == 2 and x["rt"] == 2:
+            n_reads_req += 1
+            want[0] += by_req[x["request"]]["replies"] if x["request"] in by_req else _empty_reads_replies(pb, x["q"])
+        elif x["replies"]:
+            want[x["channel"]] += [bytes.fromhex(r) for r in x["replies"]]
+
+    def feed():
+        for x in stream:
+            w = bytes.fromhex(x["request"])
+            buf = (C.c_uint8 * max(len(w), 1)).from_buffer_copy(w or b"\\0")
+            assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
+    th = threading.Thread(target=feed)
+    th.start()
+    cap = 4 << 20
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t()
+    for ch in (1, 0):
+        for j, w in enumerate(want[ch]):
+            assert L.rsbwt_transport_pop_reply(tr, ch, buf, cap, C.byref(n), 60_000_000) == 0, (ch, j)
+            assert _same(bytes(buf[:n.value]), w), (ch, j, n.value)
+    th.join()
+    L.rsbwt_transport_close(tr)
+    assert L.rsbwt_service_stop(svc) == 0
+    assert L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == -2  # exactly two per request and partition
+    assert L.rsbwt_service_read_requests(svc) == n_reads_req
+    # what is left to the embedder: KmerMatch, SiteMatch -- no ExactMatch request of either return type served here
+    assert sorted(others) == sorted(bytes.fromhex(x["request"]) for x in stream if not x["replies"] and not (x["t"] == 2 and x["rt"] == 2))
+    assert any(isinstance(r, dict) for r in want[0]) and sum(1 for x in gr["items"] if max(x["reads"]) > 4097) >= 2
+    L.rsbwt_service_free(svc)
+    L.rsbwt_transport_free(tr)
+    ss.close()
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_partition", [1, 0])
+def test_gpu_service_loop_reads_many_partitions(rsb, oracle, pb, tmp_path, per_partition):
+    """The same over a set of four suffix partitions (reads that end in A, C, G, T: csrc/synth.cpp's shard rule) held by
+    one process: per partition and strand a reply with what THAT partition holds (per_partition = 1; a tile is looked up
+    only where it ends with the partition's suffix, service.cpp:228-230,759), or the four lists joined in shard order
+    (= 0).  Expected lists composed from the oracle per shard: interval rows / reads containing the query in SA-row
+    order after the tiles; the tile matches as a set (their order is pinned on one partition by the golden test)."""
+    Request, Reply = pb
+    L = rsb.lib()
+    kw = dict(seed=31, genome_len=30000, haplotypes=4, snp_rate=0.004, read_len=60, coverage=4.0)
+    MINL, MAXL = 40, 60
+    shards, oixs, shard_reads = [], [], []
+    for s in range(4):
+        p = str(tmp_path / f"s{s}.bwt")
+        rd = str(tmp_path / f"s{s}.reads")
+        rsb.synth_popbwt(p, rd, shard=s, num_shards=4, **kw)
+        shards.append(rsb.GpuBWT(p, for_reads=(s % 2 == 0)))
+        oixs.append(oracle.load(p))
+        shard_reads.append(set(open(rd).read().split()))
+        assert all(r.endswith("ACGT"[s]) for r in shard_reads[-1])
+    all_reads = sorted(set().union(*shard_reads))
+    rng = np.random.default_rng(12)
+    rnd = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, k))
+    qs = []
+    for k in (8, 15, 31, 39, 40, 41, 50, 59):
+        for _ in range(4):
+            r = all_reads[rng.integers(len(all_reads))]
+            st = int(rng.integers(0, len(r) - k + 1))
+            qs.append(r[st:st + k])
+    qs += [all_reads[rng.integers(len(all_reads))] for _ in range(4)]
+    qs += [rnd(int(rng.integers(1, 20))) + all_reads[rng.integers(len(all_reads))] + rnd(int(rng.integers(0, 20))) for _ in range(4)]
+    qs += [_rc(all_reads[rng.integers(len(all_reads))]), rnd(30), rnd(45), rnd(100), "ACGTN" * 5, ""]
+    ss = rsb.ShardSet(shards)
+    tr, svc = C.c_void_p(), C.c_void_p()
+    assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
+    assert L.rsbwt_service_create(ss._s, tr, 2000, 64, per_partition, C.byref(svc)) == 0
+    L.rsbwt_service_set_reads(svc, 1, MINL, MAXL)
+    suf = (C.c_char_p * 4)(b"A", b"C", b"G", b"T")
+    assert L.rsbwt_service_set_suffixes(svc, suf, 4) == 0
+    for q in qs:
+        r = Request()
+        r.t, r.rt, r.q = 2, 2, q
+        w = r.SerializeToString()
+        buf = (C.c_uint8 * len(w)).from_buffer_copy(w)
+        assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
+    L.rsbwt_transport_close(tr)
+    assert L.rsbwt_service_run(svc) == 0
+
+    def expect(s, w):
+        """(tile matches as a set, the reads behind them in order) of find_reads in partition s"""
+        ok = bool(w) and all(c in "ACGT" for c in w)
+        tiles, seqs = set(), []
+        if len(w) >= MINL:
+            for T in ([MAXL, MINL] if len(w) >= MAXL else ([MINL] if len(w) != MINL else [])):
+                for i in range(len(w) - T + 1):
+                    t = w[i:i + T]
+                    if t.endswith("ACGT"[s]) and t in shard_reads[s]:
+                        tiles.add(t)
+        if ok and len(w) < MAXL:
+            lo, up = oixs[s].find_interval(w)
+            for row in range(lo, up + 1) if up >= lo else []:
+                pre, post = oixs[s].extract(row)
+                seqs.append(pre + post)
+        return tiles, seqs
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t()
+    some_tiles = some_reads = 0
+    for q in qs:
+        for s in (range(4) if per_partition else [None]):
+            for strand in (0, 1):
+                assert L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 5_000_000) == 0
+                m = Reply()
+                m.ParseFromString(bytes(buf[:n.value]))
+                assert (m.rt, m.t, m.q) == (2, 2, q) and m.HasField("r")
+                got = [x.r for x in (m.r.revcomp_matches if strand else m.r.forward_matches)]
+                assert not (m.r.forward_matches if strand else m.r.revcomp_matches)
+                w = _rc(q) if strand else q
+                parts = [expect(p, w) for p in (range(4) if s is None else [s])]
+                at = 0
+                for tiles, seqs in parts:  # a partition's list: its tile matches, then its reads (shard order when joined)
+                    assert set(got[at:at + len(tiles)]) == tiles and len(set(got[at:at + len(tiles)])) == len(tiles), (q, s, strand)
+                    at += len(tiles)
+                    assert got[at:at + len(seqs)] == seqs, (q, s, strand)
+                    at += len(seqs)
+                    some_tiles += len(tiles)
+                    some_reads += len(seqs)
+                assert at == len(got)
+    assert some_tiles > 5 and some_reads > 100
+    assert L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == -2
+    L.rsbwt_service_free(svc)
+    L.rsbwt_transport_free(tr)
+    ss.close()
+    for g in shards:
+        g.close()
 
 
 def test_exceptions_do_not_cross_the_c_boundary(rsb):
