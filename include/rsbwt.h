@@ -119,8 +119,17 @@ uint32_t rsbwt_window_span(const rsbwt_t *h);     /* symbols per window */
 uint64_t rsbwt_far_lines(const rsbwt_t *h);       /* lines that continue windows of > 120 pieces */
 uint64_t rsbwt_spilled_symbols(const rsbwt_t *h); /* positions one request past their window's line */
 uint64_t rsbwt_hbm_bytes(const rsbwt_t *h);       /* lines + tables */
-uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi hint (without RSBWT_OPEN_READS: 0 before the first extraction / getOccAt) */
+uint64_t rsbwt_psi_hint_lines(const rsbwt_t *h);  /* window lines carrying a psi hint (without RSBWT_OPEN_READS: 0 until rsbwt_prepare_extraction) */
 int rsbwt_opened_for_reads(const rsbwt_t *h);     /* 1: laid out with RSBWT_OPEN_READS */
+/* Read extraction and getOccAt need a sampled select table.  A shard opened with RSBWT_OPEN_READS has it (and a psi
+ * hint in every window line) when rsbwt_open* returns.  Any other shard builds it on its first extraction / getOccAt
+ * call INTO A SIDE TABLE: nothing a search reads -- the lines, the handle's view -- is written after the handle has
+ * been handed out, so that first call may run beside searches on other threads (until round 5 it rewrote the
+ * handle's view and wrote psi hints into the resident lines).  Such a shard then extracts WITHOUT hints (about 1.9
+ * requests per psi step instead of 1.4).  rsbwt_prepare_extraction gives it the samples and the hints its lines have
+ * room for (about two thirds of them) in one go; it WRITES INTO THE RESIDENT LINES, so the owner calls it before it
+ * shares the handle with other threads, like rsbwt_attach_ktab.  No-op on a shard opened for reads. */
+int rsbwt_prepare_extraction(rsbwt_t *h);
 /* Builds the k-mer table of depth T (2..16) of an open handle that has none. */
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 /* The same with the table's format named.  The table holds what findInterval (src/bwt/query.cpp:24-41) returns for
@@ -139,6 +148,9 @@ int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T);
 int rsbwt_attach_ktab_format(rsbwt_t *h, uint32_t T, uint32_t format);
 /* format (RSBWT_KTAB_FORMAT_PLAIN / _GROUPED), bytes in HBM and -- grouped -- the T-mers left to the search; any may be NULL */
 int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_t *untabulated);
+/* Test hook (RSBWT_ENABLE_TEST_HOOKS): n bytes of the resident index (region 0: the lines, 1: an owned k-mer table)
+ * copied out, the reading twin of rsbwt_debug_poke. */
+int rsbwt_debug_peek(rsbwt_t *h, int region, uint64_t offset, void *bytes, size_t n);
 int rsbwt_device(const rsbwt_t *h);          /* the GPU the shard is resident on */
 /* The device number the shard was opened with.  Equal to rsbwt_device() except under the TEST HOOK
  * RSBWT_TEST_DEVICE_ALIASES=N (honoured only while RSBWT_ENABLE_TEST_HOOKS is set; read at every rsbwt_open*):
@@ -338,6 +350,16 @@ rsbwt_t *rsbwt_set_shard(rsbwt_set_t *s, size_t i);
  * lines (the depth that gives, over all devices: rsbwt_set_auto_ktab_depth) */
 int rsbwt_set_attach_ktabs(rsbwt_set_t *s, uint32_t depth);
 uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s);
+/* THE sizing rule, with the format: the depth and format (RSBWT_KTAB_FORMAT_PLAIN / _GROUPED) the set's shards that
+ * have no table yet would get -- one pair for the whole set, the shallowest over its devices -- when format_in
+ * (PLAIN / GROUPED / AUTO) is asked for and keep_free_bytes of each device's free HBM are to stay free (0: the set's
+ * own rule, a quarter of what is free and at least 8 GiB).  What rsbwt_set_open and rsbwt_set_attach_ktabs*(depth 0)
+ * build, and what bench.py / onehost.py ask instead of restating the rule.  *depth 0 = no table. */
+int rsbwt_set_auto_ktab(rsbwt_set_t *s, uint32_t format_in, uint64_t keep_free_bytes, uint32_t *depth, uint32_t *format_out);
+/* The same rule as plain arithmetic (host only): the deepest table of at most budget_bytes over a shard of n_symbols --
+ * plain: 8 B x 4^T <= budget, 4^T <= n, T <= 16; grouped (3 B x 4^T, T <= 17) only where it is deeper than the plain
+ * one, a T-mer still has 64 rows and four siblings fit a record, else plain. */
+int rsbwt_auto_ktab_for_budget(uint64_t budget_bytes, uint64_t n_symbols, uint32_t format_in, uint32_t *depth, uint32_t *format_out);
 /* the same with the format named (rsbwt_attach_ktab_format; rsbwt_set_attach_ktabs = PLAIN); grouped tables are
  * interleaved like plain ones: a query's records for the S shards of a device are one stretch of 12 * S bytes */
 int rsbwt_set_attach_ktabs_format(rsbwt_set_t *s, uint32_t depth, uint32_t format);

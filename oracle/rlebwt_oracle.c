@@ -557,3 +557,46 @@ void rso_find_intervals(const rso_index *ix, const char *kmers, size_t Q,
         pthread_create(&th[t], NULL, job_main, &jobs[t]);
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
+
+/* extractPrefix + extractPostfix (src/bwt/query.cpp:43-85, joined as query() does, :94-96) of n rows, split over
+ * `nthreads` POSIX threads sharing the index: row i's read to out + i * stride (no NUL), its length to len[i] and the
+ * length of its prefix part to prefix_len[i] (may be NULL); a read that does not fit `stride` bytes gets
+ * len = UINT32_MAX.  The CPU baseline of bench.py --mode extract on the host's cores, and the checker of its reads. */
+typedef struct {
+    const rso_index *ix;
+    const uint64_t *rows;
+    size_t n, stride;
+    char *out;
+    uint32_t *len, *plen;
+    int tid, nthreads;
+} xjob_t;
+
+static void *xjob_main(void *p) {
+    const xjob_t *j = (const xjob_t *)p;
+    for (size_t i = (size_t)j->tid; i < j->n; i += (size_t)j->nthreads) {
+        char *o = j->out + i * j->stride;
+        const size_t a = rso_extract_prefix(j->ix, j->rows[i], o, j->stride);
+        size_t b = (size_t)-1;
+        if (a != (size_t)-1) b = rso_extract_postfix(j->ix, j->rows[i], o + a, j->stride - a);
+        if (a == (size_t)-1 || b == (size_t)-1) {
+            j->len[i] = 0xFFFFFFFFu;
+            if (j->plen) j->plen[i] = 0;
+        } else {
+            j->len[i] = (uint32_t)(a + b);
+            if (j->plen) j->plen[i] = (uint32_t)a;
+        }
+    }
+    return NULL;
+}
+
+void rso_extract_batch(const rso_index *ix, const uint64_t *rows, size_t n, char *out, size_t stride, uint32_t *len,
+                       uint32_t *prefix_len, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    xjob_t jobs[256];
+    pthread_t th[256];
+    for (int t = 0; t < nthreads; ++t) jobs[t] = (xjob_t){ix, rows, n, stride, out, len, prefix_len, t, nthreads};
+    if (nthreads == 1) { xjob_main(&jobs[0]); return; }
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, xjob_main, &jobs[t]);
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}

@@ -77,6 +77,11 @@ void rso_find_intervals(const rso_index *ix, const char *kmers, size_t Q,
                         uint32_t k, size_t stride, uint64_t *lower,
                         uint64_t *upper, uint8_t *steps, int nthreads);
 
+/* extractPrefix + extractPostfix of n rows over `nthreads` POSIX threads: read i at out + i * stride, len[i]
+ * (UINT32_MAX: does not fit stride), prefix_len[i] (may be NULL). */
+void rso_extract_batch(const rso_index *ix, const uint64_t *rows, size_t n, char *out, size_t stride, uint32_t *len,
+                       uint32_t *prefix_len, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     "rsbwt_hbm_bytes": (C.c_uint64, [_vp]),
     "rsbwt_psi_hint_lines": (C.c_uint64, [_vp]),
     "rsbwt_opened_for_reads": (C.c_int, [_vp]),
+    "rsbwt_prepare_extraction": (C.c_int, [_vp]),
+    "rsbwt_debug_peek": (C.c_int, [_vp, C.c_int, C.c_uint64, _vp, C.c_size_t]),
     "rsbwt_attach_ktab": (C.c_int, [_vp, C.c_uint32]),
     "rsbwt_attach_ktab_format": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rsbwt_ktab_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), _u64p, _u64p]),
@@ -151,6 +153,8 @@ SIGNATURES = {
     "rsbwt_set_attach_ktabs": (C.c_int, [_vp, C.c_uint32]),
     "rsbwt_set_attach_ktabs_format": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rsbwt_set_auto_ktab_depth": (C.c_uint32, [_vp]),
+    "rsbwt_set_auto_ktab": (C.c_int, [_vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rsbwt_auto_ktab_for_budget": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rsbwt_set_find_intervals_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp, _vp]),
     "rsbwt_set_count_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "rsbwt_set_find_interval_pairs_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),

@@ -228,6 +228,7 @@ int attach_ktab_into(rsbwt *h, uint32_t T, uint64_t *d_table, uint32_t stride, u
     h->view.ktab_fmt = fmt;
     h->ktab_untabulated = left;
     h->hbm_bytes += ktab_bytes(fmt, T);
+    if (h->d_xview == h->d_view) h->xview = h->view;  // (a shard opened for reads: one view)
     return upload_view(h);
 }
 
@@ -240,6 +241,7 @@ int detach_ktab(rsbwt *h) {
     h->view.ktab_fmt = KTAB_PLAIN;
     h->ktab_untabulated = 0;
     h->ktab_owned = true;
+    if (h->d_xview == h->d_view) h->xview = h->view;
     const int rc = use_device(h->device);
     return rc ? rc : upload_view(h);
 }
@@ -270,6 +272,17 @@ int rsbwt_attach_ktab_format(rsbwt_t *h, uint32_t T, uint32_t format) {
 }
 int rsbwt_attach_ktab(rsbwt_t *h, uint32_t T) { return rsbwt_attach_ktab_format(h, T, RSBWT_KTAB_FORMAT_PLAIN); }
 
+// The sizing rule as plain arithmetic (host only, no GPU): the deepest table of at most budget_bytes per shard over a
+// shard of n_symbols, in the format asked for (AUTO / GROUPED: grouped only where that is deeper and sensible).
+int rsbwt_auto_ktab_for_budget(uint64_t budget_bytes, uint64_t n_symbols, uint32_t format_in, uint32_t *depth, uint32_t *format_out) {
+    if (!depth || !format_out) return fail(RSBWT_EINVAL, "null argument");
+    if (format_in > RSBWT_KTAB_FORMAT_AUTO) return fail(RSBWT_EINVAL, "k-mer table format %u", format_in);
+    uint32_t fmt = format_in == RSBWT_KTAB_FORMAT_PLAIN ? KTAB_PLAIN : KTAB_GROUPED;
+    *depth = auto_ktab_depth_for(budget_bytes, n_symbols, &fmt);
+    *format_out = fmt == KTAB_GROUPED ? RSBWT_KTAB_FORMAT_GROUPED : RSBWT_KTAB_FORMAT_PLAIN;
+    return RSBWT_OK;
+}
+
 int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_t *untabulated) {
     if (!h) return fail(RSBWT_EINVAL, "null handle");
     const bool has = h->view.ktab != nullptr && h->view.ktab_depth != 0u;
@@ -279,7 +292,7 @@ int rsbwt_ktab_info(const rsbwt_t *h, uint32_t *format, uint64_t *bytes, uint64_
     return RSBWT_OK;
 }
 
-static int ensure_select_samples(rsbwt_t *h, hipStream_t stream);
+static int ensure_select_samples(rsbwt_t *h, hipStream_t stream, bool with_hints = false);
 
 static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strings, int device, int logical,
                        uint32_t flags, rsbwt_t **out) {
@@ -340,8 +353,13 @@ static int finish_open(const void *d_runs, uint64_t num_runs, uint64_t num_strin
     if ((flags & RSBWT_OPEN_READS) != 0u && h->view.n != 0) {
         ctx_guard g(h->pool);
         if (!g.c) { rsbwt_close(h); return fail(RSBWT_EHIP, "cannot create a HIP stream"); }
-        rc = ensure_select_samples(h, g.c->st[0]);
+        rc = ensure_select_samples(h, g.c->st[0], true);
         if (rc) { rsbwt_close(h); return rc; }
+        // (nobody has the handle yet: its one view names the samples)
+        (void)hipFree(h->d_xview);
+        h->view = h->xview;
+        h->d_xview = h->d_view;
+        if ((rc = upload_view(h)) != RSBWT_OK) { rsbwt_close(h); return rc; }
     }
     // k-mer table: explicit depth, none, or auto = the deepest whose 8-byte entries take no more
     // HBM than 5/4 of the index itself and no more than a quarter of what is still free (HBM is there
@@ -453,6 +471,7 @@ void rsbwt_close(rsbwt_t *h) {
     h->pool.destroy();
     if (h->view.lines) (void)hipFree((void *)h->view.lines);
     if (h->view.ktab && h->ktab_owned) (void)hipFree((void *)h->view.ktab);
+    if (h->d_xview && h->d_xview != h->d_view) (void)hipFree(h->d_xview);
     if (h->d_view) (void)hipFree(h->d_view);
     if (h->d_sel) (void)hipFree(h->d_sel);
     if (h->d_work) (void)hipFree(h->d_work);
@@ -524,50 +543,94 @@ int rsbwt_debug_poke(rsbwt_t *h, int region, uint64_t offset, const void *bytes,
     return e == hipSuccess ? RSBWT_OK : fail_hip(e, "rsbwt_debug_poke");
 }
 
+// Test hook, the reading twin of rsbwt_debug_poke: n bytes of the index in HBM (region 0: the lines, 1: the k-mer
+// table) copied to `bytes` -- so that a test can hold "nothing a search reads is written after the handle was handed
+// out" to the bytes themselves.  Answers no query.
+int rsbwt_debug_peek(rsbwt_t *h, int region, uint64_t offset, void *bytes, size_t n) {
+    if (!h || (!bytes && n)) return fail(RSBWT_EINVAL, "null argument");
+    if (getenv("RSBWT_ENABLE_TEST_HOOKS") == nullptr) return fail(RSBWT_EINVAL, "rsbwt_debug_peek is a test hook: set RSBWT_ENABLE_TEST_HOOKS=1");
+    const uint64_t size = region == 0 ? h->view.nlines * (uint64_t)LINE_BYTES
+                          : region == 1 && h->view.ktab && h->ktab_owned ? ktab_bytes(h->view.ktab_fmt, h->view.ktab_depth) : 0ull;
+    if (offset > size || n > size - offset) return fail(RSBWT_ERANGE, "peek outside the region (%llu bytes)", (unsigned long long)size);
+    if (n == 0) return RSBWT_OK;
+    int rc = use_device(h->device);
+    if (rc != RSBWT_OK) return rc;
+    const char *base = region == 0 ? (const char *)h->view.lines : (const char *)h->view.ktab;
+    const hipError_t e = hipMemcpy(bytes, base + offset, n, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? RSBWT_OK : fail_hip(e, "rsbwt_debug_peek");
+}
+
 // ---- class BWT mirrors ------------------------------------------------------------------------
 
-// the sampled select table (getOccAt, read extraction) and the psi hints: built once -- at open for a shard opened
-// with RSBWT_OPEN_READS, else on first use
-static int ensure_select_samples(rsbwt_t *h, hipStream_t stream) {
+// The sampled select table (getOccAt, read extraction): built once -- at open for a shard opened with
+// RSBWT_OPEN_READS (with the psi hints, into lines nobody reads yet), else on first use INTO A SIDE TABLE: nothing
+// the searches read (h->view, h->d_view, the lines) is written.  with_hints: also write psi hints into the window
+// lines that have room for one -- only before the handle is shared (finish_open, rsbwt_prepare_extraction).
+static int ensure_select_samples(rsbwt_t *h, hipStream_t stream, bool with_hints) {
+    if (h->x_ready.load(std::memory_order_acquire) && !with_hints) return RSBWT_OK;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (h->d_sel) return RSBWT_OK;
+    const bool have = h->x_ready.load(std::memory_order_relaxed);
+    if (have && (!with_hints || h->psi_hint_lines != 0 || getenv("RSBWT_NO_PSI_HINTS") != nullptr)) return RSBWT_OK;
     const uint64_t stride_m = select_sample_stride(h->view);
     const uint64_t words = 5 * stride_m;
-    uint64_t *d = nullptr;
-    HIP_OK(hipMalloc(&d, words * sizeof(uint64_t)));
-    hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint64_t), stream);
-    if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
-    // and the psi hints, into the window lines that have room for one (line_format.h): extraction's select then
-    // needs no sample for the rows of those windows.  Searches that run meanwhile are not disturbed: a hint sits
-    // where a line holds no piece of its own, and the flag is a header bit no search reads.
+    uint64_t *d = h->d_sel;
+    hipError_t e = hipSuccess;
+    if (!have) {
+        HIP_OK(hipMalloc(&d, words * sizeof(uint64_t)));
+        e = hipMemsetAsync(d, 0, words * sizeof(uint64_t), stream);
+        if (e == hipSuccess) e = launch_select_samples(h->view, d, stream);
+    }
     shard_view with = h->view;
     with.sel = d;
     with.sel_stride = stride_m;
+    // the psi hints, into the window lines that have room for one (line_format.h): extraction's select then needs no
+    // sample for the rows of those windows.  A hint sits where a line holds no piece of its own, behind a header bit
+    // no search reads -- but it is a write into the index: only while the owner alone holds the handle.
     unsigned long long *d_made = nullptr, made = 0;
-    if (e == hipSuccess && getenv("RSBWT_NO_PSI_HINTS") == nullptr) {
+    if (e == hipSuccess && with_hints && getenv("RSBWT_NO_PSI_HINTS") == nullptr) {
         e = hipMalloc(&d_made, sizeof made);
         if (e == hipSuccess) e = hipMemsetAsync(d_made, 0, sizeof made, stream);
         if (e == hipSuccess) e = launch_psi_hints(with, d_made, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&made, d_made, sizeof made, hipMemcpyDeviceToHost, stream);
     }
+    shard_view *dx = h->d_xview;
+    if (e == hipSuccess && !have) {
+        e = hipMalloc(&dx, sizeof(shard_view));
+        if (e == hipSuccess) e = hipMemcpyAsync(dx, &with, sizeof(shard_view), hipMemcpyHostToDevice, stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (d_made) (void)hipFree(d_made);
     if (e != hipSuccess) {
-        (void)hipFree(d);
+        if (!have) {
+            (void)hipFree(d);
+            if (dx) (void)hipFree(dx);
+        }
         return fail_hip(e, "select sample kernel");
     }
-    h->psi_hint_lines = made;
-    h->view = with;
-    h->hbm_bytes += words * sizeof(uint64_t);
-    const int rc = upload_view(h);  // (the view in HBM: the walk kernels take the samples from it)
-    if (rc != RSBWT_OK) {
-        h->view.sel = nullptr;
-        h->view.sel_stride = 0;
-        (void)hipFree(d);
-        return rc;
+    if (with_hints) h->psi_hint_lines = made;
+    if (!have) {
+        h->hbm_bytes += words * sizeof(uint64_t);
+        h->d_sel = d;
+        h->xview = with;
+        h->d_xview = dx;
+        h->x_ready.store(true, std::memory_order_release);
     }
-    h->d_sel = d;
     return RSBWT_OK;
+}
+
+// Open-time step for a shard of the PLAIN layout that will serve reads all the same (a shard opened with
+// RSBWT_OPEN_READS needs none): its select samples now, and a psi hint in every window line that has room for one
+// (about two thirds of them at the span the builder picks).  It writes into the resident lines: the owner calls it
+// BEFORE it shares the handle, like rsbwt_attach_ktab.  Without it such a shard builds its samples on its first
+// extraction -- into a side table, safely beside any other call -- and extracts without hints (more requests per step).
+int rsbwt_prepare_extraction(rsbwt_t *h) {
+    if (!h) return fail(RSBWT_EINVAL, "null handle");
+    if (h->view.n == 0 || h->view.hint_room) return RSBWT_OK;
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ctx_guard g(h->pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    return ensure_select_samples(h, g.c->st[0], true);
 }
 
 }  // extern "C"
@@ -599,7 +662,7 @@ static int mirror_batch(rsbwt_t *h, int kind, const char *syms, const uint64_t *
     hipError_t e = hipSuccess;
     if (kind == 0) e = launch_occ_batch(h->view, d_syms, d_vals, n, d_out, st);
     else if (kind == 1) e = launch_char_batch(h->view, d_vals, n, d_out, st);
-    else e = launch_occ_at_batch(h->view, d_syms, d_vals, n, d_out, st);
+    else e = launch_occ_at_batch(h->xview, d_syms, d_vals, n, d_out, st);
     if (e != hipSuccess) return fail_hip(e, "mirror kernel launch");
     HIP_OK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -1349,7 +1412,7 @@ static int extract_slices(rsbwt_t *h, call_ctx *c, const uint64_t *rows, size_t 
         uint8_t *base = (uint8_t *)c->d_stage;
         uint8_t *d_rows = base, *d_out = base + a_rows, *d_pl = d_out + a_out, *d_len = d_pl + a_len;
         HIP_OK(hipMemcpyAsync(d_rows, rows + i0, a_rows, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_extract_wave(h->scratch, h->d_view, 1, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
+        hipError_t e = launch_extract_wave(h->scratch, h->d_xview, 1, d_rows, m, d_out, stride, d_pl, d_len, h->num_cus, st);
         if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
         if ((rc = fn(i0, m, d_out, d_len, d_pl, d_len + a_len)) != RSBWT_OK) return rc;
     }
@@ -1397,7 +1460,7 @@ int rsbwt_extract_dev(rsbwt_t *h, const void *d_rows, size_t n, void *d_out, uin
         work = h->d_work;
         HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
     }
-    hipError_t e = launch_extract_wave(h->scratch, h->d_view, 1, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus,
+    hipError_t e = launch_extract_wave(h->scratch, h->d_xview, 1, d_rows, n, d_out, stride, d_prefix_len, d_len, h->num_cus,
                                        (hipStream_t)stream, work);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;

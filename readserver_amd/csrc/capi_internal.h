@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -94,8 +95,18 @@ struct rsbwt : rsb::search_meter {
     uint64_t num_runs = 0, num_strings = 0, hbm_bytes = 0;
     uint64_t far_lines = 0, chunk_windows = 0, far_windows = 0, spilled_symbols = 0;
     rsb::ctx_pool pool;
-    uint64_t *d_sel = nullptr;  // sampled select table, built on first use
-    uint64_t psi_hint_lines = 0;  // window lines that carry a psi hint (written when the samples are built)
+    // What read extraction and getOccAt read: the view PLUS the sampled select table.  `view` / `d_view` -- what every
+    // search reads -- are never written after the handle has been handed out (rsbwt_attach_ktab* apart: an explicit
+    // step of the owner's).  A shard opened with RSBWT_OPEN_READS has its samples and psi hints before that, and
+    // xview == view, d_xview == d_view.  Any other shard builds the samples on its first extraction INTO A SIDE TABLE
+    // and publishes them here (x_ready, release / acquire): its lines are not touched, searches that run meanwhile
+    // read what they always read.  psi hints go into such a shard's lines only by rsbwt_prepare_extraction, which the
+    // owner calls before it shares the handle.
+    rsb::shard_view xview;
+    rsb::shard_view *d_xview = nullptr;
+    std::atomic<bool> x_ready{false};
+    uint64_t *d_sel = nullptr;  // sampled select table
+    uint64_t psi_hint_lines = 0;  // window lines that carry a psi hint
     bool ktab_owned = true;     // false: view.ktab points into a shard set's interleaved table
     uint64_t ktab_untabulated = 0;  // grouped table: T-mers whose record leaves them to the search (empty, or a group too wide)
 };
@@ -117,7 +128,7 @@ inline bool ktab_grouped_sensible(uint64_t n, uint32_t T) {
     return T >= 2u && T <= 31u && (n >> (2u * (T - 1u))) <= 2048ull && (n >> (2u * T)) >= 64ull;
 }
 int detach_ktab(rsbwt *h);  // forgets a table it does not own
-int ensure_samples(rsbwt *h, hipStream_t stream);  // the select samples + psi hints of a shard (built once); its view then names them
+int ensure_samples(rsbwt *h, hipStream_t stream);  // the select samples of a shard (built once, into a side table): h->xview / d_xview then name them
 }  // namespace rsb
 
 #endif

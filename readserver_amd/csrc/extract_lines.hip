@@ -115,7 +115,7 @@ extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshar
     const uint64_t *__restrict__ rows = rows_all + (size_t)sid * n;
     uint8_t *__restrict__ out = out_all + (size_t)sid * n * stride;
     uint32_t *__restrict__ plen = plen_all + (size_t)sid * n;
-    unsigned long long *pool = pools + sid;
+    unsigned long long *pool = pools + (size_t)sid * POOL_STRIDE;  // (a line group apart: kernels.h)
     uint32_t ctab_lo, ctab_hi;  // C[1..4] in lanes 0..3, read with ds_bpermute
     {
         const uint64_t c1 = sv->C[1], c2 = sv->C[2], c3 = sv->C[3], c4 = sv->C[4];
@@ -341,7 +341,7 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
     uint8_t *__restrict__ out = out_all + (size_t)sid * n * stride;
     const uint32_t *__restrict__ plen = plen_all + (size_t)sid * n;
     uint32_t *__restrict__ tlen = tlen_all + (size_t)sid * n;
-    unsigned long long *pool = pools + sid;
+    unsigned long long *pool = pools + (size_t)sid * POOL_STRIDE;  // (a line group apart: kernels.h)
     bool have = false;
     row_pool rp;
     uint32_t r = 0;
@@ -757,7 +757,9 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
         return hipSuccess;
     }
     scratch_cache::lease mem;
-    const size_t pool_bytes = 2 * (size_t)nshards * sizeof(unsigned long long);
+    // (the shards' row counters a line group apart, as the search kernels' query pools are: adjacent counters are one
+    // line of one L2 channel that every wave of a small launch, and of any launch's tail, hits with atomics)
+    const size_t pool_bytes = 2 * (size_t)nshards * POOL_STRIDE * sizeof(unsigned long long);
     hipError_t e = scratch.take(pool_bytes, stream, &mem);
     if (e != hipSuccess) return e;
     unsigned long long *pool = (unsigned long long *)mem.p;
@@ -798,11 +800,11 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
     if (d_work)
         hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
-                           pool + nshards, d_work + XW_WORDS);
+                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS);
     else
         hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
-                           pool + nshards, d_work + XW_WORDS);
+                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS);
     e = hipGetLastError();
     scratch.give(mem, stream);
     return e;

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <thread>
 #include <vector>
@@ -91,7 +92,9 @@ struct dev_group : search_meter {
     int logical = 0;  // the device number its shards were opened with: what groups them (= device outside tests, capi.hip resolve_device)
     int num_cus = 256;
     std::vector<size_t> idx;         // positions in the set, ascending
-    shard_view *d_views = nullptr;   // [idx.size()] in HBM
+    shard_view *d_views = nullptr;   // [idx.size()] in HBM: what the searches read (written by make_groups and when tables are attached, never else)
+    shard_view *d_xviews = nullptr;  // the same WITH the shards' select samples, for the fused extraction: a second array, made once
+    std::atomic<bool> xviews_ready{false};
     uint64_t *d_ktab = nullptr;      // the interleaved k-mer tables of the shards this set gave one
     ctx_pool pool;
     ncclComm_t comm = nullptr;
@@ -127,7 +130,6 @@ struct rsbwt_set {
     bool owns = false;
     std::vector<dev_group *> groups;
     bool comms_tried = false, comms_ok = false;
-    bool views_name_samples = false;  // the views in HBM were published after every shard had its select samples
     std::mutex mu;
     // Collectives on the set's communicators are enqueued by one thread at a time: two callers
     // interleaving their group calls could reach the communicators in different orders.
@@ -251,6 +253,7 @@ void rsbwt_set_close(rsbwt_set_t *s) {
         if (g->peer_ready) (void)hipEventDestroy(g->peer_ready);
         if (g->peer_done) (void)hipEventDestroy(g->peer_done);
         if (g->d_views) (void)hipFree(g->d_views);
+        if (g->d_xviews) (void)hipFree(g->d_xviews);
         if (g->d_work) (void)hipFree(g->d_work);
         g->scratch.destroy();
         for (int i = 0; i < search_meter::RING; ++i) {
@@ -328,7 +331,7 @@ int rsbwt_set_open(const char *const *bwt_paths, size_t num_shards, const int *d
 // a third of it, the rule until round 4, left 8 x 20 GB shards at 13-mer tables where 15-mer ones fit), none larger
 // than 5/4 of its shard's lines, with 4^T <= the smallest shard's length; at most 16 (grouped: 17); 0 = none.
 // *fmt: in = the format asked for (KTAB_PLAIN / KTAB_GROUPED), out = the one to build (auto_ktab_depth_for).
-static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt) {
+static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt, uint64_t keep_free = 0) {
     if (use_device(g->device)) return 0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
@@ -341,19 +344,47 @@ static uint32_t auto_ktab_depth(rsbwt_set_t *s, dev_group *g, uint32_t *fmt) {
         min_bytes = std::min(min_bytes, h->hbm_bytes);
     }
     if (!need) return 0;
-    const uint64_t keep = std::max<uint64_t>(8ull << 30, free_b / 4);
+    // (keep_free: what the caller wants left of the free HBM; 0 = the set's own rule, a quarter of it and at least 8 GiB)
+    const uint64_t keep = keep_free ? keep_free : std::max<uint64_t>(8ull << 30, free_b / 4);
     const uint64_t budget = std::min<uint64_t>(min_bytes + min_bytes / 4, (free_b > keep ? free_b - keep : 0) / need);
     return auto_ktab_depth_for(budget, min_n, fmt);
 }
 
-uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {
-    if (!s) return 0;
-    uint32_t T = 16;
+// THE table-sizing rule, for every caller (rsbwt_set_open, rsbwt_set_attach_ktabs*(depth 0), bench.py, onehost.py --
+// until round 5 bench.py restated it in Python and rsbwt_set_auto_ktab_depth answered for the plain format only):
+// the depth and the format the shards of the set that have no table yet would get, one pair for the whole set (the
+// shallowest over its devices; plain if any device must).  format_in: RSBWT_KTAB_FORMAT_PLAIN / _GROUPED / _AUTO
+// (grouped where that is deeper and its records can say what four siblings hold).
+int rsbwt_set_auto_ktab(rsbwt_set_t *s, uint32_t format_in, uint64_t keep_free_bytes, uint32_t *depth, uint32_t *format_out) {
+    if (!s || !depth || !format_out) return fail(RSBWT_EINVAL, "null argument");
+    if (format_in > RSBWT_KTAB_FORMAT_AUTO) return fail(RSBWT_EINVAL, "k-mer table format %u", format_in);
+    uint32_t T = ~0u, F = KTAB_GROUPED;
     for (dev_group *g : s->groups) {
-        uint32_t fmt = KTAB_PLAIN;
-        T = std::min(T, auto_ktab_depth(s, g, &fmt));
+        uint32_t fmt = format_in == RSBWT_KTAB_FORMAT_PLAIN ? KTAB_PLAIN : KTAB_GROUPED;
+        const uint32_t t = auto_ktab_depth(s, g, &fmt, keep_free_bytes);
+        if (t < T || (t == T && fmt == KTAB_PLAIN)) {
+            if (t < T) F = fmt;
+            else F = KTAB_PLAIN;
+            T = t;
+        }
     }
-    return T;
+    if (T == ~0u) T = 0;
+    // one format for the set: a device that must take the plain format at the common depth decides it
+    if (F == KTAB_GROUPED)
+        for (dev_group *g : s->groups) {
+            uint64_t min_n = ~0ull;
+            for (size_t i : g->idx)
+                if (!s->shards[i]->view.ktab && s->shards[i]->view.n) min_n = std::min(min_n, s->shards[i]->view.n);
+            if (min_n != ~0ull && !ktab_grouped_sensible(min_n, T)) F = KTAB_PLAIN;
+        }
+    *depth = T;
+    *format_out = T >= 2u ? (F == KTAB_GROUPED ? RSBWT_KTAB_FORMAT_GROUPED : RSBWT_KTAB_FORMAT_PLAIN) : RSBWT_KTAB_FORMAT_PLAIN;
+    return RSBWT_OK;
+}
+
+uint32_t rsbwt_set_auto_ktab_depth(rsbwt_set_t *s) {  // (the plain format's depth: rsbwt_set_auto_ktab names the format too)
+    uint32_t T = 0, F = 0;
+    return rsbwt_set_auto_ktab(s, RSBWT_KTAB_FORMAT_PLAIN, 0, &T, &F) == RSBWT_OK ? T : 0u;
 }
 
 // Builds the k-mer tables of the shards that have none.  depth 0 = per device, auto_ktab_depth.  The
@@ -658,7 +689,7 @@ struct fused_1mm_layout {
     bool worklist;
     size_t wl_cap, wl, counts;
 };
-static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L) {
+static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L, bool dense = false) {
     static const bool off = getenv("RSBWT_SET_1MM_UNFUSED") != nullptr;  // A/B knob (tools/README.md)
     const size_t S = s->shards.size(), mv = m * (3 * (size_t)k + 1);
     if (off || S < 2 || S > 1024 || s->groups.size() != 1 || mv >= SIDE_BY_SIDE_BELOW || k > 32767u) return false;  // (S: a grid row per shard)
@@ -667,13 +698,19 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
         if (trace_entries(h->view, k) != tn || h->view.n == 0) return false;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     L->tn = tn;
-    L->trace = al(S * m * (size_t)tn * 16);
-    L->own = tn ? al(S * m * 16) : 0;  // the k-mers' own intervals ({lower, upper}[S][m]: nobody reads them)
     L->sparse = al(S * mv * 16);
     L->bits = al(S * hit_map_words(mv) * 8);
     L->blocks = al(S * compact_hits_block_words(mv) * 8);
     static const bool no_worklist = getenv("RSBWT_SET_1MM_NO_WORKLIST") != nullptr;  // A/B knob (tools/README.md): round 3's launches
+    static const bool no_walk = getenv("RSBWT_SET_1MM_NO_WALK") != nullptr;          // A/B knob: the traced launch + the branch kernel
     L->worklist = !no_worklist && tn > 0 && tn < k && k <= 32u && m * (size_t)tn < 0xFFFFFFFFull;
+    // the trace ([S][m][tn] intervals) and the k-mers' own intervals are what the TRACED launch leaves: the default
+    // worklist path walks the k-mers instead (search_solo.h, WALK) and touches neither (0.87 GB of scratch at 4e5
+    // 31-mers x 8 shards that the tables can have: ADVICE r04)
+    // (dense: rsbwt_set_find_intervals_1mm_dev's [S][m][3k+1] matrices -- always the traced and the resumed launch)
+    const bool traced = dense || !L->worklist || no_walk;
+    L->trace = traced ? al(S * m * (size_t)tn * 16) : 0;
+    L->own = traced && tn ? al(S * m * 16) : 0;  // the k-mers' own intervals ({lower, upper}[S][m]: nobody reads them)
     L->wl_cap = L->worklist ? m * 3u * (size_t)tn : 0;  // (a record per variant substituted left of the tables' reach, at most)
     L->wl = L->worklist ? al(S * L->wl_cap * 32) : 0;
     L->counts = L->worklist ? al(S * 8 * (size_t)WL_COUNT_STRIDE) : 0;
@@ -714,7 +751,7 @@ size_t rsbwt_set_1mm_scratch_bytes(const rsbwt_set_t *s, size_t m, uint32_t k) {
     if (!s) return 0;
     for (rsbwt_t *h : s->shards) need = std::max(need, rsbwt_1mm_scratch_bytes(h, m, k));
     fused_1mm_layout L;
-    if (fused_1mm_applies(s, m, k, &L)) need = std::max(need, ((variants_bytes(m, k) + 255) & ~(size_t)255) + L.trace + L.own);
+    if (fused_1mm_applies(s, m, k, &L, true)) need = std::max(need, ((variants_bytes(m, k) + 255) & ~(size_t)255) + L.trace + L.own);
     return need;
 }
 
@@ -726,7 +763,7 @@ static int rsbwt_set_find_intervals_1mm_dev_body(rsbwt_set_t *s, const void *d_p
     if (!d_lower || !d_upper) return fail(RSBWT_EINVAL, "null argument");
     const size_t row = m * (3 * (size_t)k + 1) * 8;
     fused_1mm_layout L;
-    if (fused_1mm_applies(s, m, k, &L)) {
+    if (fused_1mm_applies(s, m, k, &L, true)) {
         if (!d_packed || !d_valid || !d_scratch) return fail(RSBWT_EINVAL, "null argument");
         dev_group *g = s->groups[0];
         int rc = use_device(g->device);
@@ -1107,22 +1144,29 @@ int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_
     }
     int rc = use_device(g->device);
     if (rc) return rc;
-    // ONE launch sequence walks the rows of every shard (extract_lines.hip: a wave walks one shard at a time); the
-    // shards' views in HBM must name their select samples -- built here for a shard that has none yet
-    {
+    // ONE launch sequence walks the rows of every shard (extract_lines.hip: a wave walks one shard at a time) off views
+    // that name the shards' select samples: an array of its own (d_xviews), made on the first call from the shards'
+    // extraction views -- the array the searches read (d_views) is not touched, so an extraction may start beside
+    // searches on the same set
+    if (!g->xviews_ready.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(s->mu);
-        bool stale = false;
-        for (size_t i = 0; i < S; ++i) {
-            rsbwt_t *h = s->shards[i];
-            if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
-            if (!h->view.sel) {
+        if (!g->xviews_ready.load(std::memory_order_relaxed)) {
+            std::vector<shard_view> v;
+            for (size_t i = 0; i < S; ++i) {
+                rsbwt_t *h = s->shards[i];
+                if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
                 if ((rc = ensure_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
-                stale = true;
+                v.push_back(h->xview);
             }
-        }
-        if (stale || !s->views_name_samples) {
-            if ((rc = publish_views(s)) != RSBWT_OK) return rc;
-            s->views_name_samples = true;
+            shard_view *dx = nullptr;
+            HIP_OK(hipMalloc(&dx, v.size() * sizeof(shard_view)));
+            const hipError_t e = hipMemcpy(dx, v.data(), v.size() * sizeof(shard_view), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(dx);
+                return fail_hip(e, "publishing the extraction views");
+            }
+            g->d_xviews = dx;
+            g->xviews_ready.store(true, std::memory_order_release);
         }
     }
     unsigned long long *work = nullptr;
@@ -1130,7 +1174,7 @@ int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_
         work = g->d_work;
         HIP_OK(hipMemsetAsync(work, 0, WORK_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
     }
-    const hipError_t e = launch_extract_wave(g->scratch, g->d_views, (uint32_t)S, d_rows, n, d_out, stride, d_prefix_len, d_len, g->num_cus,
+    const hipError_t e = launch_extract_wave(g->scratch, g->d_xviews, (uint32_t)S, d_rows, n, d_out, stride, d_prefix_len, d_len, g->num_cus,
                                              (hipStream_t)stream, work);
     if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
     return RSBWT_OK;

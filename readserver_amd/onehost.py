@@ -76,6 +76,13 @@ class OneProcessHost:
     def auto_table_depth(self):
         return min(int(self.L.rsbwt_set_auto_ktab_depth(ss._s)) for ss in self.subsets)
 
+    def auto_tables(self, fmt=2, keep_free_bytes=0):
+        """(depth, format) for the whole job by the library's rule (rsbwt_set_auto_ktab over the spanning set): the
+        shallowest any device can hold, plain if any must.  fmt: RSBWT_KTAB_FORMAT_PLAIN (0) / _GROUPED (1) / _AUTO (2)"""
+        d, f = C.c_uint32(), C.c_uint32()
+        check(self.L.rsbwt_set_auto_ktab(self.spanning._s, fmt, keep_free_bytes, C.byref(d), C.byref(f)))
+        return int(d.value), int(f.value)
+
     def step(self, d_kmers_by_device):
         """One batch: d_kmers_by_device[g] = the [Q][k] ASCII k-mers, resident on device g."""
         i, L, Q, k = self.steps, self.L, self.Q, self.k

@@ -40,6 +40,8 @@ def load():
     L.rso_extract_postfix.restype = C.c_size_t
     L.rso_extract_postfix.argtypes = [_vp, C.c_uint64, C.c_char_p, C.c_size_t]
     L.rso_find_intervals.argtypes = [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, _vp, C.c_int]
+    L.rso_extract_batch.restype = None
+    L.rso_extract_batch.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int]
     return Oracle(L)
 
 
@@ -93,6 +95,16 @@ class OracleIndex:
         self.L.rso_find_intervals(self.h, a.ctypes.data, Q, k, k, lo.ctypes.data, up.ctypes.data,
                                   st.ctypes.data if want_steps else None, nthreads)
         return (lo, up, st) if want_steps else (lo, up)
+
+    def extract_batch(self, rows, stride=512, nthreads=1):
+        """extractPrefix + extractPostfix of every row over `nthreads` threads: ([n][stride] bytes, lengths
+        (UINT32_MAX: longer than stride), prefix lengths)"""
+        r = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((r.size, stride), np.uint8)
+        ln = np.empty(r.size, np.uint32)
+        pl = np.empty(r.size, np.uint32)
+        self.L.rso_extract_batch(self.h, r.ctypes.data, r.size, out.ctypes.data, stride, ln.ctypes.data, pl.ctypes.data, nthreads)
+        return out, ln, pl
 
     def extract(self, row, cap=4096):
         buf = C.create_string_buffer(cap)

@@ -13,15 +13,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--runs", "3e8", "--shards-per-gpu", "2", "--steps", "2", "--warmup", "1"]
 
 
-def _run(args, timeout=600, more_env=None):
+def _run(args, timeout=600, more_env=None, lines_expected=1):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(more_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
                          timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == lines_expected, out.stdout[-2000:]
+    if lines_expected == 2:
+        # an N > 1 run of the exact search: the headline line BEFORE the one-process leg, and again with the leg's record
+        # (VERDICT r04 next #1a) -- the same line but for config.cxx_host
+        first, last = json.loads(lines[0]), json.loads(lines[1])
+        assert "pending" in first["config"]["cxx_host"] and "pending" not in last["config"]["cxx_host"]
+        assert first["value"] == last["value"] and first["roofline"] == last["roofline"]
+        a, b = dict(first["config"]), dict(last["config"])
+        a.pop("cxx_host"), b.pop("cxx_host")
+        assert a == b
+    return json.loads(lines[-1])
 
 
 def _common(d, n_gpus):
@@ -78,10 +87,14 @@ def test_gpu_bench_1mm_by_the_traced_launch_and_the_branch_kernel():
 
 def test_gpu_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher (here: the two ranks share the one GPU and gather over gloo)."""
-    d = _run(SMALL + ["--queries", "2e5", "--gpus", "2", "--rehearse-on-one-gpu"])
+    d = _run(SMALL + ["--queries", "2e5", "--gpus", "2", "--rehearse-on-one-gpu"], lines_expected=2)
     _common(d, 2)
     assert d["config"]["gather_verified"] is True and "REHEARSAL" in d["config"]["multi_gpu"]
     assert d["config"]["shards"] == 4
+    leg = d["config"]["cxx_host"]  # (the second leg ran -- on one device here -- inside what was left of the run's budget)
+    assert "error" not in leg and leg["value"] > 0 and leg["leg_seconds"] <= leg["leg_limit_seconds"] <= 420.0
+    p = d["config"]["hbm_plan"]   # (rank 0's plan: its two batches of gathered blocks at N = 2)
+    assert p["world"] == 2 and p["rank"] == 0 and p["gathered"] > 0 and p["unit"] == "GB"
 
 
 @pytest.mark.parametrize("mode,extra,key", [("1mm", ["--kmers", "2e4"], "hit_lists_verified"), ("extract", ["--rows", "1e5"], "reads_verified")])

@@ -353,7 +353,9 @@ def test_gpu_set_split_over_two_devices_equals_one_device(rsb, oracle, tmp_path,
 @pytest.mark.parametrize("style,span", [("pop", 0), ("pop", 300), ("mixed", 0), ("mixed", 1024), ("dense", 90), ("long", 0)])
 def test_gpu_psi_hints_change_nothing_but_the_requests(rsb, oracle, style, span):
     """Window lines with room for it carry a psi hint (where psi takes the rows of the window: csrc/line_format.h),
-    written into the resident index when a shard's select samples are built.  It must (1) leave every other answer
+    written into the resident index by rsbwt_prepare_extraction (the owner's open-time step for a plain-layout shard
+    that will serve reads; a first extraction WITHOUT it builds the samples into a side table and leaves the lines
+    alone: no hints).  It must (1) leave every other answer
     as it was -- Occ at every position, getChar, getOccAt, findInterval with and without the table, the 1-mismatch
     matrices: the hint sits in piece bytes and behind a header bit no reader may take for data; (2) give the same
     reads as the walk without hints (RSBWT_NO_PSI_HINTS) and as the oracle."""
@@ -380,16 +382,14 @@ def test_gpu_psi_hints_change_nothing_but_the_requests(rsb, oracle, style, span)
         assert L.rsbwt_extract(g.handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
         return out, ln, pl
 
-    os.environ["RSBWT_NO_PSI_HINTS"] = "1"
-    try:
-        with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as plain:
-            o0, l0, p0 = extract(plain)
-            assert L.rsbwt_psi_hint_lines(plain.handle) == 0
-    finally:
-        del os.environ["RSBWT_NO_PSI_HINTS"]
+    with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as plain:
+        o0, l0, p0 = extract(plain)  # (samples into a side table; the lines stay as the open left them)
+        assert L.rsbwt_psi_hint_lines(plain.handle) == 0
     with rsb.GpuBWT(runs=runs, window_span=span, ktab_depth=6) as g:
         before = rsb.find_intervals(g, km)
-        o1, l1, p1 = extract(g)  # builds the samples and writes the hints
+        assert L.rsbwt_prepare_extraction(g.handle) == 0  # builds the samples and writes the hints
+        assert L.rsbwt_prepare_extraction(g.handle) == 0  # (again: nothing to do)
+        o1, l1, p1 = extract(g)
         hints = L.rsbwt_psi_hint_lines(g.handle)
         S = g.window_span()
         if S <= 1024 and style != "dense":
@@ -769,3 +769,93 @@ def test_gpu_set_table_format_auto_and_set_open_flag(rsb, oracle, tmp_path):
         assert d0 >= 2 and d0 == L.rsbwt_ktab_depth(L.rsbwt_set_shard(h, 1))
     finally:
         L.rsbwt_set_close(h)
+
+
+def test_gpu_first_extraction_beside_searches_writes_nothing_a_search_reads(rsb, oracle, monkeypatch):
+    """VERDICT r04 next #8 / ADVICE: a handle of the PLAIN layout used to be mutated by its first extraction -- its host
+    view reassigned, the view in HBM re-uploaded, psi hints written into the resident lines -- while searches on other
+    threads read all three without a lock.  Now the first extraction (and a set's first fused extraction) builds the
+    select samples into a side table and publishes them in an extraction view of its own: the lines are byte for byte
+    what rsbwt_open left (rsbwt_debug_peek), rsbwt_psi_hint_lines stays 0, and searches that run WHILE it happens
+    answer as they did before.  (rsbwt_prepare_extraction is the explicit, owner-only way to get hints into a plain
+    shard: test_gpu_psi_hints_change_nothing_but_the_requests.)"""
+    import hashlib
+    import threading
+    import torch
+    monkeypatch.setenv("RSBWT_ENABLE_TEST_HOOKS", "1")
+    L = rsb.lib()
+    rng = np.random.default_rng(77)
+    shards, oixs = [], []
+    for i, R in enumerate((400000, 250000)):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, (1 << 62) | (900 + i)) == 0
+        shards.append(rsb.GpuBWT(runs=runs, ktab_depth=8))
+        oixs.append(oracle.from_runs(runs))
+    ss = rsb.ShardSet(shards)
+
+    def lines_digest(g):
+        nb = g.num_lines() * 128
+        buf = np.empty(nb, np.uint8)
+        assert L.rsbwt_debug_peek(g.handle, 0, 0, buf.ctypes.data, nb) == 0, L.rsbwt_last_error()
+        return hashlib.sha256(buf.tobytes()).hexdigest()
+    before = [lines_digest(g) for g in shards]
+    km = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (40000, 31))].copy()
+    want = [o.find_intervals(km, nthreads=4) for o in oixs]
+    stop = threading.Event()
+    errs, rounds = [], [0]
+
+    def searcher(t):
+        try:
+            while not stop.is_set():
+                lo, up = ss.find_intervals(km[t::4])
+                for s_ in range(2):
+                    assert np.array_equal(lo[s_], want[s_][0][t::4]) and np.array_equal(up[s_], want[s_][1][t::4])
+                lo, up = rsb.find_intervals(shards[t % 2], km[t::4])
+                assert np.array_equal(lo, want[t % 2][0][t::4]) and np.array_equal(up, want[t % 2][1][t::4])
+                rounds[0] += 1
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+    th = [threading.Thread(target=searcher, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    try:
+        # the FIRST extraction of shard 0 (host rows), the first getOccAt of shard 1, the set's first fused extraction
+        rows = rng.integers(0, oixs[0].bwlen(), 3000).astype(np.uint64)
+        out = np.zeros((rows.size, 1024), np.uint8)
+        ln, pl = np.empty(rows.size, np.uint32), np.empty(rows.size, np.uint32)
+        assert L.rsbwt_extract(shards[0].handle, rows.ctypes.data, rows.size, out.ctypes.data, 1024, ln.ctypes.data, pl.ctypes.data) == 0
+        t_tot = oixs[1].occ("T", oixs[1].bwlen() - 1)
+        bc = rng.integers(1, t_tot + 1, 2000).astype(np.uint64)
+        idx = shards[1].occ_at_batch("T", bc)
+        nmin = min(o.bwlen() for o in oixs)
+        rows2 = rng.integers(0, nmin, (2, 2000)).astype(np.int64)
+        d_rows = torch.from_numpy(rows2).cuda()
+        d_out = torch.zeros((2, 2000, 512), dtype=torch.uint8, device="cuda")
+        d_len = torch.empty((2, 2000), dtype=torch.int32, device="cuda")
+        d_pl = torch.empty((2, 2000), dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        st = torch.cuda.Stream()
+        assert L.rsbwt_set_extract_dev(ss._s, p(d_rows), 2000, p(d_out), 512, p(d_len), p(d_pl), C.c_void_p(st.cuda_stream)) == 0
+        st.synchronize()
+    finally:
+        stop.set()
+        [t.join() for t in th]
+    assert not errs, errs
+    assert rounds[0] >= 1
+    for i in range(0, rows.size, 7):
+        if ln[i] != 0xFFFFFFFF:
+            pre, post = oixs[0].extract(int(rows[i]), cap=4096)
+            assert out[i, :ln[i]].tobytes().decode() == pre + post and pl[i] == len(pre)
+    assert all(int(idx[j]) == oixs[1].occ_at("T", int(bc[j])) for j in range(0, bc.size, 13))
+    xl = d_len.cpu().numpy().view(np.uint32)
+    xo = d_out.cpu().numpy()
+    for s_ in range(2):
+        for i in range(0, 2000, 11):
+            if xl[s_, i] != 0xFFFFFFFF:
+                pre, post = oixs[s_].extract(int(rows2[s_, i]), cap=4096)
+                assert xo[s_, i, :xl[s_, i]].tobytes().decode() == pre + post
+    # nothing a search reads was written
+    assert [lines_digest(g) for g in shards] == before
+    assert all(L.rsbwt_psi_hint_lines(g.handle) == 0 and L.rsbwt_opened_for_reads(g.handle) == 0 for g in shards)
+    ss.close()
+    for g in shards:
+        g.close()

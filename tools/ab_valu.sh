@@ -26,7 +26,7 @@ rec = {"build": sys.argv[3], "kernel_ms": r["kernel_ms"], "ms_per_step": b["ms_p
 if os.path.exists(sys.argv[2]):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(sys.argv[2])):
-        if "search_lines_kernel<false, false, false, 0>" in row["Kernel_Name"]:
+        if "search_lines_kernel<false, false, false, 0>" in row["Kernel_Name"] or "search_solo_kernel<false, false, false, false, false, false>" in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     rec["pmc_mean_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
     p = rec["pmc_mean_per_launch"]

@@ -24,10 +24,14 @@ MIX = sys.argv[6] if len(sys.argv) > 6 else "population"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_sha: the figure is only valid for the sources it was measured on)
-KERNEL = "search_lines_kernel<false, false, false, 0>"
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, "stats", "p_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+# the kernel the fused query launches ran on: one lane per search behind deep tables (round 5: also with several shards
+# per launch), lane pairs otherwise -- whichever the trace shows
+_names = open(os.path.join(src, "stats", "p_kernel_stats.csv")).read()
+KERNEL = ("search_solo_kernel<false, false, false, false, false, false>" if "search_solo_kernel<false, false, false, false, false, false>" in _names
+          else "search_lines_kernel<false, false, false, 0>")
 counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
     agg = collections.defaultdict(list)

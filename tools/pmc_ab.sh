@@ -21,7 +21,7 @@ for lib in "$@"; do
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "search_lines_kernel<false, false, false, 0>" in r["Kernel_Name"]:
+    if "search_lines_kernel<false, false, false, 0>" in r["Kernel_Name"] or "search_solo_kernel<false, false, false, false, false, false>" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(f"{sys.argv[2].split('/')[-1]:16s} {k:36s} {sum(v)/len(v):.6g}")

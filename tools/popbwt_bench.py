@@ -280,6 +280,7 @@ def run(a, log=sys.stderr):
     ok(L.rsbwt_set_last_search_counters(sset._s, w))
     ok(L.rsbwt_set_set_counting(sset._s, 0))
     lf, oc, ln = int(w[0]), int(w[1]), int(w[2])
+    kernel_name = "search_solo_kernel" if int(w[12]) else "search_lines_kernel"  # (WORK_SOLO: which kernel the launch ran on)
     width = torch.clamp(d_pairs[..., 1] - d_pairs[..., 0] + 1, min=0)
     gen_present = (width[:, 0::2] > 0).float()
     frac_shards = float(gen_present.mean().item())
@@ -426,7 +427,7 @@ def run(a, log=sys.stderr):
         "extraction_of_the_rows_of_the_genomic_intervals": rows_rec, "one_mismatch_hit_lists": mm_rec,
         "searches_per_s": S * Q / dt, "queries_per_s": Q / dt, "ms_per_step": dt * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "search_lines_kernel", "kernel_ms": kms,
+                     "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_name, "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": alg, "line_reads_per_launch": ln},
     }
     sset.close()

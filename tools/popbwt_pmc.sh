@@ -18,7 +18,7 @@ res = {}
 for f in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "search_lines_kernel<false, false, false, 0>" in r["Kernel_Name"]:
+        if "search_lines_kernel<false, false, false, 0>" in r["Kernel_Name"] or "search_solo_kernel<false, false, false, false, false, false>" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         v = sorted(v)
