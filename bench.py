@@ -68,7 +68,7 @@ def parse():
                     help="fourth leg of a one-GPU run: the same search on a VALID population BWT of the DEPTH north_star names -- the "
                          "reads of ~2,700 genomes in every shard (512 haplotypes, 420x per shard: tools/popbwt_bench.py --depth 420 "
                          "--haplotypes 512), a genomic 31-mer's final interval tens of rows wide -- this many symbols per shard (8 "
-                         "shards); 0 = skip; default: 1.5e9 (1.2e10 symbols in all, ~50 s to build) on a full-size run")
+                         "shards); 0 = skip; default: 3e9 (1.4e10 symbols in all after dedup, ~55 s to build) on a full-size run")
     ap.add_argument("--two-streams", action="store_true",
                     help="N = 1: batches alternate between two streams (buffers of their own), so that batch i + 1's packing, start "
                          "records and ramp run under batch i's tail -- what two of a service's pool threads calling the handle do")
@@ -795,7 +795,7 @@ def main():
                 }
             except Exception as e:  # the headline stands whatever happens to this leg
                 mixes["valid_popbwt"] = {"error": repr(e)}
-        dsym = a.deep_popbwt_symbols if a.deep_popbwt_symbols >= 0 else (1.5e9 if a.runs >= 1e10 else 0)
+        dsym = a.deep_popbwt_symbols if a.deep_popbwt_symbols >= 0 else (3e9 if a.runs >= 1e10 else 0)
         if world == 1 and dsym > 0 and not a.no_second_mix and not a.counts and S > 1:
             # the population north_star quotes its target on (~2.7k genomes): every shard holds the reads of 512 haplotypes at
             # 420x, so a genomic 31-mer ends on an interval tens of rows wide and the two ends of an interval part ways more

@@ -883,11 +883,11 @@ int search_launch_walk(search_meter &m, const shard_view *d_views, uint32_t nsha
 
 int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                            const void *d_valid, size_t nkmers, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
-                           uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream) {
+                           uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream, const void *d_pre) {
     std::lock_guard<std::mutex> lock(m.mu);
     const int slot = (int)(m.launches % search_meter::RING);
     hipError_t e = launch_search_worklist(m.scratch, d_views, nshards, d_packed, d_valid, nkmers, tn, d_worklists, d_counts, wl_cap, k, d_sparse,
-                                          d_hit_bits, m.counting ? m.d_work : nullptr, num_cus, stream, m.ev_start[slot], m.ev_stop[slot]);
+                                          d_hit_bits, m.counting ? m.d_work : nullptr, num_cus, stream, m.ev_start[slot], m.ev_stop[slot], d_pre);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail_hip(e, "worklist search kernel launch");

@@ -71,7 +71,7 @@ inline bool view_is_narrow(const shard_view &v, uint32_t k) {
 // onto what the traced launch and the branch kernel left
 int search_launch_worklist(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,
                            const void *d_valid, size_t nkmers, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
-                           uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream);
+                           uint32_t k, void *d_sparse, void *d_hit_bits, hipStream_t stream, const void *d_pre = nullptr);
 // the walk that makes those worklists (kernels.h, launch_search_walk), metered like search_launch: a counting launch
 // ZEROES the counters first (it is the first launch of the sequence)
 int search_launch_walk(search_meter &m, const shard_view *d_views, uint32_t nshards, int num_cus, const void *d_packed,

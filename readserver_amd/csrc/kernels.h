@@ -107,10 +107,13 @@ hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, co
                                 uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,
                                 void *d_counts, void *d_sparse, void *d_hit_bits, int num_cus, hipStream_t stream,
                                 unsigned long long *d_branch_work = nullptr);
+// (d_pre, optional: the implicit items' table entries read ahead by launch_wl_table_entries, u64 [nshards][m * 3 (k - tn)])
 hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                                   const void *d_valid, size_t m, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
                                   uint32_t k, void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus,
-                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const void *d_pre = nullptr);
+hipError_t launch_wl_table_entries(const shard_view *d_shards, uint32_t nshards, const void *d_packed, size_t m, uint32_t k, uint32_t tn,
+                                   void *d_pre, hipStream_t stream);
 // launch_search_walk replaces the traced launch and launch_mm1_worklists' branch kernel by ONE walk of the k-mers
 // (search_solo.h, WALK): the k-mers' own intervals to d_sparse / d_hit_bits at their canonical indices, the variants
 // that survive the step of their position appended to d_worklists (d_counts zeroed by the caller), no trace.

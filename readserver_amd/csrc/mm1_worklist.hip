@@ -47,6 +47,42 @@ __global__ void wl_init_counts_kernel(unsigned long long *__restrict__ counts, u
     if (i < nshards) counts[(size_t)i * WL_COUNT_STRIDE] = first;
 }
 
+// ---- 3'. (round 5, optional: RSBWT_SET_1MM_TABLE_PREPASS) the table entries of the variants substituted INSIDE the
+// tables' reach, read ahead for ALL the shards of the device.  Item i = variant r = i % 3T of k-mer q = i / 3T, as
+// search_solo_kernel<WL> numbers its implicit items.  The S shards' records of one variant lie side by side in the
+// interleaved tables -- one stretch of 12 S (8 S) bytes -- but the search kernel reads them from S different waves on S
+// different XCDs at S different times: the same line crosses the fabric up to S times (PMC: 86.7 GB of traffic against
+// 74.5 algorithmic per 4e5 31-mers x 8 shards, profiles/r04d_1mm_pmc.json).  Here adjacent lanes = the shards of one
+// item read the stretch ONCE; the block's V x S entries are turned round in LDS and leave as plain 8-byte entries
+// pre[s][i], which the search kernel then reads in item order (coalesced) instead of the table.
+__global__ void __launch_bounds__(256)
+wl_table_entries_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed, size_t items,
+                        uint32_t k, uint32_t tn, uint32_t V, uint64_t *__restrict__ pre) {
+    __shared__ uint64_t tile[256];
+    const size_t i0 = (size_t)blockIdx.x * V;
+    const uint32_t t = threadIdx.x;
+    {
+        const uint32_t v = t / nshards, s = t - v * nshards;
+        if (v < V && i0 + v < items) {
+            const shard_view &ix = shards[s];
+            const uint32_t T = ix.ktab_depth, per = 3u * (k - tn);
+            const uint32_t i32 = (uint32_t)(i0 + v), q = i32 / per, r = i32 - q * per;
+            const uint32_t pr = r / 3u, d = r - 3u * pr, p = tn + pr;
+            const uint64_t word = packed[q];
+            const uint32_t orig = (uint32_t)((word >> (2u * p)) & 3u);
+            const uint32_t alt = d < orig ? d : d + 1u;
+            const uint64_t vword = word ^ ((uint64_t)(orig ^ alt) << (2u * p));
+            const uint64_t code = (vword >> (2u * tn)) & ((1ull << (2u * T)) - 1ull);
+            tile[v * nshards + s] = ktab_entry(ix.ktab, ix.ktab_fmt, T, ix.ktab_stride, code);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t s = t / V, v = t - s * V;
+        if (s < nshards && i0 + v < items) pre[(size_t)s * items + i0 + v] = tile[v * nshards + s];
+    }
+}
+
 // ---- 5. variant 0 = the k-mer itself: its traced search's result
 __global__ void __launch_bounds__(256)
 wl_own_kernel(const ulonglong2 *__restrict__ own, const uint8_t *__restrict__ valid, uint32_t nshards, size_t m, uint32_t k,
@@ -217,6 +253,17 @@ wl_branch_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const 
 }
 
 }  // namespace
+
+hipError_t launch_wl_table_entries(const shard_view *d_shards, uint32_t nshards, const void *d_packed, size_t m, uint32_t k, uint32_t tn,
+                                   void *d_pre, hipStream_t stream) {
+    const size_t items = m * 3u * (size_t)(k - tn);
+    if (items == 0 || nshards == 0) return hipSuccess;
+    if (nshards > 256u || k > 32u || tn >= k || items > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t V = 256u / nshards;
+    hipLaunchKernelGGL(wl_table_entries_kernel, dim3((unsigned)((items + V - 1) / V)), dim3(256), 0, stream, d_shards, nshards,
+                       (const uint64_t *)d_packed, items, k, tn, V, (uint64_t *)d_pre);
+    return hipGetLastError();
+}
 
 hipError_t launch_mm1_worklists(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t m,
                                 uint32_t k, uint32_t tn, const void *d_trace, const void *d_own, void *d_worklists, size_t wl_cap,

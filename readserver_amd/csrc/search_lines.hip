@@ -36,21 +36,6 @@ constexpr uint64_t INIT_INVALID = 1ull << 63;   // symbol outside ACGT: result (
 constexpr uint64_t INIT_FALLBACK = 1ull << 62;  // not from the k-mer table: continue at symbol k-2
 constexpr uint64_t INIT_EXPLICIT = 1ull << 61;  // continue at the symbol named in bits 40..55 (1-mismatch variants)
 
-__device__ __forceinline__ bool view_uses_ktab(const shard_view &ix, uint32_t k) {
-    return ix.ktab != nullptr && ix.ktab_depth >= 2u && k >= ix.ktab_depth;
-}
-
-// Entry of T-mer `code` in the plain table's 8-byte form, whatever the table's format (line_format.h)
-__device__ __forceinline__ uint64_t ktab_entry(const uint64_t *__restrict__ ktab, uint32_t fmt, uint32_t T, uint32_t stride, uint64_t code) {
-    if (fmt == KTAB_GROUPED) {
-        const uint32_t gbits = 2u * (T - 1u);
-        const uint64_t g = code & ((1ull << gbits) - 1ull);
-        const uint32_t *r = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ktab) + g * stride * (uint64_t)KTAB_GROUP_BYTES);
-        return ktab_group_entry(r[0], r[1], r[2], (uint32_t)(code >> gbits) & 3u);
-    }
-    return ktab[code * stride];
-}
-
 __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const uint64_t *pq, uint32_t k) {
     ulonglong2 rec;
     const uint64_t last = pq[(k - 1u) >> 5];
@@ -775,7 +760,7 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
 hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                                   const void *d_valid, size_t m, uint32_t tn, const void *d_worklists, const void *d_counts, size_t wl_cap,
                                   uint32_t k, void *d_sparse, void *d_hit_bits, unsigned long long *d_work, int num_cus,
-                                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const void *d_pre) {
     if (nshards == 0 || m == 0) return hipSuccess;
     if (k > 32u || tn == 0 || tn >= k) return hipErrorInvalidValue;
     static const int wgs_per_cu = [] {
@@ -797,17 +782,26 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
         return e;
     }
     if (ev0) (void)hipEventRecord(ev0, stream);
+    // (the table entries of the implicit items read ahead for all shards: inside this launch's event pair, so that the
+    // time the library reports for the worklist search includes it)
+    if (d_pre) {
+        e = launch_wl_table_entries(d_shards, nshards, d_packed, m, k, tn, const_cast<void *>(d_pre), stream);
+        if (e != hipSuccess) {
+            scratch.give(mem, stream);
+            return e;
+        }
+    }
     uint32_t qchunk = 1024;
     while (qchunk > 64u && (size_t)qchunk * g * WG_WAVES * 4u > implicit * nshards) qchunk >>= 1;
     if (d_work)
         hipLaunchKernelGGL((search_solo_kernel<true, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
                            nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, mv, k, 1u,
-                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)const_cast<void *>(d_pre), tn, qchunk, 2u,
                            (const unsigned long long *)d_counts, wl_cap, implicit);
     else
         hipLaunchKernelGGL((search_solo_kernel<false, false, false, false, true>), dim3((unsigned)g), dim3(64 * WG_WAVES), 0, stream, d_shards,
                            nshards, (const uint64_t *)d_packed, (const ulonglong2 *)d_worklists, (const uint8_t *)d_valid, ctr, mv, k, 1u,
-                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)nullptr, tn, qchunk, 2u,
+                           (uint64_t *)d_sparse, (uint64_t *)d_hit_bits, d_work, (ulonglong2 *)const_cast<void *>(d_pre), tn, qchunk, 2u,
                            (const unsigned long long *)d_counts, wl_cap, implicit);
     e = hipGetLastError();
     if (ev1) (void)hipEventRecord(ev1, stream);

@@ -93,6 +93,9 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         if (visited != 0u && __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)Qs) continue;  // (search_lines_kernel: drained already)
         // per shard, as in search_lines_kernel: traces [s][Q][trace_n], hit maps [s][hit_map_words(Q)]
         ulonglong2 *trace_s = (trace && !WL) ? trace + (size_t)sid * Q * trace_n : nullptr;
+        // WL: `trace` carries the implicit items' table entries read ahead for this shard (mm1_worklist.hip,
+        // wl_table_entries_kernel: u64 [nshards][wl_implicit]), or nullptr = the lane reads the table itself
+        const uint64_t *wl_pre = (WL && trace) ? reinterpret_cast<const uint64_t *>(trace) + (size_t)sid * wl_implicit : nullptr;
         unsigned long long *hit_map = pairs == 2u ? reinterpret_cast<unsigned long long *>(out_upper) + (size_t)sid * hit_map_words(WALK ? walk_mv : Q) : nullptr;
         // C[1..4] in lanes 0..3, picked with ds_bpermute (scalar loads: see search_lines_kernel)
         uint32_t ctab_lo, ctab_hi;
@@ -281,7 +284,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     const uint32_t alt = d_ < orig ? d_ : d_ + 1u;
                     vword = nword ^ ((uint64_t)(orig ^ alt) << (2u * p_));
                     const uint64_t code = (vword >> (2u * wl_tn)) & ((1ull << (2u * ktab_T)) - 1ull);
-                    entry = ktab_entry(ktab_p, ktab_fmt, ktab_T, ktab_stride, code);
+                    entry = wl_pre ? wl_pre[nq] : ktab_entry(ktab_p, ktab_fmt, ktab_T, ktab_stride, code);
                 }
             } else if (FUSED) {
                 if (got_n) {
@@ -316,7 +319,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         altL0 = altL1 = altL2 = altU0 = altU1 = altU2 = 0;
                     }
                     // traced search (1-mismatch): the interval this query has when about to take symbol j
-                    if (trace && (uint32_t)j < trace_n) trace_s[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
+                    if (trace_s && (uint32_t)j < trace_n) trace_s[q * trace_n + (uint32_t)j] = make_ulonglong2(lo, hi);
                     if (lo == 0ull) {  // Occ(b, -1) = 0 (rlebwt.cpp:269)
                         occL = 0;
                         sub = 1u;
@@ -578,7 +581,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 if (WL && !imp) nq = (size_t)wl_index;  // from here on the search is known by its result index
             }
             if (alive && done) {
-                if (trace) {
+                if (trace_s) {  // (WL: `trace` carries the table entries read ahead, not a trace)
                     // the positions it never reached: a search resumed there ends where this one did
                     for (int jj = j < (int)trace_n ? j : (int)trace_n - 1; jj >= 0; --jj)
                         trace_s[q * trace_n + (uint32_t)jj] = make_ulonglong2(lo, hi);

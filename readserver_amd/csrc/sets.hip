@@ -29,6 +29,10 @@
 
 using namespace rsb;
 
+#ifndef RSB_1MM_TABLE_PREPASS_DEFAULT
+#define RSB_1MM_TABLE_PREPASS_DEFAULT true
+#endif
+
 namespace {
 
 #define HIP_OK(x)                                              \
@@ -681,6 +685,18 @@ static size_t side_by_side_below() {
 // one of S * m * (3k+1) in a launch that fills the GPU where a shard's own m * (3k+1) do not, and the set's tails
 // are one tail.  Needs what the fused exact search needs -- one device -- and one trace length for all shards (k-mer
 // tables of one depth: rsbwt_set_attach_ktabs gives every shard of a device the same).
+// The table entries of the variants inside the tables' reach are read ahead for all shards by a kernel of their own
+// (mm1_worklist.hip, wl_table_entries_kernel) instead of by the search kernel's lanes: the S shards' records of a variant
+// are ONE stretch of the interleaved tables, which S waves on S XCDs otherwise fetch S times (round 5: 14.07 -> 13.60 ms
+// per 4e5 31-mers x 8 shards, 1.74 -> 1.69 at 4e4; round 4 measured the same idea 2 % SLOWER -- the search kernel it
+// relieved was then bound by instruction issue, not by requests).  RSBWT_SET_1MM_TABLE_PREPASS=0: A/B knob (tools/README.md)
+static bool table_prepass() {
+    static const bool on = [] {
+        const char *e = getenv("RSBWT_SET_1MM_TABLE_PREPASS");
+        return e ? atoi(e) != 0 : RSB_1MM_TABLE_PREPASS_DEFAULT;
+    }();
+    return on;
+}
 struct fused_1mm_layout {
     uint32_t tn;
     size_t trace, own, sparse, bits, blocks, total;  // byte sizes of the parts behind the variants, each 256-aligned
@@ -688,6 +704,7 @@ struct fused_1mm_layout {
     // searches are records of live searches (a record per variant at most), no variants spelled out, no start records
     bool worklist;
     size_t wl_cap, wl, counts;
+    size_t pre;  // the table-part variants' entries read ahead for all shards (RSBWT_SET_1MM_TABLE_PREPASS): u64 [S][m * 3 (k - tn)], or 0
 };
 static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_1mm_layout *L, bool dense = false) {
     static const bool off = getenv("RSBWT_SET_1MM_UNFUSED") != nullptr;  // A/B knob (tools/README.md)
@@ -714,7 +731,8 @@ static bool fused_1mm_applies(const rsbwt_set_t *s, size_t m, uint32_t k, fused_
     L->wl_cap = L->worklist ? m * 3u * (size_t)tn : 0;  // (a record per variant substituted left of the tables' reach, at most)
     L->wl = L->worklist ? al(S * L->wl_cap * 32) : 0;
     L->counts = L->worklist ? al(S * 8 * (size_t)WL_COUNT_STRIDE) : 0;
-    L->total = L->trace + L->own + L->sparse + L->bits + L->blocks + L->wl + L->counts;
+    L->pre = (L->worklist && table_prepass() && S <= 256) ? al(S * m * 3u * (size_t)(k - tn) * 8) : 0;
+    L->total = L->trace + L->own + L->sparse + L->bits + L->blocks + L->wl + L->counts + L->pre;
     return true;
 }
 
@@ -1036,7 +1054,9 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
     if (L.worklist) {
         // the k-mers traced; the step of the three substitutions of every traced position off one fetch, the variants
         // inside the tables' reach from their table entries: worklists of live searches; then ONE launch runs them
-        uint8_t *d_wl = d_blocks + L.blocks, *d_counts = d_wl + L.wl;
+        // (d_pre: the table entries of the variants inside the tables' reach, read ahead for all shards by the worklist
+        // launch's first kernel: mm1_worklist.hip, wl_table_entries_kernel)
+        uint8_t *d_wl = d_blocks + L.blocks, *d_counts = d_wl + L.wl, *d_pre = L.pre ? d_counts + L.counts : nullptr;
         static const bool no_walk = getenv("RSBWT_SET_1MM_NO_WALK") != nullptr;  // A/B knob (tools/README.md): the traced launch + the branch kernel
         if (!no_walk) {
             // ONE walk of the k-mers: their own searches, and at every position left of the tables' reach the step of the
@@ -1053,7 +1073,7 @@ static int set_hits_1mm_fused(rsbwt_set_t *s, dev_group *g, const fused_1mm_layo
                                                        d_sparse, d_bits, g->num_cus, st, g->counting ? g->d_work : nullptr);
             if (ew != hipSuccess) return fail_hip(ew, "worklist kernels");
         }
-        rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, L.tn, d_wl, d_counts, L.wl_cap, k, d_sparse, d_bits, st);
+        rc = search_launch_worklist(*g, g->d_views, S, g->num_cus, d_packed, d_valid, m, L.tn, d_wl, d_counts, L.wl_cap, k, d_sparse, d_bits, st, d_pre);
     } else {
         rc = fused_1mm_launches(s, g, L, d_packed, d_valid, m, k, d_var, d_trace, d_own, d_sparse, nullptr, d_bits, st);
     }

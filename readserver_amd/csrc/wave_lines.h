@@ -129,6 +129,22 @@ __device__ __forceinline__ uint32_t read_chunk_dword(const staged_line &L) {
     return 2u * (((m2 >> 22) & 3u) | (((m3 >> 22) & 3u) << 2));
 }
 
+// ---- k-mer table lookups shared by the start-record kernels, the one-lane kernel and the worklist pre-pass
+__device__ __forceinline__ bool view_uses_ktab(const shard_view &ix, uint32_t k) {
+    return ix.ktab != nullptr && ix.ktab_depth >= 2u && k >= ix.ktab_depth;
+}
+
+// Entry of T-mer `code` in the plain table's 8-byte form, whatever the table's format (line_format.h)
+__device__ __forceinline__ uint64_t ktab_entry(const uint64_t *__restrict__ ktab, uint32_t fmt, uint32_t T, uint32_t stride, uint64_t code) {
+    if (fmt == KTAB_GROUPED) {
+        const uint32_t gbits = 2u * (T - 1u);
+        const uint64_t g = code & ((1ull << gbits) - 1ull);
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ktab) + g * stride * (uint64_t)KTAB_GROUP_BYTES);
+        return ktab_group_entry(r[0], r[1], r[2], (uint32_t)(code >> gbits) & 3u);
+    }
+    return ktab[code * stride];
+}
+
 // ---- the 1-mismatch worklists' shared pieces (mm1_worklist.hip, search_solo.h)
 // Worklist record (32 B): x = lower (40 bits) | next symbol j << 40 (16 bits) | WL_DEAD << 63;  y = upper;
 //                         z = canonical search index q * (3k+1) + v;  w = the variant's packed word (k <= 32).

@@ -16,7 +16,7 @@ import sys
 
 tag, mode = sys.argv[1], sys.argv[2]
 subs = sys.argv[3:] or ["extract_prefix_wave_kernel", "extract_postfix_wave_kernel", "search_solo_kernel<false, false, false, true, false, true>",
-                        "search_solo_kernel<false, false, false, false, true, false>"]
+                        "search_solo_kernel<false, false, false, false, true, false>", "wl_table_entries_kernel"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{mode}_{tag}")
 dst = os.path.join(root, "profiles")
@@ -39,31 +39,44 @@ print(json.dumps({s: {k: round(v["mean_per_launch"]) for k, v in cs.items()} for
 sys.path.insert(0, root)
 import bench  # noqa: E402
 steps = int(os.environ.get("STEPS", "4"))
-# launches of the covered kernels in the profiled run: the walk kernels of --mode extract run once more in the bench's counting
-# step under the same names (the 1-mismatch search kernels' counting instantiations have names of their own)
-cov_launches = steps + (1 if mode == "extract" else 0)
+# Every covered kernel runs ONCE per step: its bytes per step = its bytes over the profiled run / its own number of
+# dispatches there (the walk kernels of --mode extract and the 1-mismatch table pre-pass also run in the bench's one
+# counting step under the same names; the 1-mismatch search kernels' counting instantiations have names of their own).
 covered = {"1mm": ["search_solo_kernel<false, false, false, true, false, true>",   # the walk of the k-mers (search_solo.h, WALK)
+                   "wl_table_entries_kernel",                                        # the table-part variants' entries read ahead (round 5)
                    "search_solo_kernel<false, false, false, false, true, false>"],  # the worklist search (WL)
            "extract": ["extract_prefix_wave_kernel", "move_prefix", "extract_postfix_wave_kernel"]}[mode]
-# the step's other kernels: they also run in the bench's one counting step (whose search kernels have names of their own)
-others = {"1mm": ["wl_", "hit_", "pack_dense_kernel", "search_init_tiled_kernel"], "extract": []}[mode]
-tot = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
+# the step's other kernels
+others = {"1mm": ["wl_init", "wl_own", "wl_branch", "hit_", "pack_dense_kernel", "search_init_tiled_kernel"], "extract": []}[mode]
+per = {"FETCH_SIZE": collections.defaultdict(lambda: [0.0, 0]), "WRITE_SIZE": collections.defaultdict(lambda: [0.0, 0])}
 for f in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] in tot:
-            if any(c in r["Kernel_Name"] for c in covered):
-                tot[r["Counter_Name"]][0] += float(r["Counter_Value"])
-            if any(c in r["Kernel_Name"] for c in others):
-                tot[r["Counter_Name"]][1] += float(r["Counter_Value"])
+        if r["Counter_Name"] in per:
+            for c in covered + others:
+                if c in r["Kernel_Name"]:
+                    per[r["Counter_Name"]][c][0] += float(r["Counter_Value"])
+                    per[r["Counter_Name"]][c][1] += 1
+                    break
+def per_step(names):
+    b = 0.0
+    for c in names:
+        f, w = per["FETCH_SIZE"][c], per["WRITE_SIZE"][c]
+        if f[1]:
+            b += 2 * f[0] / f[1] * 1024
+        if w[1]:
+            b += w[0] / w[1] * 1024
+    return b
+tot_cov, tot_oth = per_step(covered), per_step(others)
 p_modes = os.path.join(dst, "pmc_traffic_modes.json")
 modes = json.load(open(p_modes)) if os.path.exists(p_modes) else {}
 args = dict(a.split("=", 1) for a in os.environ.get("RUN_ARGS", "").split() if "=" in a)
 modes[mode] = {"source_sha": bench.mode_source_sha(), "run_bytes_per_shard": int(float(args.get("runs", 2e10))),
                "shards_per_gpu": int(args.get("shards", 8)), "units_per_batch": int(float(args.get("units", 4e5 if mode == "1mm" else 2e6))),
                "steps_profiled": steps,
-               "hbm_bytes_per_step_covered_kernels": (2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / cov_launches,
-               "hbm_bytes_per_step_all_kernels": (2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024 / cov_launches
-                                                 + (2 * tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][1]) * 1024 / (steps + (1 if mode == "1mm" else 0)),
+               "hbm_bytes_per_step_covered_kernels": tot_cov,
+               "hbm_bytes_per_step_all_kernels": tot_cov + tot_oth,
+               "per_kernel_bytes_per_launch": {c: (2 * per["FETCH_SIZE"][c][0] / max(per["FETCH_SIZE"][c][1], 1) + per["WRITE_SIZE"][c][0] / max(per["WRITE_SIZE"][c][1], 1)) * 1024
+                                               for c in covered + others if per["FETCH_SIZE"][c][1] or per["WRITE_SIZE"][c][1]},
                "covered_kernels": covered, "from": f"profiles/{tag}_{mode}_pmc.json",
                "rule": "(2*FETCH_SIZE + WRITE_SIZE) KB * 1024 summed over the kernels' dispatches / steps; gfx950 FETCH_SIZE counts 128-B read requests at 64 B"}
 json.dump(modes, open(p_modes, "w"), indent=1)
