@@ -115,6 +115,72 @@ search_init_tiled_kernel(const shard_view *__restrict__ shards, uint32_t nshards
     }
 }
 
+// The same with FOUR queries per thread (round 5).  The tiled kernel is a chain of three dependent memory round trips
+// per thread -- validity byte and packed word, then the table record they name, then the store -- and ran at the rate
+// that chain allows at full occupancy: 0.86 ms per 10^7 queries x 8 shards where its requests (10^7 table stretches,
+// 10^7 record lines) would take 0.4.  Four independent chains per thread: the four word loads are issued together,
+// then the four table loads.
+constexpr uint32_t INIT_U = 4;
+__global__ void __launch_bounds__(256)
+search_init_tiled4_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                          const uint8_t *__restrict__ valid, size_t Q, uint32_t k, uint32_t V, ulonglong2 *__restrict__ init) {
+    __shared__ ulonglong2 tile[INIT_U][256];
+    const size_t q0 = (size_t)blockIdx.x * V * INIT_U;
+    const uint32_t t = threadIdx.x;
+    {
+        const uint32_t v = t / nshards, s = t - v * nshards;
+        if (v < V) {
+            const shard_view &ix = shards[s];
+            const bool tab = view_uses_ktab(ix, k);
+            const uint32_t T = ix.ktab_depth, off = tab ? 2u * (k - T) : 0u;  // (k <= 32: one packed word per k-mer)
+            const uint64_t *ktab = ix.ktab;
+            const uint32_t fmt = ix.ktab_fmt, stride = ix.ktab_stride;
+            const uint64_t n = ix.n;
+            uint8_t ok[INIT_U];
+            uint64_t word[INIT_U], e[INIT_U];
+#pragma unroll
+            for (uint32_t u = 0; u < INIT_U; ++u) {
+                const size_t q = q0 + (size_t)u * V + v;
+                const bool in = q < Q;
+                ok[u] = in ? valid[q] : (uint8_t)2;  // (2: no such query)
+                word[u] = in ? packed[q] : 0ull;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < INIT_U; ++u)
+                e[u] = (tab && ok[u] == 1) ? ktab_entry(ktab, fmt, T, stride, (word[u] >> off) & ((1ull << (2u * T)) - 1ull)) : ~0ull;
+#pragma unroll
+            for (uint32_t u = 0; u < INIT_U; ++u) {
+                if (ok[u] == 2) continue;
+                ulonglong2 rec;
+                const uint32_t width = (uint32_t)(e[u] >> COUNT_BITS);
+                if (ok[u] == 0) {
+                    rec.x = INIT_INVALID;
+                    rec.y = 0;
+                } else if (tab && width != KTAB_WIDE && (e[u] & COUNT_MASK) + width <= n) {  // (start_record: an entry that is an interval of this BWT)
+                    rec.x = e[u] & COUNT_MASK;
+                    rec.y = rec.x + width - 1ull;
+                } else {  // initInterval, query.cpp:18-21
+                    const uint32_t b = (uint32_t)((word[u] >> (2u * ((k - 1u) & 31u))) & 3u) + 1u;
+                    rec.x = ix.C[b] | INIT_FALLBACK;
+                    rec.y = ix.C[b] + ix.total[b] - 1ull;
+                }
+                tile[u][v * nshards + s] = rec;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t s = t / V, v = t - s * V;
+        if (s < nshards) {
+#pragma unroll
+            for (uint32_t u = 0; u < INIT_U; ++u) {
+                const size_t q = q0 + (size_t)u * V + v;
+                if (q < Q) init[(size_t)s * Q + q] = tile[u][v * nshards + s];
+            }
+        }
+    }
+}
+
 // Start records of the 3k+1 variants of m k-mers (1-mismatch search, variants_kernel's order).  A
 // variant whose substituted position is left of the k-mer table's reach shares its whole suffix
 // with the k-mer itself: it starts from the interval the k-mer's own (traced) search had when it
@@ -627,7 +693,12 @@ static void launch_k(int grid, hipStream_t stream, const shard_view *shards, uin
 static void launch_init(const shard_view *d_shards, uint32_t nshards, const uint64_t *pk, const uint8_t *vd, size_t Q, uint32_t k,
                         uint32_t wpq, ulonglong2 *init, hipStream_t stream) {
     static const bool untiled = getenv("RSBWT_INIT_UNTILED") != nullptr;  // A/B knob (tools/README.md)
-    if (nshards >= 2u && nshards <= 256u && !untiled) {
+    static const bool one_per_thread = getenv("RSBWT_INIT_ONE_PER_THREAD") != nullptr;  // A/B knob (tools/README.md)
+    if (nshards >= 2u && nshards <= 256u && !untiled && wpq == 1u && !one_per_thread) {
+        const uint32_t V = 256u / nshards;
+        hipLaunchKernelGGL(search_init_tiled4_kernel, dim3((unsigned)((Q + (size_t)V * INIT_U - 1) / ((size_t)V * INIT_U))), dim3(256), 0, stream,
+                           d_shards, nshards, pk, vd, Q, k, V, init);
+    } else if (nshards >= 2u && nshards <= 256u && !untiled) {
         const uint32_t V = 256u / nshards;
         hipLaunchKernelGGL(search_init_tiled_kernel, dim3((unsigned)((Q + V - 1) / V)), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q,
                            k, wpq, V, init);

@@ -26,7 +26,7 @@ orc = oracle_binding.load()
 rng = np.random.default_rng(SEED)
 acgt = np.frombuffer(b"ACGT", np.uint8)
 t_end = time.time() + SECONDS
-done, failures, sets, fused_sets = 0, [], 0, 0
+done, failures, sets, fused_sets, two_group_sets = 0, [], 0, 0, 0
 
 
 def make_runs(R, shape):
@@ -93,9 +93,26 @@ while time.time() < t_end:
                 oix2 = orc.from_runs(runs2)
                 # (a second shard with the first one's table depth: the set then searches both in one traced and one
                 # resumed launch, csrc/sets.hip set_hits_1mm_fused)
-                with rsb.GpuBWT(runs=runs2, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))], for_reads=bool(rng.random() < 0.5),
-                                ktab_grouped=bool(rng.random() < 0.5)) as g2:
+                # now and then the second shard sits on another LOGICAL device (the library's test hook, include/rsbwt.h,
+                # rsbwt_logical_device): the set then spans two device groups -- a thread and a fused launch per group, the
+                # groups' results merged on the host -- and only its host entry points apply
+                two_dev = bool(rng.random() < 0.3)
+                if two_dev:
+                    os.environ["RSBWT_ENABLE_TEST_HOOKS"], os.environ["RSBWT_TEST_DEVICE_ALIASES"] = "1", "2"
+                try:
+                    g2cm = rsb.GpuBWT(runs=runs2, device=1 if two_dev else 0, ktab_depth=[None, 0, 5, T, T][int(rng.integers(0, 5))],
+                                      for_reads=bool(rng.random() < 0.5), ktab_grouped=bool(rng.random() < 0.5))
+                finally:
+                    if two_dev:
+                        del os.environ["RSBWT_TEST_DEVICE_ALIASES"]
+                with g2cm as g2:
                     ss = rsb.ShardSet([g, g2])
+                    assert L.rsbwt_set_devices(ss._s) == (2 if two_dev else 1), "device groups of the set"
+                    cfg["set_devices"] = 2 if two_dev else 1
+                    if two_dev:  # the summed counts of the two groups (host-side sum: RCCL refuses two ranks on one GPU)
+                        e2c = oix2.find_intervals(km[:5000], nthreads=8)
+                        wantc = np.where(eup[:5000] >= elo[:5000], eup[:5000] - elo[:5000] + 1, 0) + np.where(e2c[1] >= e2c[0], e2c[1] - e2c[0] + 1, 0)
+                        assert np.array_equal(ss.count(km[:5000]), wantc.astype(np.uint64)), "set counts over two device groups"
                     slo, sup = ss.find_intervals(km[:5000])
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
                     ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
@@ -108,6 +125,7 @@ while time.time() < t_end:
                         if not ok_h:
                             why.append("set hits_1mm (host) vs the shards' own lists")
                         ok2 = ok2 and ok_h
+                    if k <= 40 and not two_dev:
                         # the device-resident form (fused launches when both tables have one depth) leaves the same lists
                         import torch
                         p_ = lambda t: C.c_void_p(t.data_ptr())
@@ -134,16 +152,29 @@ while time.time() < t_end:
                     # (csrc/extract_lines.hip), against each shard's own host call
                     import torch
                     p_ = lambda t: C.c_void_p(t.data_ptr())
-                    nr_ = 300
+                    nr_ = 0 if two_dev else 300
                     n2 = oix2.bwlen()
                     rws = np.stack([rng.integers(0, n + 3, nr_), rng.integers(0, n2 + 3, nr_)]).astype(np.uint64)  # (a few past the end)
                     d_rw = torch.from_numpy(rws.view(np.int64)).cuda()
                     d_o = torch.zeros((2, nr_, 512), dtype=torch.uint8, device="cuda")
                     d_l = torch.empty((2, nr_), dtype=torch.int32, device="cuda")
                     d_p = torch.empty((2, nr_), dtype=torch.int32, device="cuda")
-                    assert L.rsbwt_set_extract_dev(ss._s, p_(d_rw), nr_, p_(d_o), 512, p_(d_l), p_(d_p), None) == 0
+                    if nr_:
+                        assert L.rsbwt_set_extract_dev(ss._s, p_(d_rw), nr_, p_(d_o), 512, p_(d_l), p_(d_p), None) == 0
+                    else:  # two device groups: the host form, rows addressed as (shard, row), against the oracle
+                        shx = rng.integers(0, 2, 200).astype(np.uint32)
+                        rwx = np.array([rng.integers(0, (n, n2)[int(s_)]) for s_ in shx], dtype=np.uint64)
+                        got_x = ss.extract(shx, rwx, stride=2048)[0]
+                        for s_, r_, t_ in list(zip(shx, rwx, got_x))[::7]:
+                            try:
+                                pre_, post_ = (oix, oix2)[int(s_)].extract(int(r_), cap=2000)
+                            except AssertionError:
+                                continue
+                            if len(pre_) + len(post_) <= 2048 and t_ != pre_ + post_:
+                                why.append("set extract over two device groups")
+                                ok2 = False
                     torch.cuda.synchronize()
-                    for si, gg in enumerate((g, g2)):
+                    for si, gg in enumerate((g, g2) if nr_ else ()):
                         o1 = np.zeros((nr_, 512), np.uint8)
                         l1, p1 = np.empty(nr_, np.uint32), np.empty(nr_, np.uint32)
                         assert L.rsbwt_extract(gg.handle, rws[si].ctypes.data, nr_, o1.ctypes.data, 512, l1.ctypes.data, p1.ctypes.data) == 0
@@ -211,6 +242,7 @@ while time.time() < t_end:
                     assert ln[i] != 0xFFFFFFFF and out[i, :ln[i]].tobytes() == tx, f"extraction of row {int(rows[i])}"
         done += 1
         sets += 1 if cfg.get("set") else 0
+        two_group_sets += 1 if cfg.get("set_devices") == 2 else 0
         fused_sets += cfg.get("set_1mm_fused", 0)
         print(f"ok {done}: {cfg}", file=sys.stderr, flush=True)
     except AssertionError as e:
@@ -219,6 +251,6 @@ while time.time() < t_end:
         if len(failures) >= 5:
             break
     oix.close()
-print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "as_two_shard_sets": sets,
+print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "as_two_shard_sets": sets, "sets_over_two_device_groups": two_group_sets,
                   "sets_searched_by_the_fused_1mm_launches": fused_sets, "failures": failures}))
 sys.exit(1 if failures else 0)
