@@ -240,7 +240,7 @@ extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshar
             base = (((uint64_t)((acc_hi >> (8u * ci)) & 0xFFu) << 32) | alo) + ((hw >> (12u * (ci & 1u))) & 0xFFFu);
         } else {
             const uint32_t hb = read_half(L, ci + 1u);
-            const uint32_t m = matched24(L, HDR_DWORDS + 6u * (cq & 2u), ci + 1u);
+            const uint32_t m = matched24(L, HDR_DWORDS + 6u * (cq & 2u), cr.tab);  // (c = ci + 1 wherever the step is taken)
             base = read_count(L, ci + 1u) + (cq >= 2u ? hb : 0u) + ((cq & 1u) ? m : 0u);
         }
         // C[c], with every lane active (a ds_bpermute returns 0 from a masked-off source lane)

@@ -121,6 +121,7 @@ __device__ __forceinline__ uint32_t splat_byte(uint32_t b) { return __builtin_am
 // known already (c = want), only its count is wanted.
 struct char_rank {
     uint32_t c, occ;
+    sym_tab tab;  // make_sym_tab(c): the caller's whole-quarter sums of c use it too
 };
 __device__ __forceinline__ char_rank char_rank24(const uint32_t r[6], uint32_t rem, uint32_t want) {
     uint32_t cum[7];
@@ -142,15 +143,16 @@ __device__ __forceinline__ char_rank char_rank24(const uint32_t r[6], uint32_t r
     char_rank o;
     o.c = want ? want : (found ? here : 0u);
     const uint32_t pj = j ? __builtin_amdgcn_ubfe(ps, 8u * j - 8u, 8u) : 0u;  // symbols before piece j of the dword
-    const uint32_t bb = splat_byte(o.c);
+    o.tab = make_sym_tab(o.c);
     uint32_t mcum = 0, before = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        mcum = dword_matched(r[i], bb, mcum);
+        mcum = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, match01(r[i], o.tab), mcum, false);
         before = rem > cum[i + 1] ? mcum : before;
     }
-    const uint32_t xm = x & ((1u << (8u * j)) - 1u);  // the dword's pieces before piece j
-    const uint32_t inner = dword_matched(xm, bb, 0u);
+    // the dword's pieces before piece j: the other pieces' lengths are masked off, whatever their symbols
+    const uint32_t lm = x & 0x1F1F1F1Fu & ((1u << (8u * j)) - 1u);
+    const uint32_t inner = __builtin_amdgcn_udot4(lm, match01(x, o.tab), 0u, false);
     // piece j counts up to the position (all of it when the position lies past the pieces) if it is
     // a run of c -- always, unless c was given and differs
     const uint32_t reach = found ? rd - pj : (rem ? (ps >> 24) - pj : 0u);
@@ -162,13 +164,14 @@ __device__ __forceinline__ char_rank char_rank24(const uint32_t r[6], uint32_t r
 // piece, 0-based) of the t-th b (t >= 1); *left = what remains of t when the pieces hold fewer
 // (0: found; t == 0 gives position 0, left 0).
 __device__ __forceinline__ uint32_t select_in24(const uint32_t r[6], uint32_t b, uint32_t t, uint32_t *left) {
-    const uint32_t bb = splat_byte(b);
+    const sym_tab tab = make_sym_tab(b);
     uint32_t cum[7], mat[7];
     cum[0] = mat[0] = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        cum[i + 1] = __builtin_amdgcn_udot4(r[i] & 0x1F1F1F1Fu, 0x01010101u, cum[i], false);
-        mat[i + 1] = dword_matched(r[i], bb, mat[i]);
+        const uint32_t l = r[i] & 0x1F1F1F1Fu;
+        cum[i + 1] = __builtin_amdgcn_udot4(l, 0x01010101u, cum[i], false);
+        mat[i + 1] = __builtin_amdgcn_udot4(l, match01(r[i], tab), mat[i], false);
     }
     uint32_t x = r[0], tb = 0, mb = 0;
 #pragma unroll
@@ -181,8 +184,7 @@ __device__ __forceinline__ uint32_t select_in24(const uint32_t r[6], uint32_t b,
     *left = t > mat[6] ? t - mat[6] : 0u;
     const uint32_t td = t - mb;
     const uint32_t lx = x & 0x1F1F1F1Fu;
-    const uint32_t z = ((x >> 5) & 0x07070707u) ^ bb;
-    const uint32_t m01 = ((0x80808080u - z) >> 7) & 0x01010101u;
+    const uint32_t m01 = match01(x, tab);
     const uint32_t ps = lx * 0x01010101u;                   // symbols up to and including piece 0..3
     const uint32_t qs = (lx & (m01 * 0xFFu)) * 0x01010101u;  // b's up to and including piece 0..3
     const uint32_t j = (td > (qs & 0xFFu) ? 1u : 0u) + (td > ((qs >> 8) & 0xFFu) ? 1u : 0u) + (td > ((qs >> 16) & 0xFFu) ? 1u : 0u);

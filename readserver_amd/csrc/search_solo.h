@@ -171,10 +171,12 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     q = (size_t)q_ * (3u * k + 1u) + 1u + 3u * (wl_tn + pr) + (r_ - 3u * pr);  // the variant's canonical index
                     const uint64_t e = nrec.x;
                     const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+                    bool tabulated = false;
                     if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix_n) {
                         lo = e & COUNT_MASK;
                         hi = lo + width - 1ull;
                         j = (int)wl_tn - 1;
+                        tabulated = true;
                     } else {  // not tabulated (or not an interval of this BWT): initInterval, query.cpp:18-21
                         const uint32_t bl = (uint32_t)((nword >> (2u * ((k - 1u) & 31u))) & 3u);
                         const uint64_t cb = bl == 0u ? sc1 : bl == 1u ? sc2 : bl == 2u ? sc3 : sc4;
@@ -183,8 +185,11 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         hi = cb + tb - 1ull;
                         j = (int)k - 2;
                     }
-                    // (the reference's unsigned compare, query.cpp:35: an empty interval at row 0, (0, 2^64 - 1), lives)
-                    done = (nrec.y & 0xFFull) == 0ull || lo > hi || j < 0;
+                    // (the reference's unsigned compare, query.cpp:35: an empty interval at row 0, (0, 2^64 - 1), lives.
+                    // And it looks at the interval only after an updateInterval, query.cpp:33-37: an initInterval that is
+                    // empty -- no such symbol in the BWT -- is stepped on, as in the plain launches' start records: on a
+                    // BWT whose first rows hold none of the next symbol either it becomes that wrapped interval)
+                    done = (nrec.y & 0xFFull) == 0ull || (tabulated && lo > hi) || j < 0;
                 } else {
                     q = nq;  // (the record's result index)
                     lo = nrec.x & COUNT_MASK;

@@ -83,16 +83,15 @@ __device__ __forceinline__ const lds_u32 *own_stage_row(const uint4 *stage, uint
     return reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
 }
 
-// what the 24 pieces at dwords qd .. qd+5 hold of symbol b, 4 runs per v_dot4_u32_u8
-__device__ __forceinline__ uint32_t matched24(const staged_line &L, uint32_t qd, uint32_t b) {
+// what the 24 pieces at dwords qd .. qd+5 hold of the table's symbol (rank_device.h, sym_tab: the 0/1 match mask of a
+// dword is one v_perm_b32), 4 runs per v_dot4_u32_u8
+__device__ __forceinline__ uint32_t matched24(const staged_line &L, uint32_t qd, const sym_tab &t) {
     const uint2 x0 = L.u2(qd & 31u), x1 = L.u2((qd + 2u) & 31u), x2 = L.u2((qd + 4u) & 31u);
-    const uint32_t bb = __builtin_amdgcn_perm(0u, b, 0u);  // b in every byte
-    uint32_t m = dword_matched(x0.x, bb, 0u);
-    m = dword_matched(x0.y, bb, m);
-    m = dword_matched(x1.x, bb, m);
-    m = dword_matched(x1.y, bb, m);
-    m = dword_matched(x2.x, bb, m);
-    return dword_matched(x2.y, bb, m);
+    const uint32_t e[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+    return matched24_tab(e, t);
+}
+__device__ __forceinline__ uint32_t matched24(const staged_line &L, uint32_t qd, uint32_t b) {
+    return matched24(L, qd, make_sym_tab(b));
 }
 
 // the 24 pieces at dword dw into registers

@@ -632,6 +632,71 @@ def test_gpu_set_hits_1mm_all_shards_in_one_launch(rsb, oracle, tables):
         g.close()
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_gpu_set_hits_1mm_on_bwts_without_terminators(rsb, oracle, fmt):
+    """The fused 1-mismatch launches on run streams that are no BWT of reads at all (no '$', a handful of symbols: what
+    the fuzz campaign draws, tools/fuzz_parity.py seed 505): there a search that finds nothing at row 0 carries the
+    reference's wrapped interval (0, 2^64 - 1) on as a LIVE one (query.cpp:11-15,35: unsigned compare) and every
+    further step leaves it as it is, so whole families of variants "hit".  Every shard's list = the oracle's exact
+    search of every spelled-out variant."""
+    import torch
+    L = rsb.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    big = np.empty(40000, np.uint8)
+    assert L.rsbwt_synth_runs_host(big.ctypes.data, big.size, 2750) == 0
+    streams = [big, np.array([66, 97], np.uint8), np.array([33], np.uint8), np.array([0x9F, 0x9F, 0x41, 0x21], np.uint8)]
+    k, T = 31, 5
+    rng = np.random.default_rng(77)
+    km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(40, k))
+    for i, c in enumerate(b"ACGT"):
+        km[2 * i] = c
+        km[2 * i + 1] = c
+        km[2 * i + 1, 9 + i] = b"ACGT"[(i + 1) & 3]
+    km[8] = np.frombuffer(b"CCG" * 11, np.uint8)[:k]
+    km[9, :] = ord("A"); km[9, k - 1] = ord("C")
+    km[10, :] = ord("A"); km[10, 0] = ord("G")
+    m, V = km.shape[0], 3 * k + 1
+    variants = _spelled(km).reshape(m * V, k)
+    shards = [rsb.GpuBWT(runs=r, ktab_depth=None) for r in streams]
+    oixs = [oracle.from_runs(r) for r in streams]
+    ss = rsb.ShardSet(shards)
+    assert L.rsbwt_set_attach_ktabs_format(ss._s, T, fmt) == 0
+    S = len(streams)
+    d_km = torch.from_numpy(km).to(dev)
+    d_pk = torch.empty((m, 1), dtype=torch.int64, device=dev)
+    d_ok = torch.empty(m, dtype=torch.uint8, device=dev)
+    assert L.rsbwt_pack_kmers_dev(p(d_km), m, k, k, p(d_pk), p(d_ok), 0, None) == 0
+    assert L.rsbwt_set_hits_1mm_is_fused(ss._s, m, k) == 1
+    cap = m * V
+    d_hits = torch.full((S, cap, 4), -1, dtype=torch.int64, device=dev)
+    d_tot = torch.full((S,), -1, dtype=torch.int64, device=dev)
+    d_scr = torch.empty(L.rsbwt_set_hits_1mm_scratch_bytes(ss._s, m, k), dtype=torch.uint8, device=dev)
+    assert L.rsbwt_set_hits_1mm_dev(ss._s, p(d_pk), p(d_ok), m, k, p(d_hits), cap, p(d_tot), p(d_scr), None) == 0
+    torch.cuda.synchronize()
+    wrapped = 0
+    for s_, oix in enumerate(oixs):
+        elo, eup = oix.find_intervals(variants, nthreads=8)
+        idx = np.nonzero(elo <= eup)[0]
+        wrapped += int(np.count_nonzero(eup[idx] == np.uint64(2 ** 64 - 1)))
+        n = int(d_tot[s_].item())
+        rec = d_hits[s_, :min(n, cap)].cpu().numpy().view(np.uint64)
+        got = {int(r[2]): (int(r[0]), int(r[1])) for r in rec}
+        exp = {int(i): (int(elo[i]), int(eup[i])) for i in idx}
+        miss = sorted(set(exp) - set(got))[:6]
+        extra = sorted(set(got) - set(exp))[:6]
+        name = lambda i: (i // V, "own" if i % V == 0 else ((i % V - 1) // 3, (i % V - 1) % 3))
+        assert not miss and not extra, (s_, n, len(idx), [name(i) for i in miss], [name(i) for i in extra])
+        assert got == exp, s_
+        # ... and the shard's own list (the host form takes the shards one by one)
+        own = rsb.hits_1mm_batch(shards[s_], km)
+        assert len(own) == len(idx) and np.array_equal(own["lower"], elo[idx]) and np.array_equal(own["upper"], eup[idx])
+    assert wrapped > 100  # the wrapped interval is what this test is about
+    ss.close()
+    for g in shards:
+        g.close()
+
+
 @pytest.mark.parametrize("devices", [1, 2])
 def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices, monkeypatch):
     """readserver_amd/onehost.py -- the C++ host's shape, what `bench.py --host cxx` times: per device pack + ONE fused
