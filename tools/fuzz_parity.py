@@ -118,6 +118,11 @@ while time.time() < t_end:
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
                     ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
                            np.array_equal(slo[1], e2lo) and np.array_equal(sup[1], e2up))
+                    if Q > 20000:  # the whole batch over the set: both shards behind deep tables = the headline's launch (one lane per search)
+                        flo, fup = ss.find_intervals(km)
+                        f2lo, f2up = oix2.find_intervals(km, nthreads=8)
+                        ok2 = ok2 and (np.array_equal(flo[0], elo) and np.array_equal(fup[0], eup) and np.array_equal(flo[1], f2lo) and np.array_equal(fup[1], f2up))
+                        cfg["set_full_batch"] = True
                     why = [] if ok2 else ["set intervals"]
                     # configs[3] / configs[4] over the set: every shard's own list / reads, side by side
                     if k <= 40:
@@ -270,6 +275,6 @@ while time.time() < t_end:
         if len(failures) >= 5:
             break
     oix.close()
-print(json.dumps({"seconds": SECONDS, "seed": SEED, "configurations": done, "as_two_shard_sets": sets, "sets_over_two_device_groups": two_group_sets,
+print(json.dumps({"seconds": SECONDS, "seed": SEED, "search_kernel": os.environ.get("RSBWT_SEARCH_KERNEL", "auto"), "configurations": done, "as_two_shard_sets": sets, "sets_over_two_device_groups": two_group_sets,
                   "sets_searched_by_the_fused_1mm_launches": fused_sets, "failures": failures}))
 sys.exit(1 if failures else 0)
