@@ -750,6 +750,12 @@ def second_leg(a, out, rehearsal=False, emit=None, runner=None, clock=time.time)
 
 def main():
     a = parse()
+    if a.gpus > 1 and not a.rehearse_on_one_gpu:
+        # N > 1: the previous batch's intervals are gathered (RCCL) while this batch is searched.  A search launch is
+        # persistent and fills every CU (registers, LDS), so the collective's kernels would wait for its tail: the
+        # library leaves 32 of its 1,024 workgroups out (csrc/search_lines.hip, RSBWT_SEARCH_SPARE_WGS: measured at
+        # N = 1, no cost: 18.51 against 18.60 ms per launch, profiles/r05q_*) -- a workgroup slot on 32 CUs.
+        os.environ.setdefault("RSBWT_SEARCH_SPARE_WGS", "32")
     if a.host == "cxx":
         if a.mode != "exact":
             raise SystemExit("bench.py --host cxx: the exact search (configs[1] / configs[2])")

@@ -661,15 +661,22 @@ static void launch_solo(int grid, hipStream_t stream, const shard_view *shards, 
                         uint32_t pairs, bool fused) {
     uint32_t qchunk = 1024;
     while (qchunk > 64u && (size_t)qchunk * (size_t)grid * WG_WAVES * 4u > Q * nshards) qchunk >>= 1;
+    // results staged in LDS and stored a whole 1 KB group at a time (search_solo.h, STAGED RESULTS): 8 KB of dynamic
+    // LDS per workgroup on top of the 32 KB of line slots -- four workgroups then fill a CU's 160 KB.
+    // RSBWT_NO_STAGED_RESULTS: A/B knob (tools/README.md); also what leaves LDS to kernels running beside the search.
+    static const bool no_staged = getenv("RSBWT_NO_STAGED_RESULTS") != nullptr;
+    const bool staged = !CO && pairs != 2u && !no_staged;
+    const uint32_t pa = pairs | (staged ? SOLO_STAGED_RESULTS : 0u);
+    const size_t dyn = staged ? SOLO_RESULTS_LDS : 0u;
     if (fused)  // (one shard, k <= 32, a k-mer table, no trace: the kernel makes its own start records)
-        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false, true>), dim3(grid), dim3(64 * WG_WAVES), dyn, stream, shards, nshards,
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pa);
     else if (wpq > 1)
-        hipLaunchKernelGGL((search_solo_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, true>), dim3(grid), dim3(64 * WG_WAVES), dyn, stream, shards, nshards,
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pa);
     else
-        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, shards, nshards,
-                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pairs);
+        hipLaunchKernelGGL((search_solo_kernel<CW, CO, false>), dim3(grid), dim3(64 * WG_WAVES), dyn, stream, shards, nshards,
+                           pk, init, valid, ctr, Q, k, wpq, lo, up, work, trace, trace_n, qchunk, pa);
 }
 
 template <bool CW, bool CO>
@@ -751,7 +758,17 @@ hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uin
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : RSB_MIN_WGS_PER_CU;
     }();
-    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    // RSBWT_SEARCH_SPARE_WGS = n: n workgroups fewer than the chip holds.  A search launch is persistent (its workgroups
+    // stay until the batch is done) and fills every CU's registers (4 waves x 128 VGPRs per SIMD) and LDS: a kernel
+    // that should run BESIDE it -- RCCL's, gathering the previous batch at N > 1 -- finds room only on CUs a workgroup
+    // short.  bench.py sets it for its N > 1 ranks (32: a workgroup slot on 32 CUs for the collective's channels).
+    static const size_t spare_wgs = [] {
+        const char *e = getenv("RSBWT_SEARCH_SPARE_WGS");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v > 0 ? v : 0);
+    }();
+    const size_t cap_all = (size_t)num_cus * (size_t)wgs_per_cu;
+    const size_t cap = cap_all > 2 * spare_wgs ? cap_all - spare_wgs : cap_all;
     // (the variants of a 1-mismatch search that resume from a trace start on their k-mer's narrow interval and live
     // 2.4 steps: what bounds their launch is how fast searches are taken up, and a wave of lone lanes takes up 64 per
     // pass where pairs take 32 -- any number of shards: 25.0 -> 23.5 ms per batch of 4e5 31-mers x 8 shards)
@@ -841,7 +858,17 @@ hipError_t launch_search_worklist(scratch_cache &scratch, const shard_view *d_sh
     }();
     const size_t implicit = m * 3u * (size_t)(k - tn), mv = m * (3u * (size_t)k + 1u);
     size_t g = ((implicit + wl_cap) * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
-    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    // RSBWT_SEARCH_SPARE_WGS = n: n workgroups fewer than the chip holds.  A search launch is persistent (its workgroups
+    // stay until the batch is done) and fills every CU's registers (4 waves x 128 VGPRs per SIMD) and LDS: a kernel
+    // that should run BESIDE it -- RCCL's, gathering the previous batch at N > 1 -- finds room only on CUs a workgroup
+    // short.  bench.py sets it for its N > 1 ranks (32: a workgroup slot on 32 CUs for the collective's channels).
+    static const size_t spare_wgs = [] {
+        const char *e = getenv("RSBWT_SEARCH_SPARE_WGS");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v > 0 ? v : 0);
+    }();
+    const size_t cap_all = (size_t)num_cus * (size_t)wgs_per_cu;
+    const size_t cap = cap_all > 2 * spare_wgs ? cap_all - spare_wgs : cap_all;
     if (g > cap) g = cap;
     scratch_cache::lease mem;
     hipError_t e = scratch.take(nshards * POOL_STRIDE * sizeof(unsigned long long), stream, &mem);
@@ -894,7 +921,17 @@ hipError_t launch_search_walk(scratch_cache &scratch, const shard_view *d_shards
         return v > 0 && v <= RSB_WALK1MM_WGS_PER_CU ? v : RSB_WALK1MM_WGS_PER_CU;
     }();
     size_t g = (m * nshards + 64u * WG_WAVES - 1) / (64u * WG_WAVES);
-    const size_t cap = (size_t)num_cus * (size_t)wgs_per_cu;
+    // RSBWT_SEARCH_SPARE_WGS = n: n workgroups fewer than the chip holds.  A search launch is persistent (its workgroups
+    // stay until the batch is done) and fills every CU's registers (4 waves x 128 VGPRs per SIMD) and LDS: a kernel
+    // that should run BESIDE it -- RCCL's, gathering the previous batch at N > 1 -- finds room only on CUs a workgroup
+    // short.  bench.py sets it for its N > 1 ranks (32: a workgroup slot on 32 CUs for the collective's channels).
+    static const size_t spare_wgs = [] {
+        const char *e = getenv("RSBWT_SEARCH_SPARE_WGS");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v > 0 ? v : 0);
+    }();
+    const size_t cap_all = (size_t)num_cus * (size_t)wgs_per_cu;
+    const size_t cap = cap_all > 2 * spare_wgs ? cap_all - spare_wgs : cap_all;
     if (g > cap) g = cap;
     scratch_cache::lease mem;
     hipError_t e = scratch.take(nshards * POOL_STRIDE * sizeof(unsigned long long), stream, &mem);

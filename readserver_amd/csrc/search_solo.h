@@ -12,6 +12,16 @@
 // two passes per step instead of one, which a request-bound launch does not feel.
 // Same start records, results, trace and counters as search_lines_kernel.
 //
+// STAGED RESULTS (plain searches: not COUNTS_ONLY / WL / WALK, no hit list; `pairs` bit 2 and 8 KB of dynamic LDS per
+// workgroup): a lane's result is 16 bytes at its query's place, and lanes finish at passes of their own -- 8e7 scattered
+// 16-byte stores per headline launch, each a write request of its own AND a read of the rest of its 64 bytes (6.6e7 EA
+// writes and 5.5 GB of reads beyond the algorithmic bytes, profiles/r05_pmc_search_kernel.json).  A wave draws its
+// queries in order, so the results of 64 consecutive queries -- 1 KB, eight whole lines -- all come from ONE wave, within
+// a few passes of each other where searches are of a length: they are collected in one of the wave's two 1 KB buffers in
+// LDS and leave as one contiguous store when the 64th is in.  A group that starts while both buffers are still waiting
+// (searches of very different lengths) is not staged: its lanes store as before.  Nothing per lane: a result belongs to
+// the buffer whose group number (q >> 6) its query has.
+//
 // FUSED (a single shard behind a k-mer table, k <= 32, no trace): the kernel computes the start records itself -- no
 // start-record launch before it, no 16 bytes written and read back per search.  The record of a search is its k-mer
 // table entry (findInterval's answer for its last T symbols, src/bwt/query.cpp:18-21,24-41): a lane takes its NEXT
@@ -42,6 +52,8 @@
 namespace rsb {
 
 constexpr uint64_t WL_DEAD = 1ull << 63;  // worklist record: an empty slot (bit 63 of its first word)
+constexpr uint32_t SOLO_STAGED_RESULTS = 4u;  // `pairs` bit 2: the launch brought SOLO_RESULTS_LDS bytes of dynamic LDS for staged results
+constexpr uint32_t SOLO_RESULTS_LDS = WG_WAVES * 2u * 64u * 16u;
 
 #ifndef RSB_WALK1MM_WGS_PER_CU  // tuning knob (tools/build_variant.sh): the walk keeps three bases' counts across passes
 #define RSB_WALK1MM_WGS_PER_CU 3
@@ -54,14 +66,19 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                    size_t Q, uint32_t k, uint32_t wpq,
                    uint64_t *__restrict__ out_lower, uint64_t *__restrict__ out_upper,
                    unsigned long long *__restrict__ work,
-                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs,
+                   ulonglong2 *__restrict__ trace, uint32_t trace_n, uint32_t qchunk, uint32_t pairs_arg,
                    const unsigned long long *__restrict__ wl_counts = nullptr, size_t wl_cap = 0, size_t wl_implicit = 0) {
     __shared__ uint4 s_stage[WG_WAVES][64 * SLOT_U4];
+    extern __shared__ uint4 s_results[];  // staged results: [WG_WAVES][2][64] x 16 B when `pairs_arg` bit 2 is set (else none)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)stage);
     const uint32_t swz = lane & 7u;
+    const uint32_t pairs = pairs_arg & 3u;
+    constexpr bool CAN_STAGE = !COUNTS_ONLY && !WL && !WALK;
+    const bool stage_out = CAN_STAGE && (pairs_arg & SOLO_STAGED_RESULTS) != 0u && pairs != 2u;
+    uint4 *results = s_results + wave * 128u;
     const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
 #define SOLO_MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
 
@@ -115,6 +132,8 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint64_t st1 = sv->total[1], st2 = sv->total[2], st3 = sv->total[3], st4 = sv->total[4];
 
         const uint32_t QCHUNK = qchunk;
+        // staged results: the group numbers (q >> 6) the wave's two buffers collect (~0u: free) and how many of each are still out
+        uint32_t grp_a = ~0u, grp_b = ~0u, out_a = 0, out_b = 0;
         uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
         bool drained = false;
         size_t q = 0;  // the query this lane is stepping
@@ -252,7 +271,18 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     got_n = true;
                 }
                 const uint64_t taken = pool_next + (uint32_t)__builtin_popcountll(want_mask);
+                const uint64_t r0 = pool_next;
                 pool_next = taken < pool_end ? taken : pool_end;
+                if (CAN_STAGE && stage_out && pool_next > r0) {
+                    // a group of 64 queries begins among this pass's draws (at most one: 64 lanes draw): it gets a buffer
+                    // if one is free (chunks are multiples of 64 and this wave's alone: the whole group is drawn here)
+                    const uint64_t g0 = (r0 & 63ull) == 0ull ? r0 : (r0 | 63ull) + 1ull;
+                    if (g0 < pool_next) {
+                        const uint32_t sz = (uint32_t)((g0 + 64ull < pool_end ? g0 + 64ull : pool_end) - g0);
+                        if (grp_a == ~0u) { grp_a = (uint32_t)(g0 >> 6); out_a = sz; }
+                        else if (grp_b == ~0u) { grp_b = (uint32_t)(g0 >> 6); out_b = sz; }
+                    }
+                }
             }
             // (FUSED: a reserve whose table entry is still to come keeps the pass going -- it is taken up two passes
             // after it was drawn, and a wave whose lanes hold nothing else would otherwise spin here, or leave with it)
@@ -603,6 +633,9 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         reinterpret_cast<ulonglong2 *>(out_lo)[qi] = make_ulonglong2(lo, hi);
                         atomicOr(hit_map + (qi >> 6), 1ull << (qi & 63u));
                     }
+                } else if (CAN_STAGE && stage_out && ((uint32_t)(q >> 6) == grp_a || (uint32_t)(q >> 6) == grp_b)) {
+                    results[((uint32_t)(q >> 6) == grp_b ? 64u : 0u) + ((uint32_t)q & 63u)] =
+                        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
                 } else if (pairs) {
                     reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
                 } else {
@@ -610,6 +643,34 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     out_up[q] = hi;
                 }
                 has_q = false;
+            }
+            if (CAN_STAGE && stage_out) {
+                // a buffer whose 64th result has just come in leaves as one contiguous store (1 KB of pairs; 512 B each
+                // of lower and upper)
+                const bool fin = alive && done;
+                const uint32_t gq = (uint32_t)(q >> 6);
+                const uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && gq == grp_a));
+                const uint32_t nb = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && gq == grp_b));
+#pragma unroll
+                for (uint32_t bsel = 0; bsel < 2u; ++bsel) {
+                    uint32_t &grp = bsel ? grp_b : grp_a, &out = bsel ? out_b : out_a;
+                    const uint32_t n = bsel ? nb : na;
+                    if (grp == ~0u || n == 0u) continue;
+                    out -= n;
+                    if (out != 0u) continue;
+                    const size_t qq = ((size_t)grp << 6) + lane;
+                    if (qq < Qs) {
+                        const uint4 v = results[bsel * 64u + lane];
+                        const uint64_t vlo = ((uint64_t)v.y << 32) | v.x, vhi = ((uint64_t)v.w << 32) | v.z;
+                        if (pairs) {
+                            reinterpret_cast<ulonglong2 *>(out_lo)[qq] = make_ulonglong2(vlo, vhi);
+                        } else {
+                            out_lo[qq] = vlo;
+                            out_up[qq] = vhi;
+                        }
+                    }
+                    grp = ~0u;
+                }
             }
             if (COUNT_WORK) ++passes;
         }
