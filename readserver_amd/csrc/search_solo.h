@@ -14,13 +14,13 @@
 //
 // STAGED RESULTS (plain searches: not COUNTS_ONLY / WL / WALK, no hit list; `pairs` bit 2 and 8 KB of dynamic LDS per
 // workgroup): a lane's result is 16 bytes at its query's place, and lanes finish at passes of their own -- 8e7 scattered
-// 16-byte stores per headline launch, each a write request of its own AND a read of the rest of its 64 bytes (6.6e7 EA
-// writes and 5.5 GB of reads beyond the algorithmic bytes, profiles/r05_pmc_search_kernel.json).  A wave draws its
-// queries in order, so the results of 64 consecutive queries -- 1 KB, eight whole lines -- all come from ONE wave, within
-// a few passes of each other where searches are of a length: they are collected in one of the wave's two 1 KB buffers in
-// LDS and leave as one contiguous store when the 64th is in.  A group that starts while both buffers are still waiting
-// (searches of very different lengths) is not staged: its lanes store as before.  Nothing per lane: a result belongs to
-// the buffer whose group number (q >> 6) its query has.
+// 16-byte stores per headline launch, 6.6e7 EA write requests (profiles/r05_pmc_search_kernel.json).  A wave draws its
+// queries in order, so the 8 results of one 128-byte line of the result array all come from ONE wave, a few passes
+// apart: they are collected in LDS -- 15 line buffers per wave, a group of 8 consecutive queries (g = q >> 3) in buffer
+// g mod 15 if that was free when the group's first query was drawn -- and the lane that brings the last one in (an LDS
+// counter per buffer) has lanes 0..7 store the line whole.  A group whose buffer was still taken is not staged: its
+// lanes store as before.  The buffers' tags and counters are the wave's 16th line (2 KB per wave in all: with the line
+// slots exactly the 160 KB of a CU at four workgroups).
 //
 // FUSED (a single shard behind a k-mer table, k <= 32, no trace): the kernel computes the start records itself -- no
 // start-record launch before it, no 16 bytes written and read back per search.  The record of a search is its k-mer
@@ -53,7 +53,8 @@ namespace rsb {
 
 constexpr uint64_t WL_DEAD = 1ull << 63;  // worklist record: an empty slot (bit 63 of its first word)
 constexpr uint32_t SOLO_STAGED_RESULTS = 4u;  // `pairs` bit 2: the launch brought SOLO_RESULTS_LDS bytes of dynamic LDS for staged results
-constexpr uint32_t SOLO_RESULTS_LDS = WG_WAVES * 2u * 64u * 16u;
+constexpr uint32_t SOLO_RESULTS_LDS = WG_WAVES * 2048u;
+constexpr uint32_t RES_BUFS = 15u;  // line buffers per wave (8 results each); the 16th line holds {tag, results still out} per buffer
 
 #ifndef RSB_WALK1MM_WGS_PER_CU  // tuning knob (tools/build_variant.sh): the walk keeps three bases' counts across passes
 #define RSB_WALK1MM_WGS_PER_CU 3
@@ -77,8 +78,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
     const uint32_t swz = lane & 7u;
     const uint32_t pairs = pairs_arg & 3u;
     constexpr bool CAN_STAGE = !COUNTS_ONLY && !WL && !WALK;
-    const bool stage_out = CAN_STAGE && (pairs_arg & SOLO_STAGED_RESULTS) != 0u && pairs != 2u;
+    // (group numbers are kept in 32 bits)
+    const bool stage_out = CAN_STAGE && (pairs_arg & SOLO_STAGED_RESULTS) != 0u && pairs != 2u && Q < (1ull << 34);
     uint4 *results = s_results + wave * 128u;
+    uint32_t *res_state = reinterpret_cast<uint32_t *>(results + RES_BUFS * 8u);  // [RES_BUFS] x {tag, out}
     const lds_u32 *mine0 = reinterpret_cast<const lds_u32 *>(stage + (lane & 7u) * 64u + (lane >> 3) * SLOT_U4);
 #define SOLO_MINE(d) (mine0 + (((((uint32_t)(d)) >> 2) ^ swz) << 2) + (((uint32_t)(d)) & 3u))
 
@@ -132,8 +135,10 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         const uint64_t st1 = sv->total[1], st2 = sv->total[2], st3 = sv->total[3], st4 = sv->total[4];
 
         const uint32_t QCHUNK = qchunk;
-        // staged results: the group numbers (q >> 6) the wave's two buffers collect (~0u: free) and how many of each are still out
-        uint32_t grp_a = ~0u, grp_b = ~0u, out_a = 0, out_b = 0;
+        if (CAN_STAGE && stage_out && lane < RES_BUFS) {  // every buffer free (the previous shard's groups have all left)
+            res_state[2u * lane] = ~0u;
+            res_state[2u * lane + 1u] = 0u;
+        }
         uint64_t pool_next = 0, pool_end = 0;  // wave-uniform
         bool drained = false;
         size_t q = 0;  // the query this lane is stepping
@@ -159,6 +164,7 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         for (;;) {
             // ---- a lane whose query ended in the last pass takes up the one it had prefetched
             bool done = false;
+            bool last_in = false;  // staged results: this lane's result completed its group's line
             if (FUSED && !has_q && has_n && nstage == 2u) {
                 // start_record() (search_lines.hip) on the entry the reserve brought: an entry that is not an interval
                 // of this BWT's rows (a damaged table) is not believed -- initInterval instead (query.cpp:18-21)
@@ -274,13 +280,21 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                 const uint64_t r0 = pool_next;
                 pool_next = taken < pool_end ? taken : pool_end;
                 if (CAN_STAGE && stage_out && pool_next > r0) {
-                    // a group of 64 queries begins among this pass's draws (at most one: 64 lanes draw): it gets a buffer
-                    // if one is free (chunks are multiples of 64 and this wave's alone: the whole group is drawn here)
-                    const uint64_t g0 = (r0 & 63ull) == 0ull ? r0 : (r0 | 63ull) + 1ull;
-                    if (g0 < pool_next) {
-                        const uint32_t sz = (uint32_t)((g0 + 64ull < pool_end ? g0 + 64ull : pool_end) - g0);
-                        if (grp_a == ~0u) { grp_a = (uint32_t)(g0 >> 6); out_a = sz; }
-                        else if (grp_b == ~0u) { grp_b = (uint32_t)(g0 >> 6); out_b = sz; }
+                    // the groups of 8 queries that BEGIN among this pass's draws (at most 9): each gets its buffer,
+                    // g mod 15, if that is free (chunks are multiples of 64 and this wave's alone: a group is drawn here whole)
+                    const uint64_t first = (r0 + 7ull) & ~7ull;
+                    if (first < pool_next) {
+                        const uint32_t ga = (uint32_t)(first >> 3), gb = (uint32_t)((pool_next - 1ull) >> 3) + 1u;
+                        const uint32_t ga15 = ga % RES_BUFS;
+                        if (lane < RES_BUFS) {
+                            const uint32_t d = lane >= ga15 ? lane - ga15 : lane + RES_BUFS - ga15;
+                            const uint32_t g = ga + d;
+                            if (g < gb && res_state[2u * lane + 1u] == 0u) {
+                                const uint64_t q0 = (uint64_t)g << 3;
+                                res_state[2u * lane] = g;
+                                res_state[2u * lane + 1u] = (uint32_t)((q0 + 8ull < pool_end ? q0 + 8ull : pool_end) - q0);
+                            }
+                        }
                     }
                 }
             }
@@ -633,34 +647,32 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                         reinterpret_cast<ulonglong2 *>(out_lo)[qi] = make_ulonglong2(lo, hi);
                         atomicOr(hit_map + (qi >> 6), 1ull << (qi & 63u));
                     }
-                } else if (CAN_STAGE && stage_out && ((uint32_t)(q >> 6) == grp_a || (uint32_t)(q >> 6) == grp_b)) {
-                    results[((uint32_t)(q >> 6) == grp_b ? 64u : 0u) + ((uint32_t)q & 63u)] =
-                        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-                } else if (pairs) {
-                    reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
                 } else {
-                    out_lo[q] = lo;
-                    out_up[q] = hi;
+                    const uint32_t g32 = (uint32_t)(q >> 3), rb = g32 % RES_BUFS;
+                    if (CAN_STAGE && stage_out && res_state[2u * rb] == g32) {
+                        results[rb * 8u + ((uint32_t)q & 7u)] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                        last_in = atomicSub(&res_state[2u * rb + 1u], 1u) == 1u;  // (LDS: ds_add_rtn_u32)
+                    } else if (pairs) {
+                        reinterpret_cast<ulonglong2 *>(out_lo)[q] = make_ulonglong2(lo, hi);
+                    } else {
+                        out_lo[q] = lo;
+                        out_up[q] = hi;
+                    }
                 }
                 has_q = false;
             }
             if (CAN_STAGE && stage_out) {
-                // a buffer whose 64th result has just come in leaves as one contiguous store (1 KB of pairs; 512 B each
-                // of lower and upper)
-                const bool fin = alive && done;
-                const uint32_t gq = (uint32_t)(q >> 6);
-                const uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && gq == grp_a));
-                const uint32_t nb = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && gq == grp_b));
-#pragma unroll
-                for (uint32_t bsel = 0; bsel < 2u; ++bsel) {
-                    uint32_t &grp = bsel ? grp_b : grp_a, &out = bsel ? out_b : out_a;
-                    const uint32_t n = bsel ? nb : na;
-                    if (grp == ~0u || n == 0u) continue;
-                    out -= n;
-                    if (out != 0u) continue;
-                    const size_t qq = ((size_t)grp << 6) + lane;
-                    if (qq < Qs) {
-                        const uint4 v = results[bsel * 64u + lane];
+                // the buffers whose last result has just come in: lanes 0..7 store the line whole (pairs), or its 64
+                // bytes of lower and of upper
+                uint64_t fm = __builtin_amdgcn_ballot_w64(last_in);
+                while (fm != 0ull) {
+                    const int src = __builtin_ctzll(fm);
+                    fm &= fm - 1ull;
+                    // (q still names the query that has just ended)
+                    const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 3), src), bsel = g % RES_BUFS;
+                    const size_t qq = ((size_t)g << 3) + lane;
+                    if (lane < 8u && qq < Qs) {
+                        const uint4 v = results[bsel * 8u + lane];
                         const uint64_t vlo = ((uint64_t)v.y << 32) | v.x, vhi = ((uint64_t)v.w << 32) | v.z;
                         if (pairs) {
                             reinterpret_cast<ulonglong2 *>(out_lo)[qq] = make_ulonglong2(vlo, vhi);
@@ -669,7 +681,6 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                             out_up[qq] = vhi;
                         }
                     }
-                    grp = ~0u;
                 }
             }
             if (COUNT_WORK) ++passes;
