@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""How fast the service loop answers `ExactMatch` / `Reads` requests (find_reads + ReplyReads, csrc/service_slice.cpp;
+reference: src/service/service.cpp:714-797,1260-1291): P suffix partitions of a synthetic read collection held by one
+process, N requests pushed into the in-process transport, the loop run to the end of input, the replies popped and
+counted (2 per request and partition: forward strand, reverse complement).  Queries: substrings of reads, a third each
+shorter than min_read_length (every read containing the query: query()), of min..max (tiles of min_read_length as exact
+reads + query()), and whole reads + flanks (tiles of both lengths: query_exactmatch()).
+usage: tools/service_reads_probe.py [requests=20000] [partitions=4] [genome=300000] [coverage=8]   -> one JSON line"""
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import readserver_amd as rsb  # noqa: E402
+
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+GENOME = int(float(sys.argv[3])) if len(sys.argv) > 3 else 300000
+COV = float(sys.argv[4]) if len(sys.argv) > 4 else 8.0
+READ_LEN, MINL, MAXL = 100, 73, 100  # the reference's defaults (service.cpp:56-57)
+L = rsb.lib()
+
+
+def varint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def request(q):  # Request{t = ExactMatch(2), rt = Reads(2), q}
+    b = q.encode()
+    return b"\x08\x02\x10\x02\x1a" + varint(len(b)) + b
+
+
+with tempfile.TemporaryDirectory() as td:
+    kw = dict(seed=77, genome_len=GENOME, haplotypes=8, snp_rate=0.002, read_len=READ_LEN, coverage=COV)
+    shards, reads = [], []
+    for s in range(P):
+        p, rd = os.path.join(td, f"s{s}.bwt"), os.path.join(td, f"s{s}.reads")
+        rsb.synth_popbwt(p, rd, shard=s, num_shards=P, **kw)
+        shards.append(rsb.GpuBWT(p, for_reads=True))
+        reads += open(rd).read().split()
+    rng = np.random.default_rng(5)
+    qs = []
+    for i in range(N):
+        r = reads[int(rng.integers(len(reads)))]
+        kind = i % 3
+        if kind == 0:
+            k = int(rng.integers(25, MINL))
+            st = int(rng.integers(0, len(r) - k + 1))
+            qs.append(r[st:st + k])
+        elif kind == 1:
+            k = int(rng.integers(MINL, MAXL))
+            st = int(rng.integers(0, len(r) - k + 1))
+            qs.append(r[st:st + k])
+        else:
+            qs.append("".join("ACGT"[x] for x in rng.integers(0, 4, 10)) + r + "".join("ACGT"[x] for x in rng.integers(0, 4, 10)))
+    ss = rsb.ShardSet(shards)
+    tr, svc = C.c_void_p(), C.c_void_p()
+    assert L.rsbwt_transport_inproc(C.byref(tr)) == 0
+    assert L.rsbwt_service_create(ss._s, tr, 2000, 4096, 1, C.byref(svc)) == 0
+    L.rsbwt_service_set_reads(svc, 1, MINL, MAXL)
+    if P == 4:
+        suf = (C.c_char_p * 4)(b"A", b"C", b"G", b"T")
+        assert L.rsbwt_service_set_suffixes(svc, suf, 4) == 0
+    msgs = [request(q) for q in qs]
+    for w in msgs:
+        buf = (C.c_uint8 * len(w)).from_buffer_copy(w)
+        assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
+    L.rsbwt_transport_close(tr)
+    t0 = time.time()
+    assert L.rsbwt_service_run(svc) == 0
+    dt = time.time() - t0
+    cap = 1 << 24
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t()
+    replies = nbytes = 0
+    while L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == 0:
+        replies += 1
+        nbytes += n.value
+    st = (C.c_uint64 * 6)()
+    L.rsbwt_service_stats(svc, st)
+    print(json.dumps({"requests": N, "partitions": P, "reads_in_the_collection": len(reads), "read_length": READ_LEN,
+                      "min_read_length": MINL, "max_read_length": MAXL, "seconds": round(dt, 4), "requests_per_s": round(N / dt, 1),
+                      "replies": replies, "replies_expected": 2 * P * N, "reply_bytes": nbytes,
+                      "reply_MB_per_s": round(nbytes / dt / 1e6, 1), "windows": int(st[2]),
+                      "queries": "a third shorter than min_read_length, a third of min..max, a third whole reads with 10-base flanks"}))
+    L.rsbwt_service_free(svc)
+    L.rsbwt_transport_free(tr)
+    ss.close()
+    for g in shards:
+        g.close()
+    sys.exit(0 if replies == 2 * P * N else 1)
