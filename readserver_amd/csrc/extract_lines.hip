@@ -45,7 +45,7 @@ namespace rsb {
 constexpr int XWG_WAVES = RSB_WALK_WG_WAVES;
 
 
-// Hands rows to the lanes that have none.  A wave draws chunks of ROW_CHUNK consecutive rows from the
+// Hands rows to the lanes that have none.  A wave draws chunks of `chunk` (at most ROW_CHUNK) consecutive rows from the
 // global counter (one atomic per chunk, not per pass: the atomic's round trip would otherwise sit in
 // front of every pass's line fetch) and gives the next one to whichever lane is free.
 constexpr uint32_t ROW_CHUNK = 256;
@@ -54,16 +54,16 @@ struct row_pool {
     bool drained = false;
 };
 __device__ __forceinline__ bool draw_row(bool want, unsigned long long *pool, size_t n, uint32_t lane, row_pool &rp,
-                                         size_t *row) {
+                                         size_t *row, uint32_t chunk) {
     const uint64_t mask = __builtin_amdgcn_ballot_w64(want);
     if (mask == 0ull) return false;
     if (rp.next >= rp.end && !rp.drained) {
         unsigned long long c = 0;
-        if (lane == 0u) c = atomicAdd(pool, (unsigned long long)ROW_CHUNK);
+        if (lane == 0u) c = atomicAdd(pool, (unsigned long long)chunk);
         c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
             __builtin_amdgcn_readfirstlane((uint32_t)c);
         rp.next = c;
-        rp.end = c + ROW_CHUNK < n ? c + ROW_CHUNK : n;
+        rp.end = c + chunk < n ? c + chunk : n;
         if (c >= n) {
             rp.drained = true;
             rp.next = rp.end = 0;
@@ -92,7 +92,7 @@ template <bool COUNT_WORK>
 __global__ void __launch_bounds__(64 * XWG_WAVES, RSB_WALK_MIN_WGS)
 extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
                            size_t n, uint8_t *__restrict__ out_all, uint32_t stride, uint32_t *__restrict__ plen_all,
-                           unsigned long long *__restrict__ pools, unsigned long long *__restrict__ work) {
+                           unsigned long long *__restrict__ pools, unsigned long long *__restrict__ work, uint32_t row_chunk) {
     __shared__ uint4 s_stage[XWG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
@@ -141,7 +141,7 @@ extract_prefix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshar
     uint32_t chars = 0, q1 = 0, q2 = 0, q3 = 0;  // (chars doubles as q0)
     for (;;) {
         size_t nr = 0;
-        if (draw_row(!have, pool, n, lane, rp, &nr)) {
+        if (draw_row(!have, pool, n, lane, rp, &nr, row_chunk)) {
             r = (uint32_t)nr;
             idx = rows[r];
             len = 0;
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(64 * XWG_WAVES, RSB_WALK_MIN_WGS)
 extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ rows_all,
                             size_t n, uint8_t *__restrict__ out_all, uint32_t stride, const uint32_t *__restrict__ plen_all,
                             uint32_t *__restrict__ tlen_all, unsigned long long *__restrict__ pools,
-                            unsigned long long *__restrict__ work) {
+                            unsigned long long *__restrict__ work, uint32_t row_chunk) {
     __shared__ uint4 s_stage[XWG_WAVES][64 * SLOT_U4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = s_stage[wave];
@@ -374,7 +374,7 @@ extract_postfix_wave_kernel(const shard_view *__restrict__ shards, uint32_t nsha
     uint32_t word = 0, w1 = 0, w2 = 0, w3 = 0;
     for (;;) {
         size_t nr = 0;
-        if (draw_row(!have, pool, n, lane, rp, &nr)) {
+        if (draw_row(!have, pool, n, lane, rp, &nr, row_chunk)) {
             r = (uint32_t)nr;
             idx = rows[r];
             const uint32_t pl = plen[r];
@@ -784,12 +784,18 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
     const size_t cap = (size_t)num_cus * wgs_per_cu;
     if (g > cap) g = cap;
     if (g >= nshards) g -= g % nshards;  // (every shard starts with as many workgroups as any other)
+    // rows per draw from a shard's counter: ROW_CHUNK for a launch that fills the chip, fewer for a small one so that
+    // every wave launched draws twice or more (until round 5 a call of a few hundred rows -- the rows of a service
+    // window's intervals -- gave all of them to the first wave that asked: 242 rows took four walks one after the other,
+    // 1.24 ms, tools/probe_setquery.py)
+    uint32_t row_chunk = ROW_CHUNK;
+    while (row_chunk > 1u && (size_t)row_chunk * g * XWG_WAVES * 2u > total) row_chunk >>= 1;
     if (d_work)
         hipLaunchKernelGGL(extract_prefix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
-                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work, row_chunk);
     else
         hipLaunchKernelGGL(extract_prefix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
-                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work);
+                           (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (uint32_t *)d_plen, pool, d_work, row_chunk);
     // (the row buffers of the shards lie back to back: one launch moves every prefix)
     if ((stride & 15u) == 0u && ((uintptr_t)d_out & 15u) == 0u)
         hipLaunchKernelGGL(move_prefix16_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, (uint8_t *)d_out, stride,
@@ -800,11 +806,11 @@ hipError_t launch_extract_wave(scratch_cache &scratch, const shard_view *d_shard
     if (d_work)
         hipLaunchKernelGGL(extract_postfix_wave_kernel<true>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
-                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS);
+                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS, row_chunk);
     else
         hipLaunchKernelGGL(extract_postfix_wave_kernel<false>, dim3((unsigned)g), dim3(64 * XWG_WAVES), 0, stream, d_shards, nshards,
                            (const uint64_t *)d_rows, n, (uint8_t *)d_out, stride, (const uint32_t *)d_plen, (uint32_t *)d_len,
-                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS);
+                           pool + (size_t)nshards * POOL_STRIDE, d_work + XW_WORDS, row_chunk);
     e = hipGetLastError();
     scratch.give(mem, stream);
     return e;

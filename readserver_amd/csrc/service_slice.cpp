@@ -12,10 +12,15 @@
 // compares it byte for byte with the Python protobuf runtime on a re-typed schema.
 // Transport (ZeroMQ SUB/PUSH, service.cpp:1493-1502) stays with the caller: INTEGRATION.md.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <new>
 #include <string>
 #include <unordered_set>
@@ -307,6 +312,51 @@ void service_reads_empty(const std::vector<service_request> &rq, size_t rows, re
     replies->first[n] = replies->off.size() - 1;
 }
 
+// fn(i) for i in [0, n), on up to 8 threads (the library's entry points are re-entrant: a stream per calling thread):
+// a window's ExactMatch / Reads requests make one engine call per distinct query length -- dozens of small launch
+// sequences, each waiting for its own copy back -- and one per (partition, tile length).  The first error wins.
+template <class F>
+static int for_each_parallel(size_t n, F &&fn) {
+    if (n == 0) return RSBWT_OK;
+    const size_t T = std::min<size_t>({n, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (T <= 1) {
+        for (size_t i = 0; i < n; ++i) {
+            const int rc = fn(i);
+            if (rc != RSBWT_OK) return rc;
+        }
+        return RSBWT_OK;
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{RSBWT_OK};
+    std::vector<std::string> msg(T);
+    auto work = [&](size_t t) {
+        for (size_t i = next.fetch_add(1); i < n && err.load(std::memory_order_relaxed) == RSBWT_OK; i = next.fetch_add(1)) {
+            int rc;
+            try {
+                rc = fn(i);
+            } catch (...) {
+                rc = RSBWT_ENOMEM;
+            }
+            if (rc != RSBWT_OK) {
+                int none = RSBWT_OK;
+                if (err.compare_exchange_strong(none, rc)) msg[t] = rsbwt_last_error();  // (thread-local: carried over below)
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    try {
+        for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+    } catch (...) {  // no more threads to be had: the ones that started and this one do the work
+    }
+    work(0);
+    for (auto &t : th) t.join();
+    const int rc = err.load();
+    if (rc != RSBWT_OK)
+        for (const std::string &m : msg)
+            if (!m.empty()) return fail(rc, "%s", m.c_str());
+    return rc;
+}
+
 int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq, bool per_partition, const reads_config &cfg,
                         reply_arena *replies, std::vector<char> *handled) {
     const size_t n = rq.size(), S = rsbwt_set_size(set);
@@ -346,6 +396,11 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
         replies->first.assign(n + 1, 0);
         return RSBWT_OK;
     }
+    // RSBWT_SERVICE_TIMING: a line per window on stderr with what its phases took (diagnosis, tools/README.md)
+    static const bool timing = getenv("RSBWT_SERVICE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = timing ? now() : 0.0;
+    double t_tiles = 0, t_exact = 0, t_query = 0;
     // ---- the tiles (service.cpp:755-764,773-794): MAX-long ones of a query of MAX or more, then MIN-long ones (of any
     // query longer than MIN; not again when MIN == MAX).  A tile is looked up in the partitions whose suffix it ends
     // with; query_exactmatch (query.cpp:102-120) says whether it is a read there.  One batched call per (partition, length).
@@ -374,22 +429,32 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
             }
         }
     }
+    if (timing) t_tiles = now();
     std::vector<std::vector<std::pair<size_t, std::pair<size_t, std::string>>>> hits(jobs.size());  // job -> (seq, (shard, tile))
-    for (auto &g : by_shard_len) {
-        const size_t p = g.first.first, T = g.first.second, m = g.second.size();
-        if (T == 0 || m == 0) continue;
-        std::string flat(m * T, 'N');
-        for (size_t j = 0; j < m; ++j) memcpy(&flat[j * T], g.second[j].tile.data(), T);
-        std::vector<uint8_t> found(m, 0);
-        const int rc = rsbwt_query_exactmatch(rsbwt_set_shard(set, p), flat.data(), m, (uint32_t)T, T, found.data());
+    {
+        // the (partition, tile length) groups side by side; what each found is merged afterwards (a job's tiles may
+        // sit in several groups)
+        std::vector<std::pair<const std::pair<size_t, size_t>, std::vector<cand_t>> *> groups;
+        for (auto &g : by_shard_len) groups.push_back(&g);
+        std::vector<std::vector<uint8_t>> found(groups.size());
+        const int rc = for_each_parallel(groups.size(), [&](size_t gi) -> int {
+            const size_t p = groups[gi]->first.first, T = groups[gi]->first.second, m = groups[gi]->second.size();
+            if (T == 0 || m == 0) return RSBWT_OK;
+            std::string flat(m * T, 'N');
+            for (size_t j = 0; j < m; ++j) memcpy(&flat[j * T], groups[gi]->second[j].tile.data(), T);
+            found[gi].assign(m, 0);
+            return rsbwt_query_exactmatch(rsbwt_set_shard(set, p), flat.data(), m, (uint32_t)T, T, found[gi].data());
+        });
         if (rc != RSBWT_OK) return rc;
-        for (size_t j = 0; j < m; ++j)
-            if (found[j]) hits[g.second[j].job].push_back({g.second[j].seq, {p, g.second[j].tile}});
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (size_t j = 0; j < found[gi].size(); ++j)
+                if (found[gi][j]) hits[groups[gi]->second[j].job].push_back({groups[gi]->second[j].seq, {groups[gi]->first.first, groups[gi]->second[j].tile}});
     }
     for (size_t ji = 0; ji < jobs.size(); ++ji) {
         std::sort(hits[ji].begin(), hits[ji].end(), [](const auto &a, const auto &b) { return a.first < b.first; });
         for (auto &h : hits[ji]) jobs[ji].tiles[h.second.first].push_back(std::move(h.second.second));
     }
+    if (timing) t_exact = now();
     // ---- the reads that CONTAIN w: query() for MIN <= |w| < MAX (service.cpp:767; query.cpp:87-100), the interval's
     // rows for |w| < MIN (service.cpp:718-753).  One batched call per query length over all partitions.
     std::map<size_t, std::vector<size_t>> by_len;
@@ -397,7 +462,11 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
         const size_t sz = jobs[ji].w.size();
         if (sz != 0 && sz < MAXL) by_len[sz].push_back(ji);
     }
-    for (auto &g : by_len) {
+    std::vector<std::pair<const size_t, std::vector<size_t>> *> len_groups;
+    for (auto &g : by_len) len_groups.push_back(&g);
+    // (a job has one length: the groups write into jobs of their own)
+    const int rc_len = for_each_parallel(len_groups.size(), [&](size_t gi) -> int {
+        auto &g = *len_groups[gi];
         const size_t k = g.first, m = g.second.size();
         std::string flat(m * k, 'N');
         for (size_t j = 0; j < m; ++j) memcpy(&flat[j * k], jobs[g.second[j]].w.data(), k);
@@ -406,15 +475,18 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
         uint32_t stride = (uint32_t)std::max<size_t>(256, (2 * MAXL + 63) & ~(size_t)15);
         std::vector<char> reads;
         std::vector<uint32_t> rlen, rshard;
+        size_t room = 16 * m + 256;  // reads the buffers hold: one call answers when they fit, else it says how many there are
         for (int attempt = 0;; ++attempt) {
-            int rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), nullptr, nullptr, stride, nullptr, 0, &nreads);
-            if (rc != RSBWT_OK && rc != RSBWT_ERANGE) return rc;
-            if (nreads == 0) break;
-            reads.assign(nreads * (size_t)stride, 0);
-            rlen.assign(nreads, 0);
-            rshard.assign(nreads, 0);
-            rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), rshard.data(), reads.data(), stride, rlen.data(), nreads, &nreads);
+            int rc = RSBWT_ERANGE;
+            for (int sized = 0; sized < 2 && rc == RSBWT_ERANGE; ++sized) {
+                reads.assign(room * (size_t)stride, 0);
+                rlen.assign(room, 0);
+                rshard.assign(room, 0);
+                rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), rshard.data(), reads.data(), stride, rlen.data(), room, &nreads);
+                if (rc == RSBWT_ERANGE && nreads > room) room = nreads;
+            }
             if (rc != RSBWT_OK) return rc;
+            if (nreads == 0) break;
             bool over = false;
             for (size_t r = 0; r < nreads && !over; ++r) over = rlen[r] == 0xFFFFFFFFu;
             if (!over || attempt == 2) break;
@@ -438,7 +510,10 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
                 }
             }
         }
-    }
+        return RSBWT_OK;
+    });
+    if (rc_len != RSBWT_OK) return rc_len;
+    if (timing) t_query = now();
     // ---- Reply bytes: request by request, partition by partition (or all partitions' lists joined, shard 0's first),
     // forward then reverse complement
     const size_t rows = per_partition ? S : 1;
@@ -480,6 +555,9 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
         ji += 2;
     }
     replies->first[n] = replies->off.size() - 1;
+    if (timing)
+        fprintf(stderr, "rsbwt reads window: %zu requests, tiles %.1f ms, exact-match calls %.1f (%zu groups), query calls %.1f (%zu lengths), replies %.1f ms (%zu bytes)\n",
+                jobs.size() / 2, t_tiles - t_begin, t_exact - t_tiles, by_shard_len.size(), t_query - t_exact, by_len.size(), now() - t_query, total);
     return RSBWT_OK;
 }
 

@@ -914,6 +914,34 @@ int rsbwt_set_hits_1mm(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, 
     return guarded("rsbwt_set_hits_1mm", [&]() -> int { return rsbwt_set_hits_1mm_body(s, kmers, Q, k, stride, hits, cap, first, nhits); });
 }
 
+// The group's shard views WITH the shards' select samples, for the fused extraction (extract_lines.hip: ONE launch sequence
+// walks the rows of every shard of the group): an array of its own (d_xviews), made on the first call from the shards'
+// extraction views -- the array the searches read (d_views) is not touched, so an extraction may start beside searches
+// on the same set.
+static int ensure_group_xviews(rsbwt_set_t *s, dev_group *g, hipStream_t stream) {
+    if (g->xviews_ready.load(std::memory_order_acquire)) return RSBWT_OK;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (g->xviews_ready.load(std::memory_order_relaxed)) return RSBWT_OK;
+    std::vector<shard_view> v;
+    for (size_t i : g->idx) {
+        rsbwt_t *h = s->shards[i];
+        if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
+        const int rc = ensure_samples(h, stream);
+        if (rc != RSBWT_OK) return rc;
+        v.push_back(h->xview);
+    }
+    shard_view *dx = nullptr;
+    HIP_OK(hipMalloc(&dx, v.size() * sizeof(shard_view)));
+    const hipError_t e = hipMemcpy(dx, v.data(), v.size() * sizeof(shard_view), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dx);
+        return fail_hip(e, "publishing the extraction views");
+    }
+    g->d_xviews = dx;
+    g->xviews_ready.store(true, std::memory_order_release);
+    return RSBWT_OK;
+}
+
 // row i = SA row rows[i] of shard shard_of[i]
 static int rsbwt_set_extract_body(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *rows, size_t n, char *out,
                                   uint32_t stride, uint32_t *len, uint32_t *prefix_len) {
@@ -926,8 +954,62 @@ static int rsbwt_set_extract_body(rsbwt_set_t *s, const uint32_t *shard_of, cons
         if (shard_of[i] >= S) return fail(RSBWT_EINVAL, "row %zu names shard %u of %zu", i, shard_of[i], S);
         where[shard_of[i]].push_back(i);
     }
+    static const bool turns_only = getenv("RSBWT_SET_EXTRACT_TURNS") != nullptr;  // A/B knob (tools/README.md): a launch sequence per shard
     return for_each_group(s, [&](size_t gi) -> int {
         dev_group *g = s->groups[gi];
+        // The rows of all the group's shards in ONE launch sequence (the fused extraction bench.py --mode extract times):
+        // [S_g][nmax] rows, a shard with fewer padded with rows past any index (they end at once).  What a window of the
+        // service loop asks for -- a few hundred rows spread over the partitions -- then costs one walk's latency, not
+        // one per partition (round 5; until then a launch sequence and a copy back per shard).
+        const size_t Sg = g->idx.size();
+        size_t nmax = 0, ng = 0;
+        for (size_t si : g->idx) {
+            nmax = std::max(nmax, where[si].size());
+            ng += where[si].size();
+        }
+        if (ng == 0) return RSBWT_OK;
+        if (!turns_only && Sg > 1 && nmax < (1ull << 31) && Sg * nmax <= 4 * ng + 4096) {
+            int rc = use_device(g->device);
+            if (rc) return rc;
+            call_ctx *c = g->pool.acquire();
+            if (!c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+            struct release_t {
+                dev_group *g;
+                call_ctx *c;
+                ~release_t() { g->pool.release(c); }
+            } release{g, c};
+            hipStream_t st = c->st[0];
+            if ((rc = ensure_group_xviews(s, g, st)) != RSBWT_OK) return rc;
+            const size_t cells = Sg * nmax;
+            const size_t a_rows = (cells * 8 + 255) & ~(size_t)255, a_out = (cells * (size_t)stride + 255) & ~(size_t)255, a_u32 = (cells * 4 + 255) & ~(size_t)255;
+            if ((rc = c->stage(a_rows + a_out + 2 * a_u32)) != RSBWT_OK) return rc;
+            uint8_t *d_rows = (uint8_t *)c->d_stage, *d_out = d_rows + a_rows, *d_len = d_out + a_out, *d_pl = d_len + a_u32;
+            std::vector<uint64_t> hr(cells, ~0ull);
+            for (size_t j = 0; j < Sg; ++j) {
+                const std::vector<size_t> &w = where[g->idx[j]];
+                for (size_t t = 0; t < w.size(); ++t) hr[j * nmax + t] = rows[w[t]];
+            }
+            HIP_OK(hipMemcpyAsync(d_rows, hr.data(), cells * 8, hipMemcpyHostToDevice, st));
+            const hipError_t e = launch_extract_wave(g->scratch, g->d_xviews, (uint32_t)Sg, d_rows, nmax, d_out, stride, d_pl, d_len, g->num_cus, st, nullptr);
+            if (e != hipSuccess) return fail_hip(e, "extract kernel launch");
+            std::vector<char> ho(cells * (size_t)stride);
+            std::vector<uint32_t> hl(cells), hp(cells);
+            HIP_OK(hipMemcpyAsync(ho.data(), d_out, cells * (size_t)stride, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(hl.data(), d_len, cells * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(hp.data(), d_pl, cells * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            for (size_t j = 0; j < Sg; ++j) {
+                const std::vector<size_t> &w = where[g->idx[j]];
+                for (size_t t = 0; t < w.size(); ++t) {
+                    const size_t cell = j * nmax + t;
+                    const uint32_t keep = hl[cell] == 0xFFFFFFFFu ? 0u : hl[cell];
+                    if (keep) memcpy(out + w[t] * (size_t)stride, ho.data() + cell * (size_t)stride, keep);
+                    if (len) len[w[t]] = hl[cell];
+                    if (prefix_len) prefix_len[w[t]] = hp[cell];
+                }
+            }
+            return RSBWT_OK;
+        }
         for (size_t si : g->idx) {
             const std::vector<size_t> &w = where[si];
             if (w.empty()) continue;
@@ -962,52 +1044,47 @@ static int rsbwt_set_query_body(rsbwt_set_t *s, const char *kmers, size_t Q, uin
     *nreads = 0;
     if (Q == 0) return RSBWT_OK;
     if (!kmers) return fail(RSBWT_EINVAL, "null argument");
+    if (read_stride == 0) return fail(RSBWT_EINVAL, "read_stride must be positive");
     const size_t S = s->shards.size();
-    struct part_t {
-        std::vector<uint64_t> first;
-        std::vector<char> reads;
-        std::vector<uint32_t> len;
-    };
-    std::vector<part_t> part(S);
-    const bool sizing = cap_reads == 0;  // the caller only wants the number: nothing is extracted
-    int rc = for_each_group(s, [&](size_t gi) -> int {
-        dev_group *g = s->groups[gi];
-        for (size_t i : g->idx) {
-            part_t &p = part[i];
-            p.first.assign(Q + 1, 0);
-            size_t n = 0;
-            int r = rsbwt_query(s->shards[i], kmers, Q, k, stride, p.first.data(), nullptr, read_stride, nullptr, 0, &n);
-            if (r != RSBWT_OK && r != RSBWT_ERANGE) return r;
-            if (n == 0 || sizing) continue;
-            p.reads.resize(n * (size_t)read_stride);
-            p.len.resize(n);
-            r = rsbwt_query(s->shards[i], kmers, Q, k, stride, p.first.data(), p.reads.data(), read_stride, p.len.data(), n, &n);
-            if (r) return r;
-        }
+    if (k == 0) {  // (rsbwt_query: no rows)
+        for (size_t q = 0; q <= Q; ++q) first[q] = 0;
         return RSBWT_OK;
-    });
+    }
+    // ONE search of the batch over all the shards (a fused launch per device), then ONE extraction of the intervals' rows
+    // addressed as (shard, row) in the order the caller gets them.  (Until round 5 every shard ran rsbwt_query by itself,
+    // twice -- to size, then to fetch: 2 S searches and S extractions, each a launch sequence with a copy back of its
+    // own; a window of the service loop makes one such call per distinct query length.)
+    std::vector<uint64_t> lo(S * Q), up(S * Q);
+    int rc = rsbwt_set_find_intervals_body(s, kmers, Q, k, stride, lo.data(), up.data());
     if (rc) return rc;
+    // rows of shard i for k-mer q: its interval, if it is one of rows of that shard (rsbwt_query's rule: capi.hip, interval_rows)
+    auto width = [&](size_t i, size_t q) -> uint64_t {
+        const uint64_t l = lo[i * Q + q], u = up[i * Q + q];
+        return (l <= u && u < s->shards[i]->view.n) ? u - l + 1 : 0;
+    };
     size_t total = 0;
     for (size_t q = 0; q < Q; ++q) {
         first[q] = total;
-        for (size_t i = 0; i < S; ++i) total += (size_t)(part[i].first[q + 1] - part[i].first[q]);
+        for (size_t i = 0; i < S; ++i) total += (size_t)width(i, q);
     }
     first[Q] = total;
     *nreads = total;
     if (total > cap_reads) return fail(RSBWT_ERANGE, "%zu reads over the set, room for %zu", total, cap_reads);
-    if (total && (!reads || !read_len)) return fail(RSBWT_EINVAL, "null argument");
+    if (total == 0) return RSBWT_OK;
+    if (!reads || !read_len) return fail(RSBWT_EINVAL, "null argument");
+    std::vector<uint32_t> shard_of(total);
+    std::vector<uint64_t> rows(total);
     size_t at = 0;
     for (size_t q = 0; q < Q; ++q)
         for (size_t i = 0; i < S; ++i) {
-            const part_t &p = part[i];
-            for (uint64_t r = p.first[q]; r < p.first[q + 1]; ++r, ++at) {
-                const uint32_t ln = p.len[r];
-                if (ln != 0xFFFFFFFFu && ln) memcpy(reads + at * (size_t)read_stride, p.reads.data() + r * (size_t)read_stride, ln);
-                read_len[at] = ln;
-                if (read_shard) read_shard[at] = (uint32_t)i;
+            const uint64_t w = width(i, q), l = lo[i * Q + q];
+            for (uint64_t r = 0; r < w; ++r, ++at) {
+                shard_of[at] = (uint32_t)i;
+                rows[at] = l + r;
             }
         }
-    return RSBWT_OK;
+    if (read_shard) memcpy(read_shard, shard_of.data(), total * sizeof(uint32_t));
+    return rsbwt_set_extract_body(s, shard_of.data(), rows.data(), total, reads, read_stride, read_len, nullptr);
 }
 int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
                     uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
@@ -1164,31 +1241,7 @@ int rsbwt_set_extract_dev(rsbwt_set_t *s, const void *d_rows, size_t n, void *d_
     }
     int rc = use_device(g->device);
     if (rc) return rc;
-    // ONE launch sequence walks the rows of every shard (extract_lines.hip: a wave walks one shard at a time) off views
-    // that name the shards' select samples: an array of its own (d_xviews), made on the first call from the shards'
-    // extraction views -- the array the searches read (d_views) is not touched, so an extraction may start beside
-    // searches on the same set
-    if (!g->xviews_ready.load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> lock(s->mu);
-        if (!g->xviews_ready.load(std::memory_order_relaxed)) {
-            std::vector<shard_view> v;
-            for (size_t i = 0; i < S; ++i) {
-                rsbwt_t *h = s->shards[i];
-                if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index");
-                if ((rc = ensure_samples(h, (hipStream_t)stream)) != RSBWT_OK) return rc;
-                v.push_back(h->xview);
-            }
-            shard_view *dx = nullptr;
-            HIP_OK(hipMalloc(&dx, v.size() * sizeof(shard_view)));
-            const hipError_t e = hipMemcpy(dx, v.data(), v.size() * sizeof(shard_view), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                (void)hipFree(dx);
-                return fail_hip(e, "publishing the extraction views");
-            }
-            g->d_xviews = dx;
-            g->xviews_ready.store(true, std::memory_order_release);
-        }
-    }
+    if ((rc = ensure_group_xviews(s, g, (hipStream_t)stream)) != RSBWT_OK) return rc;
     unsigned long long *work = nullptr;
     if (g->counting) {  // rsbwt_set_set_counting: the walk kernels' counters over all shards, read with rsbwt_set_last_search_counters
         work = g->d_work;

@@ -75,26 +75,44 @@ with tempfile.TemporaryDirectory() as td:
         suf = (C.c_char_p * 4)(b"A", b"C", b"G", b"T")
         assert L.rsbwt_service_set_suffixes(svc, suf, 4) == 0
     msgs = [request(q) for q in qs]
-    for w in msgs:
-        buf = (C.c_uint8 * len(w)).from_buffer_copy(w)
-        assert L.rsbwt_transport_push_request(tr, buf, len(w)) == 0
-    L.rsbwt_transport_close(tr)
+    threaded = os.environ.get("PROBE_ONE_THREAD") is None  # the loop as a pipeline (receiver, window workers, ordered sender): rsbwt_service_start
+    if threaded:
+        L.rsbwt_service_set_workers(svc, 8)
+        assert L.rsbwt_service_start(svc) == 0
+    flat = np.frombuffer(b"".join(msgs), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in msgs])]).astype(np.uint64)
     t0 = time.time()
-    assert L.rsbwt_service_run(svc) == 0
-    dt = time.time() - t0
-    cap = 1 << 24
+    for i0 in range(0, N, 512):  # the in-process transport in bulk, as tools/service_bench.cpp
+        m = min(512, N - i0)
+        o = (offs[i0:i0 + m + 1] - offs[i0]).astype(np.uint64)
+        assert L.rsbwt_transport_push_requests(tr, C.c_void_p(flat.ctypes.data + int(offs[i0])), C.c_void_p(o.ctypes.data), m) == 0
+    cap = 1 << 26
     buf = (C.c_uint8 * cap)()
     n = C.c_size_t()
     replies = nbytes = 0
-    while L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == 0:
-        replies += 1
-        nbytes += n.value
+    if threaded:
+        roff = np.zeros(8193, np.uint64)
+        while replies < 2 * P * N:
+            if L.rsbwt_transport_pop_replies(tr, 0, buf, cap, C.c_void_p(roff.ctypes.data), 8192, C.byref(n), 30_000_000) != 0 or n.value == 0:
+                break
+            replies += n.value
+            nbytes += int(roff[n.value])
+        dt = time.time() - t0
+        L.rsbwt_transport_close(tr)
+        L.rsbwt_service_stop(svc)
+    else:
+        L.rsbwt_transport_close(tr)
+        assert L.rsbwt_service_run(svc) == 0
+        dt = time.time() - t0
+        while L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == 0:
+            replies += 1
+            nbytes += n.value
     st = (C.c_uint64 * 6)()
     L.rsbwt_service_stats(svc, st)
     print(json.dumps({"requests": N, "partitions": P, "reads_in_the_collection": len(reads), "read_length": READ_LEN,
                       "min_read_length": MINL, "max_read_length": MAXL, "seconds": round(dt, 4), "requests_per_s": round(N / dt, 1),
                       "replies": replies, "replies_expected": 2 * P * N, "reply_bytes": nbytes,
-                      "reply_MB_per_s": round(nbytes / dt / 1e6, 1), "windows": int(st[2]),
+                      "reply_MB_per_s": round(nbytes / dt / 1e6, 1), "windows": int(st[2]), "loop": "pipeline, 8 window workers" if threaded else "rsbwt_service_run on one thread",
                       "queries": "a third shorter than min_read_length, a third of min..max, a third whole reads with 10-base flanks"}))
     L.rsbwt_service_free(svc)
     L.rsbwt_transport_free(tr)
