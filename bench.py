@@ -624,29 +624,31 @@ def run_exact(a, c, mix, steps, warmup, headline):
     single = None
     if headline and S > 1 and not a.no_single_check:
         g0 = shards[0]
-        lo1 = torch.empty(Q, dtype=torch.int64, device=dev)
-        up1 = torch.empty(Q, dtype=torch.int64, device=dev)
+        pr1 = torch.empty((Q, 2), dtype=torch.int64, device=dev)  # {lower, upper} pairs, as the headline's launch writes them
         ok(c, L.rsbwt_set_counting(g0.handle, 1))
-        ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+        ok(c, L.rsbwt_find_interval_pairs_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr1), sp))
         torch.cuda.synchronize()
         w1 = (C.c_uint64 * 16)()
         ok(c, L.rsbwt_last_search_counters(g0.handle, w1))
         ok(c, L.rsbwt_set_counting(g0.handle, 0))
         for _ in range(2):
-            ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+            ok(c, L.rsbwt_find_interval_pairs_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr1), sp))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n1 = 10
         for _ in range(n1):
-            ok(c, L.rsbwt_find_intervals_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(lo1), ptr(up1), sp))
+            ok(c, L.rsbwt_find_interval_pairs_dev(g0.handle, ptr(d_packed), ptr(d_valid), Q, k, ptr(pr1), sp))
         torch.cuda.synchronize()
         d1 = (time.perf_counter() - t1) / n1
         b1 = (C.c_float * 64)()
         ok(c, L.rsbwt_search_history_ms(g0.handle, b1, n1, C.byref(cnt)))
         km1 = float(np.mean(list(b1[:cnt.value])))
         single = {"searches_per_s": Q / d1, "kernel": search_kernel_name(1, int(g0.getBWLen()), g0.ktab_depth(), g0.window_span()), "kernel_ms": km1, "mean_lf_steps_per_search": w1[0] / Q,
-                  "roofline_frac": (w1[2] * LINE_BYTES + Q * SEARCH_BYTES) / (km1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del lo1, up1
+                  "roofline_frac": (w1[2] * LINE_BYTES + Q * SEARCH_BYTES) / (km1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "what": "shard 0 of the resident set alone, behind the SET's table (its share of the 8 shards' interleaved tables): the "
+                          "one-shard kernel on the headline's data, not configs[1]'s own line -- `python bench.py --shards-per-gpu 1` sizes a "
+                          "table for one shard (plain 16-mer: a step less per search) and is profiles/rNN_bench_1shard.json"}
+        del pr1
 
     res = {
         "mix": mix, "value": value, "queries_per_s_all_shards": value / (world * S), "ms_per_step": ms_per_step,
