@@ -419,6 +419,15 @@ int rsbwt_set_extract(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *
 int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
                     uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
                     size_t *nreads);
+/* Queries of LENGTHS OF THEIR OWN in one call: query q = text[off[q] .. off[q+1]) (off has Q + 1 entries).  What a window of
+ * the service loop holds -- the reference answers each request with its own findInterval (src/service/service.cpp:303,
+ * src/bwt/query.cpp:24-41), whatever its length -- without a launch sequence per distinct length.  Results as
+ * rsbwt_set_find_intervals / rsbwt_set_count / rsbwt_set_query give them for the queries of one length; an empty query,
+ * one with a symbol outside ACGT or one longer than 65,535 symbols ends as the empty interval (1, 0) / count 0 / no reads. */
+int rsbwt_set_find_intervals_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *lower, uint64_t *upper);
+int rsbwt_set_count_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *counts);
+int rsbwt_set_query_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *first, uint32_t *read_shard,
+                        char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads);
 /* Device-resident forms, for a set on ONE device (one process per GPU: bench.py --mode 1mm|extract).
  * d_hits [num_shards][cap_per_shard] x 32-byte records (rsbwt_hits_1mm_dev's), d_totals u64[num_shards];
  * d_rows [num_shards][n] (row numbers are per shard), d_out [num_shards][n][stride], d_len / d_prefix_len [num_shards][n]. */

@@ -163,6 +163,9 @@ SIGNATURES = {
     "rsbwt_set_extract": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp]),
     "rsbwt_set_query": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_size_t, _vp, _vp, _vp, C.c_uint32, _vp, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
+    "rsbwt_set_find_intervals_var": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "rsbwt_set_count_var": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "rsbwt_set_query_var": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsbwt_set_hits_1mm_scratch_bytes": (C.c_size_t, [_vp, C.c_size_t, C.c_uint32]),
     "rsbwt_set_hits_1mm_is_fused": (C.c_int, [_vp, C.c_size_t, C.c_uint32]),
     "rsbwt_set_hits_1mm_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp, _vp, _vp]),

@@ -379,6 +379,48 @@ class ShardSet:
         check(lib().rsbwt_set_count(self._s, _ptr(a), a.shape[0], k, max(k, 1), _ptr(out)))
         return out
 
+    # -- queries of lengths of their own in one call (a window of the service loop): rsbwt_set_*_var
+    @staticmethod
+    def _var_text(queries):
+        bs = [q if isinstance(q, (bytes, bytearray)) else str(q).encode() for q in queries]
+        off = np.zeros(len(bs) + 1, np.uint64)
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        text = np.frombuffer(b"".join(bs) + b"\0", np.uint8).copy()
+        return text, off
+
+    def find_intervals_var(self, queries):
+        text, off = self._var_text(queries)
+        Q, S = len(queries), len(self.shards)
+        lower = np.empty((S, Q), np.uint64)
+        upper = np.empty((S, Q), np.uint64)
+        check(lib().rsbwt_set_find_intervals_var(self._s, _ptr(text), _ptr(off), Q, _ptr(lower), _ptr(upper)))
+        return lower, upper
+
+    def count_var(self, queries):
+        text, off = self._var_text(queries)
+        out = np.empty(len(queries), np.uint64)
+        check(lib().rsbwt_set_count_var(self._s, _ptr(text), _ptr(off), len(queries), _ptr(out)))
+        return out
+
+    def query_var(self, queries, read_stride=256):
+        """per query: [(shard, read)] of every read containing it, shard 0's first (rsbwt_set_query_var)"""
+        text, off = self._var_text(queries)
+        Q = len(queries)
+        first = np.zeros(Q + 1, np.uint64)
+        n = C.c_size_t()
+        rc = lib().rsbwt_set_query_var(self._s, _ptr(text), _ptr(off), Q, _ptr(first), None, None, read_stride, None, 0, C.byref(n))
+        if rc not in (0, -7):
+            check(rc)
+        total = n.value
+        reads = np.zeros((max(total, 1), read_stride), np.uint8)
+        ln = np.zeros(max(total, 1), np.uint32)
+        sh = np.zeros(max(total, 1), np.uint32)
+        if total:
+            check(lib().rsbwt_set_query_var(self._s, _ptr(text), _ptr(off), Q, _ptr(first), _ptr(sh), _ptr(reads), read_stride, _ptr(ln), total, C.byref(n)))
+            if (ln[:total] == 0xFFFFFFFF).any():
+                raise RsbwtError(-1, "a read does not fit read_stride")
+        return [[(int(sh[r]), reads[r, :ln[r]].tobytes().decode()) for r in range(int(first[q]), int(first[q + 1]))] for q in range(Q)]
+
     # -- BASELINE configs[3] / configs[4] over the set: per-shard results side by side, the way the front-end
     # concatenates its partitions' replies (src/service/server.cpp:199-261)
     def hits_1mm(self, kmers):

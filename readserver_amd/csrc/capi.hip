@@ -1003,6 +1003,63 @@ int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views
     if (prev.m && (rc = collect(prev)) != RSBWT_OK) return rc;
     return RSBWT_OK;
 }
+
+// The same for queries of LENGTHS OF THEIR OWN: query q = text[off[q] .. off[q+1]) (search_lines.hip, search_init_var_kernel:
+// a start record says where its search goes on).  lower / upper [nshards][Q]; an empty query, one with a symbol outside
+// ACGT or one longer than 65,535 symbols ends as (1, 0) / count 0.
+int search_host_views_var(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
+                          const char *text, const uint64_t *off, size_t Q, uint64_t *lower, uint64_t *upper, bool counts_only,
+                          bool narrow) {
+    ctx_guard g(pool);
+    if (!g.c) return fail(RSBWT_EHIP, "cannot create a HIP stream");
+    hipStream_t st = g.c->st[0];
+    const size_t SLICE = 1u << 16;
+    std::vector<uint64_t> rel;
+    for (size_t q0 = 0; q0 < Q; q0 += SLICE) {
+        const size_t mq = std::min(SLICE, Q - q0);
+        uint64_t kmax = 0;
+        for (size_t i = 0; i < mq; ++i) {
+            if (off[q0 + i + 1] < off[q0 + i]) return fail(RSBWT_EINVAL, "query %zu: its end lies before its start", q0 + i);
+            const uint64_t n = off[q0 + i + 1] - off[q0 + i];
+            if (n <= 65535ull) kmax = std::max(kmax, n);  // (a longer one is refused by the packing: it does not size the batch)
+        }
+        if (kmax == 0) {  // nothing to search in this slice
+            for (uint32_t s = 0; s < nshards; ++s)
+                for (size_t i = 0; i < mq; ++i) {
+                    lower[s * Q + q0 + i] = counts_only ? 0 : 1;
+                    if (!counts_only) upper[s * Q + q0 + i] = 0;
+                }
+            continue;
+        }
+        const uint32_t k = (uint32_t)kmax, wpq = words_per_kmer(k);
+        const size_t tb = (size_t)(off[q0 + mq] - off[q0]);
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t a_text = al(tb + 16), a_off = al((mq + 1) * 8), a_pk = al(mq * wpq * 8), a_ok = al(mq), a_len = al(mq * 4),
+                     a_rec = al((size_t)nshards * mq * 16), a_res = al((size_t)nshards * mq * 8);
+        int rc;
+        if ((rc = g.c->stage(a_text + a_off + a_pk + a_ok + a_len + a_rec + 2 * a_res)) != RSBWT_OK) return rc;
+        uint8_t *d_text = (uint8_t *)g.c->d_stage, *d_off = d_text + a_text, *d_pk = d_off + a_off, *d_ok = d_pk + a_pk, *d_len = d_ok + a_ok,
+                *d_rec = d_len + a_len, *d_lo = d_rec + a_rec, *d_up = d_lo + a_res;
+        rel.resize(mq + 1);
+        for (size_t i = 0; i <= mq; ++i) rel[i] = off[q0 + i] - off[q0];
+        if (tb) HIP_OK(hipMemcpyAsync(d_text, text + off[q0], tb, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_off, rel.data(), (mq + 1) * 8, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_pack_var(d_text, d_off, mq, wpq, d_pk, d_ok, d_len, st);
+        if (e != hipSuccess) return fail_hip(e, "pack kernel launch");
+        e = launch_search_init_var(d_views, nshards, d_pk, d_ok, d_len, mq, wpq, d_rec, st);
+        if (e != hipSuccess) return fail_hip(e, "start-record kernel launch");
+        search_extra ex;
+        ex.narrow = narrow;
+        ex.d_init = d_rec;
+        if ((rc = search_launch(m, d_views, nshards, num_cus, d_pk, d_ok, mq, k, d_lo, d_up, counts_only, st, &ex)) != RSBWT_OK) return rc;
+        for (uint32_t s = 0; s < nshards; ++s) {
+            HIP_OK(hipMemcpyAsync(lower + s * Q + q0, d_lo + (size_t)s * mq * 8, mq * 8, hipMemcpyDeviceToHost, st));
+            if (!counts_only) HIP_OK(hipMemcpyAsync(upper + s * Q + q0, d_up + (size_t)s * mq * 8, mq * 8, hipMemcpyDeviceToHost, st));
+        }
+        HIP_OK(hipStreamSynchronize(st));  // (rel and the staging buffer are used again by the next slice)
+    }
+    return RSBWT_OK;
+}
 }  // namespace rsb
 
 static int search_host(rsbwt_t *h, const char *kmers, size_t Q, uint32_t k, size_t stride,

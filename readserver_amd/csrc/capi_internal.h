@@ -62,6 +62,9 @@ int search_launch(search_meter &m, const shard_view *d_views, uint32_t nshards, 
 int search_host_views(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
                       const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *lower, uint64_t *upper,
                       bool counts_only, bool narrow = false);
+int search_host_views_var(search_meter &m, ctx_pool &pool, const shard_view *d_views, uint32_t nshards, int num_cus,
+                          const char *text, const uint64_t *off, size_t Q, uint64_t *lower, uint64_t *upper, bool counts_only,
+                          bool narrow = false);
 // search_extra::narrow for a launch on this shard: a T-mer's interval is ~ n / 4^T rows wide;
 // a quarter of a window or less = the steps after the table find both positions in one line
 inline bool view_is_narrow(const shard_view &v, uint32_t k) {

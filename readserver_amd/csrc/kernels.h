@@ -80,6 +80,12 @@ struct search_extra {
 // the start-record kernel alone: d_init[s * Q + q] for every (query, shard) search of a batch
 hipError_t launch_search_init(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t Q,
                               uint32_t k, void *d_init, hipStream_t stream);
+// queries of lengths of their own (search_lines.hip, search_init_var_kernel): the packing of `text` cut at off[0..Q] into wpq
+// words per query + validity + lengths, and the start records [nshards][Q] a search launch then takes as search_extra::d_init
+hipError_t launch_pack_var(const void *d_text, const void *d_off, size_t Q, uint32_t wpq, void *d_packed, void *d_valid, void *d_len,
+                           hipStream_t stream);
+hipError_t launch_search_init_var(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
+                                  const void *d_len, size_t Q, uint32_t wpq, void *d_init, hipStream_t stream);
 hipError_t launch_search(scratch_cache &scratch, const shard_view *d_shards, uint32_t nshards, const void *d_packed,
                          const void *d_valid, size_t Q, uint32_t k, void *d_lower, void *d_upper, bool counts_only,
                          unsigned long long *d_work, int num_cus, hipStream_t stream, hipEvent_t ev0 = nullptr,

@@ -48,6 +48,42 @@ __global__ void pack_kernel(const uint8_t *__restrict__ kmers, size_t Q, uint32_
     }
 }
 
+// Queries of lengths of their own, one after the other in `text` (query q = bytes off[q] .. off[q+1]): packed from word
+// q * wpq on (wpq words hold the batch's longest), len[q] = its length, valid[q] = 0 for an empty one, one with a symbol
+// outside ACGT (service.cpp:299: the callers' find_first_not_of("ACGT")) or one longer than 65,535.  A thread per query.
+__global__ void pack_var_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ off, size_t Q, uint32_t wpq,
+                                uint64_t *__restrict__ packed, uint8_t *__restrict__ valid, uint32_t *__restrict__ len) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = gid; q < Q; q += nthreads) {
+        const uint8_t *s = text + off[q];
+        const uint64_t n64 = off[q + 1] - off[q];
+        const bool fits = n64 != 0ull && n64 <= 65535ull && n64 <= 32ull * wpq;
+        const uint32_t n = fits ? (uint32_t)n64 : 0u;
+        bool ok = fits;
+        for (uint32_t w = 0; w < wpq; ++w) {
+            uint64_t word = 0;
+            const uint32_t base = w * 32u;
+            const uint32_t m = base >= n ? 0u : ((n - base) < 32u ? (n - base) : 32u);
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint8_t ch = s[base + i];
+                uint32_t code;
+                switch (ch) {
+                case 'A': code = 0; break;
+                case 'C': code = 1; break;
+                case 'G': code = 2; break;
+                case 'T': code = 3; break;
+                default: code = 0; ok = false; break;
+                }
+                word |= (uint64_t)code << (2u * i);
+            }
+            packed[q * wpq + w] = word;
+        }
+        valid[q] = ok ? 1 : 0;
+        len[q] = n;
+    }
+}
+
 // Dense input (stride == k): a workgroup's 256 k-mers are one contiguous byte range; it is
 // read with aligned 16-byte loads into LDS and packed from there.
 __global__ void __launch_bounds__(256)
@@ -592,6 +628,14 @@ hipError_t launch_pack(const void *d_kmers, size_t Q, uint32_t k, size_t stride,
         hipLaunchKernelGGL(pack_kernel, dim3(grid_for(256, Q, 8192)), dim3(256), 0, stream,
                            (const uint8_t *)d_kmers, Q, k, stride, wpq, (uint64_t *)d_packed,
                            (uint8_t *)d_valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_var(const void *d_text, const void *d_off, size_t Q, uint32_t wpq, void *d_packed, void *d_valid, void *d_len,
+                           hipStream_t stream) {
+    if (Q == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_var_kernel, dim3(grid_for(64, Q, 16384)), dim3(64), 0, stream, (const uint8_t *)d_text, (const uint64_t *)d_off, Q,
+                       wpq, (uint64_t *)d_packed, (uint8_t *)d_valid, (uint32_t *)d_len);
     return hipGetLastError();
 }
 

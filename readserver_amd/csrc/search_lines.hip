@@ -35,6 +35,8 @@ namespace rsb {
 constexpr uint64_t INIT_INVALID = 1ull << 63;   // symbol outside ACGT: result (1, 0)
 constexpr uint64_t INIT_FALLBACK = 1ull << 62;  // not from the k-mer table: continue at symbol k-2
 constexpr uint64_t INIT_EXPLICIT = 1ull << 61;  // continue at the symbol named in bits 40..55 (1-mismatch variants)
+constexpr uint64_t INIT_NOCHECK = 1ull << 60;   // (with INIT_EXPLICIT) an initInterval: the reference looks at it only after its first update (query.cpp:33-37)
+constexpr uint64_t INIT_VAR = 1ull << 59;       // (with INIT_EXPLICIT) a query of a length of its own: bits 40..55 hold the next symbol's index + 1 (0: none left)
 
 __device__ __forceinline__ ulonglong2 start_record(const shard_view &ix, const uint64_t *pq, uint32_t k) {
     ulonglong2 rec;
@@ -79,6 +81,52 @@ search_init_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
         rec.y = 0;
     } else {
         rec = start_record(shards[s], packed + q * wpq, k);
+    }
+    init[s * Q + q] = rec;
+}
+
+// Start records of a batch whose queries have LENGTHS OF THEIR OWN (len[q] symbols, packed from word q * wpq on): what
+// the service loop's windows hold -- the reference answers a request of any length up to the front-end's limit, and a
+// launch per distinct length is a launch sequence and a copy back per length (75 of them in a window of 4,096 reads
+// requests).  A record says where ITS search goes on (INIT_EXPLICIT | INIT_VAR: bits 40..55 = index of
+// the next symbol + 1): from the k-mer table entry of the query's last T symbols when it has that many, else from
+// initInterval (INIT_NOCHECK: not looked at before its first update, query.cpp:33-37); the search kernels take such
+// records up as they take a resumed 1-mismatch variant's.
+__global__ void __launch_bounds__(256)
+search_init_var_kernel(const shard_view *__restrict__ shards, uint32_t nshards, const uint64_t *__restrict__ packed,
+                       const uint8_t *__restrict__ valid, const uint32_t *__restrict__ len, size_t Q, uint32_t wpq,
+                       ulonglong2 *__restrict__ init) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * nshards) return;
+    const size_t q = i / nshards, s = i - q * nshards;
+    const uint32_t L = len[q];
+    ulonglong2 rec;
+    if (valid[q] == 0 || L == 0u) {
+        rec.x = INIT_INVALID;
+        rec.y = 0;
+    } else {
+        const shard_view &ix = shards[s];
+        const uint64_t *pq = packed + q * wpq;
+        bool tabulated = false;
+        if (view_uses_ktab(ix, L)) {
+            const uint32_t T = ix.ktab_depth;
+            const uint32_t off = 2u * (L - T);
+            const uint32_t w0 = off >> 6, sh = off & 63u;
+            uint64_t bits = pq[w0] >> sh;
+            if (sh + 2u * T > 64u) bits |= pq[w0 + 1u] << (64u - sh);
+            const uint64_t e = ktab_entry(ix.ktab, ix.ktab_fmt, T, ix.ktab_stride, bits & ((1ull << (2u * T)) - 1ull));
+            const uint32_t width = (uint32_t)(e >> COUNT_BITS);
+            if (width != KTAB_WIDE && (e & COUNT_MASK) + width <= ix.n) {  // (start_record's rule)
+                rec.x = (e & COUNT_MASK) | ((uint64_t)(L - T) << COUNT_BITS) | INIT_EXPLICIT | INIT_VAR;  // next symbol: L - T - 1
+                rec.y = (e & COUNT_MASK) + width - 1ull;
+                tabulated = true;
+            }
+        }
+        if (!tabulated) {  // initInterval, query.cpp:18-21; next symbol: L - 2
+            const uint32_t b = (uint32_t)((pq[(L - 1u) >> 5] >> (2u * ((L - 1u) & 31u))) & 3u) + 1u;
+            rec.x = ix.C[b] | ((uint64_t)(L - 1u) << COUNT_BITS) | INIT_EXPLICIT | INIT_VAR | INIT_NOCHECK;
+            rec.y = ix.C[b] + ix.total[b] - 1ull;
+        }
     }
     init[s * Q + q] = rec;
 }
@@ -335,12 +383,13 @@ search_lines_kernel(const shard_view *__restrict__ shards, uint32_t nshards, con
                     hi = 0;
                     j = -1;
                     done = true;
-                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search
+                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search, or a query of a length of its own (INIT_VAR)
                     lo = nrec.x & COUNT_MASK;
                     hi = nrec.y;
-                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull) - ((nrec.x & INIT_VAR) ? 1 : 0);
                     word = nword;
-                    done = lo > hi;  // the shared suffix was already absent (query.cpp:35-37)
+                    // the shared suffix was already absent (query.cpp:35-37); an initInterval is not looked at (INIT_NOCHECK)
+                    done = j < 0 || ((nrec.x & INIT_NOCHECK) == 0ull && lo > hi);
                     if (LONGK) {
                         if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
                     }
@@ -714,6 +763,15 @@ static void launch_init(const shard_view *d_shards, uint32_t nshards, const uint
         hipLaunchKernelGGL(search_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, d_shards, nshards, pk, vd, Q, k,
                            wpq, init);
     }
+}
+
+hipError_t launch_search_init_var(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid,
+                                  const void *d_len, size_t Q, uint32_t wpq, void *d_init, hipStream_t stream) {
+    if (Q == 0 || nshards == 0) return hipSuccess;
+    const size_t nrec = Q * nshards;
+    hipLaunchKernelGGL(search_init_var_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, d_shards, nshards,
+                       (const uint64_t *)d_packed, (const uint8_t *)d_valid, (const uint32_t *)d_len, Q, wpq, (ulonglong2 *)d_init);
+    return hipGetLastError();
 }
 
 hipError_t launch_search_init(const shard_view *d_shards, uint32_t nshards, const void *d_packed, const void *d_valid, size_t Q,

@@ -235,12 +235,12 @@ search_solo_kernel(const shard_view *__restrict__ shards, uint32_t nshards, cons
                     hi = 0;
                     j = -1;
                     done = true;
-                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search
+                } else if (nrec.x & INIT_EXPLICIT) {  // a 1-mismatch variant resuming its k-mer's search, or a query of a length of its own (INIT_VAR: search_lines.hip)
                     lo = nrec.x & COUNT_MASK;
                     hi = nrec.y;
-                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull);
+                    j = (int)((nrec.x >> COUNT_BITS) & 0xFFFFull) - ((nrec.x & INIT_VAR) ? 1 : 0);
                     word = nword;
-                    done = lo > hi;
+                    done = j < 0 || ((nrec.x & INIT_NOCHECK) == 0ull && lo > hi);
                     if (LONGK) {
                         if (!done && ((uint32_t)j >> 5) != w_table) word = packed[q * wpq + ((uint32_t)j >> 5)];
                     }

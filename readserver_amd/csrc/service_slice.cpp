@@ -173,6 +173,45 @@ int service_count_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
     // per request: [strand][shard] counts (one row when summed)
     const size_t rows = per_partition ? S : 1;
     std::vector<std::vector<uint64_t>> cnt(n);
+    // A window whose requests have lengths of their own (what a front-end sends: any length up to its limit): ONE search
+    // of all of them, both strands -- forward queries, then their reverse complements (rsbwt_set_find_intervals_var /
+    // rsbwt_set_count_var: a start record per search says where it goes on).  A window of one length keeps the
+    // fixed-length call (its summed form reduces over RCCL on a set of several devices).
+    if (by_len.size() > 1) {
+        std::vector<size_t> who;
+        for (size_t i = 0; i < n; ++i)
+            if ((*handled)[i]) {
+                cnt[i].assign(2 * rows, 0);
+                if (!rq[i].q.empty()) who.push_back(i);  // (empty query: count 0, findInterval on "" is undefined in the reference)
+            }
+        const size_t m = who.size();
+        std::string text;
+        std::vector<uint64_t> off(2 * m + 1, 0);
+        for (size_t j = 0; j < m; ++j) {
+            text += rq[who[j]].q;
+            off[j + 1] = text.size();
+        }
+        for (size_t j = 0; j < m; ++j) {
+            text += rev_comp(rq[who[j]].q.data(), rq[who[j]].q.size());
+            off[m + j + 1] = text.size();
+        }
+        if (m != 0 && per_partition) {
+            std::vector<uint64_t> lo(S * 2 * m), up(S * 2 * m);
+            const int rc = rsbwt_set_find_intervals_var(set, text.data(), off.data(), 2 * m, lo.data(), up.data());
+            if (rc != RSBWT_OK) return rc;
+            for (size_t s = 0; s < S; ++s)
+                for (size_t j = 0; j < 2 * m; ++j) {
+                    const uint64_t l = lo[s * 2 * m + j], u = up[s * 2 * m + j];
+                    cnt[who[j % m]][(j / m) * rows + s] = u >= l ? u - l + 1 : 0;  // service.cpp:304
+                }
+        } else if (m != 0) {
+            std::vector<uint64_t> c(2 * m);
+            const int rc = rsbwt_set_count_var(set, text.data(), off.data(), 2 * m, c.data());
+            if (rc != RSBWT_OK) return rc;
+            for (size_t j = 0; j < 2 * m; ++j) cnt[who[j % m]][j / m] = c[j];
+        }
+        by_len.clear();
+    }
     for (auto &g : by_len) {
         const size_t k = g.first, m = g.second.size();
         for (size_t j = 0; j < m; ++j) cnt[g.second[j]].assign(2 * rows, 0);
@@ -456,20 +495,27 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
     }
     if (timing) t_exact = now();
     // ---- the reads that CONTAIN w: query() for MIN <= |w| < MAX (service.cpp:767; query.cpp:87-100), the interval's
-    // rows for |w| < MIN (service.cpp:718-753).  One batched call per query length over all partitions.
-    std::map<size_t, std::vector<size_t>> by_len;
+    // rows for |w| < MIN (service.cpp:718-753).
+    // The jobs' queries have lengths of their own: rsbwt_set_query_var answers a slice of them in ONE search + ONE
+    // extraction (until round 5: a call per distinct length, 75 of them in a window of 4,096 requests).  Slices of 2,048
+    // jobs, side by side on the worker's threads.
+    std::vector<std::vector<size_t>> slices;
     for (size_t ji = 0; ji < jobs.size(); ++ji) {
         const size_t sz = jobs[ji].w.size();
-        if (sz != 0 && sz < MAXL) by_len[sz].push_back(ji);
+        if (sz == 0 || sz >= MAXL) continue;
+        if (slices.empty() || slices.back().size() >= 2048) slices.emplace_back();
+        slices.back().push_back(ji);
     }
-    std::vector<std::pair<const size_t, std::vector<size_t>> *> len_groups;
-    for (auto &g : by_len) len_groups.push_back(&g);
-    // (a job has one length: the groups write into jobs of their own)
-    const int rc_len = for_each_parallel(len_groups.size(), [&](size_t gi) -> int {
-        auto &g = *len_groups[gi];
-        const size_t k = g.first, m = g.second.size();
-        std::string flat(m * k, 'N');
-        for (size_t j = 0; j < m; ++j) memcpy(&flat[j * k], jobs[g.second[j]].w.data(), k);
+    // (the slices write into jobs of their own)
+    const int rc_len = for_each_parallel(slices.size(), [&](size_t gi) -> int {
+        const std::vector<size_t> &members = slices[gi];
+        const size_t m = members.size();
+        std::string flat;
+        std::vector<uint64_t> qoff(m + 1, 0);
+        for (size_t j = 0; j < m; ++j) {
+            flat += jobs[members[j]].w;
+            qoff[j + 1] = flat.size();
+        }
         std::vector<uint64_t> first(m + 1, 0);
         size_t nreads = 0;
         uint32_t stride = (uint32_t)std::max<size_t>(256, (2 * MAXL + 63) & ~(size_t)15);
@@ -482,7 +528,7 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
                 reads.assign(room * (size_t)stride, 0);
                 rlen.assign(room, 0);
                 rshard.assign(room, 0);
-                rc = rsbwt_set_query(set, flat.data(), m, (uint32_t)k, k, first.data(), rshard.data(), reads.data(), stride, rlen.data(), room, &nreads);
+                rc = rsbwt_set_query_var(set, flat.data(), qoff.data(), m, first.data(), rshard.data(), reads.data(), stride, rlen.data(), room, &nreads);
                 if (rc == RSBWT_ERANGE && nreads > room) room = nreads;
             }
             if (rc != RSBWT_OK) return rc;
@@ -493,7 +539,8 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
             stride = attempt == 0 ? 4096u : 65536u;  // a read longer than the buffer (none in a collection built for these lengths): once more, wider
         }
         for (size_t j = 0; j < m && nreads; ++j) {
-            job_t &jb = jobs[g.second[j]];
+            job_t &jb = jobs[members[j]];
+            const size_t k = jb.w.size();
             // this query's reads arrive shard by shard (shard 0's first), each shard's in SA-row order
             std::vector<size_t> begin_of(S + 1, 0);
             for (uint64_t r = first[j]; r < first[j + 1]; ++r) begin_of[rshard[r] + 1]++;
@@ -556,8 +603,8 @@ int service_reads_batch(rsbwt_set_t *set, const std::vector<service_request> &rq
     }
     replies->first[n] = replies->off.size() - 1;
     if (timing)
-        fprintf(stderr, "rsbwt reads window: %zu requests, tiles %.1f ms, exact-match calls %.1f (%zu groups), query calls %.1f (%zu lengths), replies %.1f ms (%zu bytes)\n",
-                jobs.size() / 2, t_tiles - t_begin, t_exact - t_tiles, by_shard_len.size(), t_query - t_exact, by_len.size(), now() - t_query, total);
+        fprintf(stderr, "rsbwt reads window: %zu requests, tiles %.1f ms, exact-match calls %.1f (%zu groups), query calls %.1f (%zu slices), replies %.1f ms (%zu bytes)\n",
+                jobs.size() / 2, t_tiles - t_begin, t_exact - t_tiles, by_shard_len.size(), t_query - t_exact, slices.size(), now() - t_query, total);
     return RSBWT_OK;
 }
 

@@ -482,6 +482,61 @@ int rsbwt_set_find_intervals(rsbwt_set_t *s, const char *kmers, size_t Q, uint32
     return guarded("rsbwt_set_find_intervals", [&]() -> int { return rsbwt_set_find_intervals_body(s, kmers, Q, k, stride, lower, upper); });
 }
 
+// Queries of lengths of their own: query q = text[off[q] .. off[q+1]) -- a window of the service loop in ONE search
+// (search_lines.hip, search_init_var_kernel).  lower / upper: [num_shards][Q]; an empty query, one with a symbol
+// outside ACGT or one longer than 65,535 symbols ends as (1, 0).
+static int rsbwt_set_find_intervals_var_body(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *lower,
+                                             uint64_t *upper, bool counts_only) {
+    if (!s) return fail(RSBWT_EINVAL, "null set");
+    if (Q == 0) return RSBWT_OK;
+    if (!off || !lower || (!upper && !counts_only) || (!text && off[Q] != off[0])) return fail(RSBWT_EINVAL, "null argument");
+    for (rsbwt_t *h : s->shards)
+        if (h->view.n == 0) return fail(RSBWT_EINVAL, "empty index in the set");
+    uint64_t kmax = 0;
+    for (size_t q = 0; q < Q; ++q)
+        if (off[q + 1] >= off[q] && off[q + 1] - off[q] <= 65535ull) kmax = std::max(kmax, off[q + 1] - off[q]);
+    return for_each_group(s, [&](size_t gi) -> int {
+        dev_group *g = s->groups[gi];
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        const size_t Sg = g->idx.size();
+        const bool narrow = kmax != 0 && group_is_narrow(s, g, (uint32_t)kmax);
+        const bool contiguous = g->idx.back() - g->idx.front() + 1 == Sg;
+        if (contiguous)
+            return search_host_views_var(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, text, off, Q, lower + g->idx.front() * Q,
+                                         counts_only ? nullptr : upper + g->idx.front() * Q, counts_only, narrow);
+        std::vector<uint64_t> lo(Sg * Q), up(counts_only ? 0 : Sg * Q);
+        rc = search_host_views_var(*g, g->pool, g->d_views, (uint32_t)Sg, g->num_cus, text, off, Q, lo.data(), counts_only ? nullptr : up.data(),
+                                   counts_only, narrow);
+        if (rc) return rc;
+        for (size_t j = 0; j < Sg; ++j) {
+            memcpy(lower + g->idx[j] * Q, lo.data() + j * Q, Q * 8);
+            if (!counts_only) memcpy(upper + g->idx[j] * Q, up.data() + j * Q, Q * 8);
+        }
+        return RSBWT_OK;
+    });
+}
+int rsbwt_set_find_intervals_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *lower, uint64_t *upper) {
+    return guarded("rsbwt_set_find_intervals_var", [&]() -> int { return rsbwt_set_find_intervals_var_body(s, text, off, Q, lower, upper, false); });
+}
+// counts[Q] summed over the set's shards (what rsbwt_set_count gives for one length); the sum is made on the host
+int rsbwt_set_count_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *counts) {
+    return guarded("rsbwt_set_count_var", [&]() -> int {
+        if (!s || (!counts && Q)) return fail(RSBWT_EINVAL, "null argument");
+        if (Q == 0) return RSBWT_OK;
+        const size_t S = s->shards.size();
+        std::vector<uint64_t> c(S * Q);
+        const int rc = rsbwt_set_find_intervals_var_body(s, text, off, Q, c.data(), nullptr, true);
+        if (rc) return rc;
+        for (size_t q = 0; q < Q; ++q) {
+            uint64_t t = 0;
+            for (size_t i = 0; i < S; ++i) t += c[i * Q + q];
+            counts[q] = t;
+        }
+        return RSBWT_OK;
+    });
+}
+
 
 // counts[Q] summed over the set's shards, the way the front-end sums per-partition replies
 // (src/service/server.cpp:184-197): per device one fused search + a row sum; the per-device sums
@@ -1035,28 +1090,10 @@ int rsbwt_set_extract(rsbwt_set_t *s, const uint32_t *shard_of, const uint64_t *
     return guarded("rsbwt_set_extract", [&]() -> int { return rsbwt_set_extract_body(s, shard_of, rows, n, out, stride, len, prefix_len); });
 }
 
-// query() of every shard (query.cpp:87-100), k-mer by k-mer: k-mer q's reads are first[q] .. first[q+1],
-// shard 0's first (each shard's in SA-row order), read_shard[r] naming the shard read r came from
-static int rsbwt_set_query_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
-                                uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
-                                size_t *nreads) {
-    if (!s || !nreads || (!first && Q)) return fail(RSBWT_EINVAL, "null argument");
-    *nreads = 0;
-    if (Q == 0) return RSBWT_OK;
-    if (!kmers) return fail(RSBWT_EINVAL, "null argument");
-    if (read_stride == 0) return fail(RSBWT_EINVAL, "read_stride must be positive");
+// what rsbwt_set_query makes of the batch's intervals lo / up [S][Q]: first[], and the rows' reads in the caller's order
+static int set_query_rows(rsbwt_set_t *s, size_t Q, const std::vector<uint64_t> &lo, const std::vector<uint64_t> &up, uint64_t *first,
+                          uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
     const size_t S = s->shards.size();
-    if (k == 0) {  // (rsbwt_query: no rows)
-        for (size_t q = 0; q <= Q; ++q) first[q] = 0;
-        return RSBWT_OK;
-    }
-    // ONE search of the batch over all the shards (a fused launch per device), then ONE extraction of the intervals' rows
-    // addressed as (shard, row) in the order the caller gets them.  (Until round 5 every shard ran rsbwt_query by itself,
-    // twice -- to size, then to fetch: 2 S searches and S extractions, each a launch sequence with a copy back of its
-    // own; a window of the service loop makes one such call per distinct query length.)
-    std::vector<uint64_t> lo(S * Q), up(S * Q);
-    int rc = rsbwt_set_find_intervals_body(s, kmers, Q, k, stride, lo.data(), up.data());
-    if (rc) return rc;
     // rows of shard i for k-mer q: its interval, if it is one of rows of that shard (rsbwt_query's rule: capi.hip, interval_rows)
     auto width = [&](size_t i, size_t q) -> uint64_t {
         const uint64_t l = lo[i * Q + q], u = up[i * Q + q];
@@ -1085,6 +1122,46 @@ static int rsbwt_set_query_body(rsbwt_set_t *s, const char *kmers, size_t Q, uin
         }
     if (read_shard) memcpy(read_shard, shard_of.data(), total * sizeof(uint32_t));
     return rsbwt_set_extract_body(s, shard_of.data(), rows.data(), total, reads, read_stride, read_len, nullptr);
+}
+
+// query() of every shard (query.cpp:87-100), k-mer by k-mer: k-mer q's reads are first[q] .. first[q+1],
+// shard 0's first (each shard's in SA-row order), read_shard[r] naming the shard read r came from
+static int rsbwt_set_query_body(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
+                                uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,
+                                size_t *nreads) {
+    if (!s || !nreads || (!first && Q)) return fail(RSBWT_EINVAL, "null argument");
+    *nreads = 0;
+    if (Q == 0) return RSBWT_OK;
+    if (!kmers) return fail(RSBWT_EINVAL, "null argument");
+    if (read_stride == 0) return fail(RSBWT_EINVAL, "read_stride must be positive");
+    const size_t S = s->shards.size();
+    if (k == 0) {  // (rsbwt_query: no rows)
+        for (size_t q = 0; q <= Q; ++q) first[q] = 0;
+        return RSBWT_OK;
+    }
+    // ONE search of the batch over all the shards (a fused launch per device), then ONE extraction of the intervals' rows
+    // addressed as (shard, row) in the order the caller gets them.  (Until round 5 every shard ran rsbwt_query by itself,
+    // twice -- to size, then to fetch: 2 S searches and S extractions, each a launch sequence with a copy back of its
+    // own; a window of the service loop made one such call per distinct query length.)
+    std::vector<uint64_t> lo(S * Q), up(S * Q);
+    const int rc = rsbwt_set_find_intervals_body(s, kmers, Q, k, stride, lo.data(), up.data());
+    if (rc) return rc;
+    return set_query_rows(s, Q, lo, up, first, read_shard, reads, read_stride, read_len, cap_reads, nreads);
+}
+// the same for queries of lengths of their own (rsbwt_set_find_intervals_var): one call answers a window of the service loop
+int rsbwt_set_query_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *first, uint32_t *read_shard,
+                        char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
+    return guarded("rsbwt_set_query_var", [&]() -> int {
+        if (!s || !nreads || (!first && Q)) return fail(RSBWT_EINVAL, "null argument");
+        *nreads = 0;
+        if (Q == 0) return RSBWT_OK;
+        if (read_stride == 0) return fail(RSBWT_EINVAL, "read_stride must be positive");
+        const size_t S = s->shards.size();
+        std::vector<uint64_t> lo(S * Q), up(S * Q);
+        const int rc = rsbwt_set_find_intervals_var_body(s, text, off, Q, lo.data(), up.data(), false);
+        if (rc) return rc;
+        return set_query_rows(s, Q, lo, up, first, read_shard, reads, read_stride, read_len, cap_reads, nreads);
+    });
 }
 int rsbwt_set_query(rsbwt_set_t *s, const char *kmers, size_t Q, uint32_t k, size_t stride, uint64_t *first,
                     uint32_t *read_shard, char *reads, uint32_t read_stride, uint32_t *read_len, size_t cap_reads,

@@ -68,6 +68,40 @@ int rsbwt_set_query(rsbwt_set_t *, const char *kmers, size_t Q, uint32_t k, size
     *nreads = total;
     return (cap_reads == 0 || total > cap_reads) && total ? RSBWT_ERANGE : RSBWT_OK;
 }
+// (the mixed-length forms: the same made-up reads, keyed on each query's own bytes)
+int rsbwt_set_query_var(rsbwt_set_t *s, const char *text, const uint64_t *off, size_t Q, uint64_t *first, uint32_t *read_shard, char *reads,
+                        uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
+    size_t total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t at = 0;
+        for (size_t q = 0; q < Q; ++q) {
+            uint64_t x = 7;
+            for (uint64_t i = off[q]; i < off[q + 1]; ++i) x = mix(x + (uint8_t)text[i]);
+            first[q] = at;
+            for (size_t sh = 0; sh < g_shards; ++sh) {
+                const size_t cnt = (x % 97 == 0) ? 5000 : (size_t)(mix(x + sh) % 6);
+                for (size_t r = 0; r < cnt; ++r, ++at) {
+                    if (pass == 0 || cap_reads == 0) continue;
+                    const uint64_t y = mix(x + 131 * sh + r);
+                    uint32_t len = (uint32_t)(y % 120);
+                    if (y % 50 == 0 && read_stride < 4096) len = 0xFFFFFFFFu;
+                    read_len[at] = len;
+                    if (read_shard) read_shard[at] = (uint32_t)sh;
+                    if (len != 0xFFFFFFFFu)
+                        for (uint32_t i = 0; i < len; ++i) reads[at * (size_t)read_stride + i] = "ACGT"[(y >> (i % 60)) & 3];
+                }
+            }
+        }
+        first[Q] = at;
+        total = at;
+        if (cap_reads == 0 || total > cap_reads) break;
+    }
+    (void)s;
+    *nreads = total;
+    return (cap_reads == 0 || total > cap_reads) && total ? RSBWT_ERANGE : RSBWT_OK;
+}
+int rsbwt_set_find_intervals_var(rsbwt_set_t *, const char *, const uint64_t *, size_t, uint64_t *, uint64_t *) { return RSBWT_ENODEV; }
+int rsbwt_set_count_var(rsbwt_set_t *, const char *, const uint64_t *, size_t, uint64_t *) { return RSBWT_ENODEV; }
 int rsbwt_set_find_intervals(rsbwt_set_t *, const char *, size_t, uint32_t, size_t, uint64_t *, uint64_t *) { return RSBWT_ENODEV; }
 int rsbwt_set_count(rsbwt_set_t *, const char *, size_t, uint32_t, size_t, uint64_t *) { return RSBWT_ENODEV; }
 const char *rsbwt_last_error(void) { return ""; }

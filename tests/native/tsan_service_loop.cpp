@@ -33,6 +33,14 @@ int rsbwt_set_count(rsbwt_set_t *, const char *, size_t Q, uint32_t, size_t, uin
     for (size_t i = 0; i < Q; ++i) c[i] = 0;
     return RSBWT_OK;
 }
+int rsbwt_set_find_intervals_var(rsbwt_set_t *, const char *, const uint64_t *, size_t Q, uint64_t *lo, uint64_t *up) {
+    for (size_t i = 0; i < PARTS * Q; ++i) { lo[i] = 1; up[i] = 0; }
+    return RSBWT_OK;
+}
+int rsbwt_set_count_var(rsbwt_set_t *, const char *, const uint64_t *, size_t Q, uint64_t *c) {
+    for (size_t i = 0; i < Q; ++i) c[i] = 0;
+    return RSBWT_OK;
+}
 const char *rsbwt_last_error(void) { return ""; }
 rsbwt_t *rsbwt_set_shard(rsbwt_set_t *, size_t i) { return (rsbwt_t *)(uintptr_t)(i + 1); }
 int rsbwt_query_exactmatch(rsbwt_t *, const char *, size_t Q, uint32_t, size_t, uint8_t *found) {
@@ -42,6 +50,19 @@ int rsbwt_query_exactmatch(rsbwt_t *, const char *, size_t Q, uint32_t, size_t, 
 // two 6-base reads per k-mer and partition
 int rsbwt_set_query(rsbwt_set_t *, const char *, size_t Q, uint32_t, size_t, uint64_t *first, uint32_t *read_shard, char *reads,
                     uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
+    const size_t total = Q * PARTS * 2;
+    for (size_t q = 0; q <= Q; ++q) first[q] = q * PARTS * 2;
+    *nreads = total;
+    if (cap_reads < total) return RSBWT_ERANGE;
+    for (size_t r = 0; r < total; ++r) {
+        memcpy(reads + r * (size_t)read_stride, "ACGTAC", 6);
+        read_len[r] = 6;
+        if (read_shard) read_shard[r] = (uint32_t)((r / 2) % PARTS);
+    }
+    return RSBWT_OK;
+}
+int rsbwt_set_query_var(rsbwt_set_t *, const char *, const uint64_t *, size_t Q, uint64_t *first, uint32_t *read_shard, char *reads,
+                        uint32_t read_stride, uint32_t *read_len, size_t cap_reads, size_t *nreads) {
     const size_t total = Q * PARTS * 2;
     for (size_t q = 0; q <= Q; ++q) first[q] = q * PARTS * 2;
     *nreads = total;

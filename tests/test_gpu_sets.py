@@ -697,6 +697,106 @@ def test_gpu_set_hits_1mm_on_bwts_without_terminators(rsb, oracle, fmt):
         g.close()
 
 
+@pytest.mark.parametrize("tables", [0, 6, -6, 10])
+def test_gpu_queries_of_their_own_lengths_in_one_search(rsb, oracle, tables):
+    """rsbwt_set_find_intervals_var / rsbwt_set_count_var / rsbwt_set_query_var: a batch whose queries have lengths of
+    their own -- a window of the service loop -- in ONE search (start records that say where their search goes on,
+    csrc/search_lines.hip search_init_var_kernel).  Every (query, shard) = the oracle's findInterval of that string
+    (query.cpp:24-41): lengths 1 .. 70 and the edges (the table's depth and its neighbours, 32 / 33 / 64 / 65 symbols, an
+    empty query, foreign symbols, a run stream without terminators where an empty initInterval is stepped on); tables:
+    none, plain, grouped, and a depth at which most T-mers of the small shards do not occur.  Then a batch large enough
+    for the one-lane kernel."""
+    L = rsb.lib()
+    streams = []
+    for i, R in enumerate([300000, 40000, 900000]):
+        runs = np.empty(R, np.uint8)
+        assert L.rsbwt_synth_runs_host(runs.ctypes.data, R, 3100 + i) == 0
+        streams.append(runs)
+    streams.append(np.array([66, 97], np.uint8))  # "CCG": no terminator, no A, no T
+    shards = [rsb.GpuBWT(runs=r, ktab_depth=None) for r in streams]
+    oixs = [oracle.from_runs(r) for r in streams]
+    ss = rsb.ShardSet(shards)
+    T = abs(tables)
+    if tables:
+        assert L.rsbwt_set_attach_ktabs_format(ss._s, T, 1 if tables < 0 else 0) == 0
+    rng = np.random.default_rng(tables + 100)
+    acgt = "ACGT"
+    rnd = lambda k: "".join(acgt[x] for x in rng.integers(0, 4, k))
+    # strings that occur: read off shard 2's rows by the oracle
+    texts = []
+    for r in rng.integers(0, oixs[2].bwlen(), 60):
+        try:
+            pre, post = oixs[2].extract(int(r), cap=2000)
+            if len(pre) + len(post) >= 80:
+                texts.append(pre + post)
+        except AssertionError:
+            pass
+    assert len(texts) > 10
+    qs = ["", "A", "C", "G", "T", "N", "ACGTN", "A" * 40, "C" * 33, "CCG" * 9, "GCC" * 7 + "G", "ACGT" * 16, "ACGT" * 16 + "A"]
+    for k in list(range(1, 71)) + [max(T - 1, 1), max(T, 1), T + 1, 31, 32, 33, 63, 64, 65]:
+        qs.append(rnd(k))
+        t = texts[int(rng.integers(len(texts)))]
+        st = int(rng.integers(0, len(t) - k + 1))
+        qs.append(t[st:st + k])
+        qs.append("A" * (k - 1) + "C")
+    def check(qs_):
+        lo, up = ss.find_intervals_var(qs_)
+        cnt = ss.count_var(qs_)
+        want_cnt = np.zeros(len(qs_), np.uint64)
+        for s_, oix in enumerate(oixs):
+            for q_, w in enumerate(qs_):
+                ok_ = len(w) > 0 and all(c in acgt for c in w)
+                e = oix.find_interval(w) if ok_ else (1, 0)
+                assert (int(lo[s_, q_]), int(up[s_, q_])) == e, (tables, s_, q_, w)
+                if e[1] >= e[0]:
+                    want_cnt[q_] += np.uint64((e[1] - e[0] + 1) & (2 ** 64 - 1))
+        assert np.array_equal(cnt, want_cnt)
+    check(qs)
+    check(qs[:1])  # a lone empty query
+    check(["ACGTAC"])
+    # a batch that fills every lane of the launch: >= 262,144 searches per shard set go to the one-lane kernel when the
+    # tables are deep enough for it (tables = 10 on these shards)
+    big = []
+    lens = rng.integers(12, 40, 70000)
+    for k in lens[:35000]:
+        t = texts[int(rng.integers(len(texts)))]
+        st = int(rng.integers(0, len(t) - k + 1))
+        big.append(t[st:st + int(k)])
+    big += [rnd(int(k)) for k in lens[35000:]]
+    lo, up = ss.find_intervals_var(big)
+    by_len = {}
+    for i, w in enumerate(big):
+        by_len.setdefault(len(w), []).append(i)
+    for k, idx in by_len.items():
+        km = np.frombuffer("".join(big[i] for i in idx).encode(), np.uint8).reshape(len(idx), k)
+        for s_, oix in enumerate(oixs):
+            elo, eup = oix.find_intervals(km, nthreads=8)
+            assert np.array_equal(lo[s_, idx], elo) and np.array_equal(up[s_, idx], eup), (tables, k, s_)
+    ss.close()
+    for g in shards:
+        g.close()
+
+
+def test_gpu_reads_of_queries_of_their_own_lengths(rsb, four_shards):
+    """rsbwt_set_query_var: the reads containing each query of a mixed-length batch, partition by partition -- what the
+    fixed-length call (rsbwt_set_query, pinned to the oracle above) gives query by query."""
+    ss, shards, oixs, reads = four_shards
+    rng = np.random.default_rng(8)
+    qs = ["", "ACN", "N" * 12]
+    for k in list(range(6, 60)) * 2:
+        r = reads[int(rng.integers(len(reads)))]
+        st = int(rng.integers(0, len(r) - k + 1))
+        qs.append(r[st:st + k])
+    qs += ["".join("ACGT"[x] for x in rng.integers(0, 4, int(k))) for k in rng.integers(6, 40, 30)]
+    got = ss.query_var(qs, read_stride=96)
+    some = 0
+    for q_, w in enumerate(qs):
+        want = ss.query([w], read_stride=96)[0] if w and "N" not in w else []
+        assert got[q_] == want, (q_, w)
+        some += len(want)
+    assert some > 300
+
+
 @pytest.mark.parametrize("devices", [1, 2])
 def test_gpu_one_process_host_runs_the_benchs_sequence(rsb, oracle, devices, monkeypatch):
     """readserver_amd/onehost.py -- the C++ host's shape, what `bench.py --host cxx` times: per device pack + ONE fused
