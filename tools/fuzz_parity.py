@@ -118,12 +118,25 @@ while time.time() < t_end:
                     e2lo, e2up = oix2.find_intervals(km[:5000], nthreads=8)
                     ok2 = (np.array_equal(slo[0], elo[:5000]) and np.array_equal(sup[0], eup[:5000]) and
                            np.array_equal(slo[1], e2lo) and np.array_equal(sup[1], e2up))
+                    # queries of lengths of their own in one search (rsbwt_set_find_intervals_var): prefixes of the k-mers
+                    vq = [bytes(km[i, :int(rng.integers(1, k + 1))]) for i in range(0, 600)]
+                    vlo, vup = ss.find_intervals_var(vq)
+                    by_l = {}
+                    for i, w_ in enumerate(vq):
+                        by_l.setdefault(len(w_), []).append(i)
+                    ok_v = True
+                    for L_, idx in by_l.items():
+                        arr = np.frombuffer(b"".join(vq[i] for i in idx), np.uint8).reshape(len(idx), L_)
+                        for si_, ox_ in enumerate((oix, oix2)):
+                            a_lo, a_up = ox_.find_intervals(arr, nthreads=8)
+                            ok_v = ok_v and np.array_equal(vlo[si_, idx], a_lo) and np.array_equal(vup[si_, idx], a_up)
+                    ok2 = ok2 and ok_v
                     if Q > 20000:  # the whole batch over the set: both shards behind deep tables = the headline's launch (one lane per search)
                         flo, fup = ss.find_intervals(km)
                         f2lo, f2up = oix2.find_intervals(km, nthreads=8)
                         ok2 = ok2 and (np.array_equal(flo[0], elo) and np.array_equal(fup[0], eup) and np.array_equal(flo[1], f2lo) and np.array_equal(fup[1], f2up))
                         cfg["set_full_batch"] = True
-                    why = [] if ok2 else ["set intervals"]
+                    why = [] if ok2 else ["set intervals" if ok_v else "set find_intervals_var (mixed lengths)"]
                     # configs[3] / configs[4] over the set: every shard's own list / reads, side by side
                     if k <= 40:
                         sh, first = ss.hits_1mm(km[:60])

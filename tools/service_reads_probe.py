@@ -5,7 +5,9 @@ process, N requests pushed into the in-process transport, the loop run to the en
 counted (2 per request and partition: forward strand, reverse complement).  Queries: substrings of reads, a third each
 shorter than min_read_length (every read containing the query: query()), of min..max (tiles of min_read_length as exact
 reads + query()), and whole reads + flanks (tiles of both lengths: query_exactmatch()).
-usage: tools/service_reads_probe.py [requests=20000] [partitions=4] [genome=300000] [coverage=8]   -> one JSON line"""
+usage: tools/service_reads_probe.py [requests=20000] [partitions=4] [genome=300000] [coverage=8]   -> one JSON line
+PROBE_COUNT=1: the same queries as CountReads requests (ReplyCount on the count socket): a window of mixed lengths in
+one search (rsbwt_set_find_intervals_var)."""
 import ctypes as C
 import json
 import os
@@ -38,9 +40,13 @@ def varint(n):
             return bytes(out)
 
 
-def request(q):  # Request{t = ExactMatch(2), rt = Reads(2), q}
+COUNT = os.environ.get("PROBE_COUNT") is not None
+CH = 1 if COUNT else 0  # the count socket / the reads socket (service.cpp:1499-1502,1568)
+
+
+def request(q):  # Request{t = ExactMatch(2), rt = Reads(2), q}; PROBE_COUNT: {t = CountReads(1), rt = Count(1), q}
     b = q.encode()
-    return b"\x08\x02\x10\x02\x1a" + varint(len(b)) + b
+    return (b"\x08\x01\x10\x01\x1a" if COUNT else b"\x08\x02\x10\x02\x1a") + varint(len(b)) + b
 
 
 with tempfile.TemporaryDirectory() as td:
@@ -93,7 +99,7 @@ with tempfile.TemporaryDirectory() as td:
     if threaded:
         roff = np.zeros(8193, np.uint64)
         while replies < 2 * P * N:
-            if L.rsbwt_transport_pop_replies(tr, 0, buf, cap, C.c_void_p(roff.ctypes.data), 8192, C.byref(n), 30_000_000) != 0 or n.value == 0:
+            if L.rsbwt_transport_pop_replies(tr, CH, buf, cap, C.c_void_p(roff.ctypes.data), 8192, C.byref(n), 30_000_000) != 0 or n.value == 0:
                 break
             replies += n.value
             nbytes += int(roff[n.value])
@@ -104,12 +110,12 @@ with tempfile.TemporaryDirectory() as td:
         L.rsbwt_transport_close(tr)
         assert L.rsbwt_service_run(svc) == 0
         dt = time.time() - t0
-        while L.rsbwt_transport_pop_reply(tr, 0, buf, cap, C.byref(n), 1000) == 0:
+        while L.rsbwt_transport_pop_reply(tr, CH, buf, cap, C.byref(n), 1000) == 0:
             replies += 1
             nbytes += n.value
     st = (C.c_uint64 * 6)()
     L.rsbwt_service_stats(svc, st)
-    print(json.dumps({"requests": N, "partitions": P, "reads_in_the_collection": len(reads), "read_length": READ_LEN,
+    print(json.dumps({"request_type": "CountReads -> ReplyCount" if COUNT else "ExactMatch / Reads -> ReplyReads", "requests": N, "partitions": P, "reads_in_the_collection": len(reads), "read_length": READ_LEN,
                       "min_read_length": MINL, "max_read_length": MAXL, "seconds": round(dt, 4), "requests_per_s": round(N / dt, 1),
                       "replies": replies, "replies_expected": 2 * P * N, "reply_bytes": nbytes,
                       "reply_MB_per_s": round(nbytes / dt / 1e6, 1), "windows": int(st[2]), "loop": "pipeline, 8 window workers" if threaded else "rsbwt_service_run on one thread",
