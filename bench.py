@@ -157,11 +157,14 @@ def total(t):
 
 
 def mode_source_sha():
-    """Identifies the kernels a PMC traffic figure of --mode 1mm / extract was measured on: every source under csrc/."""
+    """Identifies the kernels a PMC traffic figure of --mode 1mm / extract was measured on: every device source under
+    csrc/ and the host code that launches it (*.hip, *.h; the service loop, the file readers and the synthesiser -- *.cpp --
+    launch nothing these modes time)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "readserver_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        h.update(open(os.path.join(d, f), "rb").read())
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
