@@ -503,8 +503,8 @@ def _same(got, want):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window_us,max_batch,for_reads", [(5000, 4096, True), (0, 1, False), (300, 7, True)])
-def test_gpu_service_loop_reads_golden_replies(rsb, pb, fixture_bwt, golden_dir, window_us, max_batch, for_reads):
+@pytest.mark.parametrize("window_us,max_batch,for_reads,repeat", [(5000, 4096, True, 1), (0, 1, False, 1), (300, 7, True, 1), (200, 16, True, 12)])
+def test_gpu_service_loop_reads_golden_replies(rsb, pb, fixture_bwt, golden_dir, window_us, max_batch, for_reads, repeat):
     """J1: ExactMatch Requests whose return type is Reads, answered by the loop itself.  The stream is
     service_v1.json's (counts, other types, malformed) with service_reads_v1.json's woven in; one partition = the golden
     fixture, min / max read length 50 / 70 as in the golden file.  Every Reads request must come back on `push` as the
@@ -512,7 +512,10 @@ def test_gpu_service_loop_reads_golden_replies(rsb, pb, fixture_bwt, golden_dir,
     out of the compiled reference, tests/golden/make_service_reads_golden.py) -- byte for byte, in arrival order,
     between the count replies of the same socket; intervals of more than 4,097 rows in find_reads' chunked order; the
     tiles in the reference's container order.  A Reads request with a symbol outside ACGT or an empty query gets two
-    replies with an empty list (this service's rule: include/rsbwt.h).  Shards opened for reads or not: same bytes."""
+    replies with an empty list (this service's rule: include/rsbwt.h).  Shards opened for reads or not: same bytes.
+    repeat = 12: the stream twelve times over in windows of 16 -- hundreds of windows on the loop's eight workers at once,
+    each answering its mixed-length queries in one search and its reads in one fused extraction from threads of its own:
+    every reply still byte for byte, in order."""
     import json
     import threading
     L = rsb.lib()
@@ -526,6 +529,7 @@ def test_gpu_service_loop_reads_golden_replies(rsb, pb, fixture_bwt, golden_dir,
         if i % 2 == 0 and extra:
             stream.append(extra.pop(0))
     stream += extra
+    stream = stream * repeat
     path, _ = fixture_bwt
     g = rsb.GpuBWT(path, for_reads=for_reads)
     ss = rsb.ShardSet([g])
